@@ -1,0 +1,153 @@
+"""ORACLE (test infrastructure only) -- the reference's harness circuits restated as
+(R1CS matrices, instance, witness) tuples (SURVEY.md §8 a-H), plus the synthetic
+"random A*B=C gates" R1CS of SURVEY.md §8d used by bench.py.
+
+Variable numbering follows ark-relations `to_matrices` [ark, from memory]:
+column 0 = One, 1..m0-1 = instance variables in allocation order, then witness
+variables in allocation order.
+"""
+from .protocol import R1CS
+
+SPLITMIX_SEED = 0x706F6C796D617468  # "polymath"
+_M64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed=SPLITMIX_SEED):
+        self.s = seed & _M64
+
+    def next_u64(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & _M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        return z ^ (z >> 31)
+
+    def fr(self, r):
+        """4 draws (limb 0 first) masked to the modulus bit length, rejection."""
+        nb = r.bit_length()
+        while True:
+            v = 0
+            for i in range(4):
+                v |= self.next_u64() << (64 * i)
+            v &= (1 << nb) - 1
+            if v < r:
+                return v
+
+    def below(self, n):
+        return self.next_u64() % n
+
+
+def dummy_circuit(c, a, b):
+    """tests/dummy.rs:20-35 -- witnesses a, b; public c = a*b; one constraint a*b=c."""
+    r = c.r
+    m0, mw = 2, 2
+    A = [[(1, 2)]]      # a = witness 0 -> column m0+0
+    B = [[(1, 3)]]
+    Cm = [[(1, 1)]]     # c = instance 1
+    return R1CS(m0, mw, A, B, Cm), [1, a * b % r], [a % r, b % r]
+
+
+def bench_circuit(c, a, b, num_variables, num_constraints):
+    """benches/bench.rs:38-61 -- witnesses a, b, public c=a*b, num_variables-3 padding
+    witnesses all equal to a; num_constraints-1 copies of a*b=c plus one empty row."""
+    r = c.r
+    m0 = 2
+    mw = 2 + (num_variables - 3)
+    A = [[(1, 2)] for _ in range(num_constraints - 1)] + [[]]
+    B = [[(1, 3)] for _ in range(num_constraints - 1)] + [[]]
+    Cm = [[(1, 1)] for _ in range(num_constraints - 1)] + [[]]
+    wit = [a % r, b % r] + [a % r] * (num_variables - 3)
+    return R1CS(m0, mw, A, B, Cm), [1, a * b % r], wit
+
+
+def mimc_circuit(c, xl, xr, constants):
+    """tests/mimc.rs:46-61 (native) and :74-143 (constraints), MIMC_ROUNDS = len(constants).
+    Per round i:  tmp = (xl + C_i)^2 ;  new_xl = xr + tmp*(xl + C_i); last new_xl is public."""
+    r = c.r
+    rounds = len(constants)
+    m0 = 2
+    wit = [xl % r, xr % r]
+    col_xl, col_xr = m0 + 0, m0 + 1
+    v_xl, v_xr = xl % r, xr % r
+    A, B, Cm = [], [], []
+    nwit = 2
+    for i in range(rounds):
+        ci = constants[i] % r
+        tmp_v = pow((v_xl + ci) % r, 2, r)
+        col_tmp = m0 + nwit
+        nwit += 1
+        wit.append(tmp_v)
+        # (xl + Ci) * (xl + Ci) = tmp      (mimc.rs:98-102); LC order: variable term then One
+        lc = [(1, col_xl), (ci, 0)]
+        A.append(list(lc))
+        B.append(list(lc))
+        Cm.append([(1, col_tmp)])
+        new_v = ((v_xl + ci) * tmp_v + v_xr) % r
+        if i == rounds - 1:
+            col_new = 1                      # public input (mimc.rs:115-118)
+            pub = new_v
+        else:
+            col_new = m0 + nwit
+            nwit += 1
+            wit.append(new_v)
+        # tmp * (xl + Ci) = new_xl - xr     (mimc.rs:123-127)
+        A.append([(1, col_tmp)])
+        B.append(list(lc))
+        Cm.append([(1, col_new), (r - 1, col_xr)])
+        col_xr, v_xr = col_xl, v_xl
+        col_xl, v_xl = col_new, new_v
+    return R1CS(m0, nwit, A, B, Cm), [1, pub], wit
+
+
+def mimc_native(c, xl, xr, constants):
+    r = c.r
+    for ci in constants:
+        t = (xl + ci) % r
+        xl, xr = (pow(t, 3, r) + xr) % r, xl
+    return xl
+
+
+def synthetic_r1cs(c, nr, seed=SPLITMIX_SEED):
+    """m0 = 2 (One, out); gate i: A_i={(alpha_i,p_i)}, B_i={(beta_i,q_i)},
+    C_i={(1, t_i)}, t_i = (alpha_i z_{p_i})(beta_i z_{q_i}); p_i,q_i uniform over the
+    already-defined variables (One, then the two seed witnesses, then earlier gate
+    outputs); the last gate's output is the public input (column 1).
+    Draw order per gate: alpha, beta, p, q.  Seed witnesses w0, w1 are drawn first."""
+    r = c.r
+    g = SplitMix64(seed)
+    m0 = 2
+    wit = [g.fr(r), g.fr(r)]
+    # "defined" list holds (column, value); instance column 1 is defined only at the end
+    defined_cols = [0, m0 + 0, m0 + 1]
+    defined_vals = [1, wit[0], wit[1]]
+    A, B, Cm = [], [], []
+    pub = None
+    for i in range(nr):
+        alpha, beta = g.fr(r), g.fr(r)
+        pi, qi = g.below(len(defined_cols)), g.below(len(defined_cols))
+        t = (alpha * defined_vals[pi] % r) * (beta * defined_vals[qi] % r) % r
+        if i == nr - 1:
+            col = 1
+            pub = t
+        else:
+            col = m0 + len(wit)
+            wit.append(t)
+            defined_cols.append(col)
+            defined_vals.append(t)
+        A.append([(alpha, defined_cols[pi])])
+        B.append([(beta, defined_cols[qi])])
+        Cm.append([(1, col)])
+    return R1CS(m0, len(wit), A, B, Cm), [1, pub], wit
+
+
+def r1cs_is_satisfied(c, q, inst, wit):
+    r = c.r
+    zz = list(inst) + list(wit)
+    for ra, rb, rc in zip(q.a, q.b, q.c):
+        az = sum(v * zz[j] for v, j in ra) % r
+        bz = sum(v * zz[j] for v, j in rb) % r
+        cz = sum(v * zz[j] for v, j in rc) % r
+        if az * bz % r != cz:
+            return False
+    return True
