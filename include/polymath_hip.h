@@ -1,0 +1,159 @@
+/*
+ * polymath_hip.h -- C ABI of libpolymath_hip.so, the MI355X (gfx950) implementation of
+ * the Polymath prover hot path.  This is the drop-in boundary: everything the reference's
+ * Rust crate would bind over FFI for `create_proof_with_assignment`
+ * (/root/reference/src/prover.rs:66-237) plus the standalone MSM / NTT entry points the
+ * headline metric is quoted on.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Data conventions (identical to arkworks' in-memory layout):
+ *   Fr  : PM_FR_LIMBS  u64 little-endian limbs, MONTGOMERY form (R = 2^256).
+ *   Fq  : fq_limbs     u64 little-endian limbs, MONTGOMERY form (R = 2^384 BLS12-381, 2^256 BN254).
+ *   G1 affine in : x||y (2*fq_limbs u64) every `stride` bytes.  If stride > 16*fq_limbs the byte
+ *                  at offset 16*fq_limbs is arkworks' `infinity: bool`; a point whose x and y are
+ *                  both all-zero is also treated as the point at infinity.
+ *   G1 affine out: x||y Montgomery into `out_xy` (2*fq_limbs u64) and *out_inf = 1 for infinity
+ *                  (then x = y = 0).
+ * All functions return PM_OK (0) or a pm_status error; none throws or aborts.  The caller owns
+ * every host buffer; the library keeps no host pointer after a call returns.
+ *
+ * Threading: pm_pk is immutable after creation and may be shared by contexts on the same device;
+ * a pm_ctx owns its HIP stream and per-proof state, so one proof in flight per ctx
+ * (the reference has no global state: src/lib.rs:44-50).
+ */
+#ifndef POLYMATH_HIP_H
+#define POLYMATH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_FR_LIMBS 4
+
+typedef enum pm_curve {
+    PM_BLS12_381 = 0, /* the reference's only instantiated curve (Cargo.toml:35) */
+    PM_BN254 = 1      /* BASELINE.json configs[4] */
+} pm_curve;
+
+typedef enum pm_status {
+    PM_OK = 0,
+    PM_ERR_INVALID_ARG = 1,
+    PM_ERR_LEN_MISMATCH = 2,       /* == assert!(scalars.len() <= g1_elems.len())  prover.rs:381 */
+    PM_ERR_DOMAIN_TOO_LARGE = 3,   /* == D::new(..) None / PolynomialDegreeTooLarge prover.rs:83,317 */
+    PM_ERR_REMAINDER_NONZERO = 4,  /* == assert!(rem_poly.is_zero())               prover.rs:108,221 */
+    PM_ERR_DEGREE_BOUND = 5,       /* == degree asserts                            prover.rs:107,113,222 */
+    PM_ERR_HIP = 6,                /* a HIP runtime call failed; see pm_last_error */
+    PM_ERR_NO_DEVICE = 7,
+    PM_ERR_STATE = 8               /* phases called out of order */
+} pm_status;
+
+typedef struct pm_ctx pm_ctx;
+typedef struct pm_pk pm_pk;
+typedef struct pm_bases pm_bases;
+
+/* R1CS matrix in CSR form: what ark-relations `ConstraintMatrices` (generator.rs:46-54) holds as
+ * Vec<Vec<(F, usize)>>, flattened.  Column 0 = One, 1..m0-1 instance, then witness. */
+typedef struct pm_csr {
+    uint64_t nrows;
+    const uint64_t *rowptr; /* nrows+1 */
+    const uint32_t *col;    /* nnz */
+    const uint64_t *val;    /* nnz * PM_FR_LIMBS, Montgomery */
+} pm_csr;
+
+/* Base-vector selector, one per ProvingKey field (data_structures.rs:56-73). */
+typedef enum pm_base_vec {
+    PM_X_POWERS = 0,             /* x_powers_g1                  n+1 points     generator.rs:82  */
+    PM_X_POWERS_Y_ALPHA = 1,     /* x_powers_y_alpha_g1          3 points       generator.rs:86  */
+    PM_X_POWERS_Y_GAMMA = 2,     /* x_powers_y_gamma_g1          2 points       generator.rs:90  */
+    PM_X_POWERS_Y_GAMMA_Z = 3,   /* x_powers_y_gamma_z_g1        10n+23 points  generator.rs:94  */
+    PM_X_POWERS_ZH_BY_Y_ALPHA = 4,/* x_powers_zh_by_y_alpha_g1   n-1 points     generator.rs:107 */
+    PM_UJ_WJ_LCS_BY_Y_ALPHA = 5, /* uj_wj_lcs_by_y_alpha_g1      M-m0 points    generator.rs:115 */
+    PM_NUM_BASE_VECS = 6
+} pm_base_vec;
+
+typedef struct pm_base_array {
+    const void *points; /* host pointer, G1 affine-in convention above */
+    size_t len;         /* number of points */
+    size_t stride;      /* bytes between points */
+} pm_base_array;
+
+/* ---- library / context ------------------------------------------------------------------ */
+int pm_device_count(void);
+int pm_ctx_create(int device, pm_ctx **out);
+void pm_ctx_destroy(pm_ctx *ctx);
+const char *pm_last_error(const pm_ctx *ctx);
+/* Wall-clock GPU milliseconds of the most recent call's kernels, by stage (hipEvent timers;
+ * replaces the reference's start_timer!/end_timer! tracing, prover.rs:32-61). */
+int pm_last_timings(const pm_ctx *ctx, double *ms_out, int n_slots);
+
+/* ---- standalone kernels (unit parity + the "G1 MSM pairs/s" metric) ----------------------- */
+/* Radix-2 NTT over Fr, natural order in and out, like ark-poly Radix2EvaluationDomain::fft /
+ * ifft (prover.rs:241,319,325); inverse scales by 1/n.  `data` is a HOST buffer of 2^log_n Fr. */
+int pm_ntt(pm_ctx *ctx, int curve, uint64_t *data, unsigned log_n, int inverse);
+/* Same on a DEVICE buffer (hipMalloc'd by the caller, e.g. a torch tensor's data_ptr). */
+int pm_ntt_device(pm_ctx *ctx, int curve, uint64_t *d_data, unsigned log_n, int inverse);
+
+/* Variable-base MSM == E::G1::msm_unchecked(bases, scalars) (prover.rs:380-384), host buffers. */
+int pm_msm_g1(pm_ctx *ctx, int curve, const void *bases, size_t base_stride, const uint64_t *scalars,
+              size_t len, uint64_t *out_xy, int *out_inf);
+/* Resident form: upload a base vector once (the pk's bases are fixed), then run MSMs against a
+ * sub-range of it with scalars already in HBM (`d_scalars` device pointer) or on the host. */
+int pm_bases_upload(pm_ctx *ctx, int curve, const void *bases, size_t base_stride, size_t len, pm_bases **out);
+/* Synthetic base vector P_i = (i+1)*G built on the device (SURVEY.md §8d MSM micro-inputs). */
+int pm_bases_generate_multiples(pm_ctx *ctx, int curve, size_t len, pm_bases **out);
+int pm_bases_download(pm_ctx *ctx, const pm_bases *b, size_t offset, size_t len, uint64_t *out_xy);
+size_t pm_bases_len(const pm_bases *b);
+void pm_bases_free(pm_bases *b);
+int pm_msm_g1_resident(pm_ctx *ctx, const pm_bases *bases, size_t base_offset, const uint64_t *scalars,
+                       int scalars_on_device, size_t len, uint64_t *out_xy, int *out_inf);
+
+/* Host-side G1 helpers used to combine per-GPU partial MSM results (RCCL has no
+ * elliptic-curve reduction op, so partial points are all-gathered and summed locally). */
+int pm_g1_sum(int curve, const uint64_t *points_xy, const int *infs, size_t count, uint64_t *out_xy, int *out_inf);
+
+/* ---- proving key ------------------------------------------------------------------------ */
+/* Upload an existing ProvingKey (data_structures.rs:56-73).  `shard_rank/shard_count` keep only
+ * the contiguous 1/shard_count slice of every MSM's pair range on this device;
+ * pass 0,1 for a whole key. */
+int pm_pk_load(pm_ctx *ctx, int curve, uint64_t n, uint64_t m0, uint64_t mw, uint64_t nr, uint64_t sigma,
+               const pm_csr *a, const pm_csr *b, const pm_csr *c, const pm_base_array bases[PM_NUM_BASE_VECS],
+               int shard_rank, int shard_count, pm_pk **out);
+/* Circuit-specific setup on the device == generate_proving_key (generator.rs:24-167) with the two
+ * rng draws (x then z, generator.rs:72,77) supplied by the caller so RNG stays on the host side.
+ * Sparse O(nnz) replacement of the dense uj_wj_lcs loop; base vectors never leave HBM. */
+int pm_pk_generate(pm_ctx *ctx, int curve, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a,
+                   const pm_csr *b, const pm_csr *c, const uint64_t *x_trapdoor, const uint64_t *z_trapdoor,
+                   int shard_rank, int shard_count, pm_pk **out);
+int pm_pk_info(const pm_pk *pk, uint64_t *n, uint64_t *m0, uint64_t *sigma, uint64_t *omega /*Fr*/,
+               uint64_t base_lens[PM_NUM_BASE_VECS]);
+/* Copy (a range of) one base vector back to the host, x||y Montgomery, 16*fq_limbs bytes apart. */
+int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_t offset, size_t len, uint64_t *out_xy);
+void pm_pk_free(pm_pk *pk);
+
+/* ---- prove: create_proof_with_assignment split at its two transcript calls ---------------- */
+/* Phase 1 (prover.rs:75-123): witness map, iNTTs, u^2, h, then [a]_1 and [c]_1.
+ *   x   : m0 Fr, instance assignment INCLUDING the leading one (prover.rs:56)
+ *   w   : mw Fr, witness assignment
+ *   r_a : 2 Fr, the two F::rand draws of prover.rs:110 (constant term first) -- an input so
+ *         the RNG stays with the caller.
+ * On a sharded pk the outputs are this shard's PARTIAL sums; combine with pm_g1_sum. */
+int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
+                    uint64_t *a_g1_xy, int *a_inf, uint64_t *c_g1_xy, int *c_inf);
+/* Phase 2 (prover.rs:132): u(x1), the only O(n) part of a_at_x1; the caller adds r_a(x1)*y1^alpha. */
+int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
+/* Phase 3 (prover.rs:142-229): assemble the Y^-gamma-scaled numerator, divide by (X - x1),
+ * commit the dense quotient: [d]_1.  Returns PM_ERR_REMAINDER_NONZERO like prover.rs:221. */
+int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
+                    const uint64_t *c_at_x1, uint64_t *d_g1_xy, int *d_inf);
+
+/* Debug / parity taps: copy an intermediate vector of the proof in flight back to the host.
+ * which: 0 u_evals(n) 1 w_evals(n) 2 u coeffs(n) 3 w coeffs(n) 4 h coeffs(n) 5 witness-u coeffs(n)
+ *        6 z_tail(M-m0) 7 quotient (10n+23) */
+int pm_prove_tap(pm_ctx *ctx, int which, uint64_t *out, size_t max_elems, size_t *n_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYMATH_HIP_H */
