@@ -1,0 +1,312 @@
+"""ctypes binding of libpolymath_hip.so (include/polymath_hip.h).
+
+This is the Python face of the C ABI: thin, typed wrappers on numpy uint64 limb arrays
+(Montgomery form, arkworks' in-memory layout).  There is NO CPU fallback: if the library is
+missing or no GPU is present, calls raise.
+"""
+import ctypes as ct
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpolymath_hip.so")
+
+PM_BLS12_381, PM_BN254 = 0, 1
+CURVE_IDS = {"bls12_381": PM_BLS12_381, "bn254": PM_BN254}
+FQ_LIMBS64 = {PM_BLS12_381: 6, PM_BN254: 4}
+
+STATUS = {0: "PM_OK", 1: "PM_ERR_INVALID_ARG", 2: "PM_ERR_LEN_MISMATCH", 3: "PM_ERR_DOMAIN_TOO_LARGE",
+          4: "PM_ERR_REMAINDER_NONZERO", 5: "PM_ERR_DEGREE_BOUND", 6: "PM_ERR_HIP", 7: "PM_ERR_NO_DEVICE",
+          8: "PM_ERR_STATE"}
+(X_POWERS, X_POWERS_Y_ALPHA, X_POWERS_Y_GAMMA, X_POWERS_Y_GAMMA_Z, X_POWERS_ZH_BY_Y_ALPHA,
+ UJ_WJ_LCS_BY_Y_ALPHA) = range(6)
+TIMING_SLOTS = ["witness_map", "ntt", "poly", "msm_sort", "msm_accumulate", "msm_reduce", "msm_total", "phase"]
+
+u64p = ct.POINTER(ct.c_uint64)
+u32p = ct.POINTER(ct.c_uint32)
+intp = ct.POINTER(ct.c_int)
+
+
+class PmCsr(ct.Structure):
+    _fields_ = [("nrows", ct.c_uint64), ("rowptr", u64p), ("col", u32p), ("val", u64p)]
+
+
+class PmBaseArray(ct.Structure):
+    _fields_ = [("points", ct.c_void_p), ("len", ct.c_size_t), ("stride", ct.c_size_t)]
+
+
+class PolymathError(RuntimeError):
+    def __init__(self, status, detail=""):
+        super().__init__("%s (%d) %s" % (STATUS.get(status, "?"), status, detail))
+        self.status = status
+
+
+EXPORTS = [
+    "pm_device_count", "pm_ctx_create", "pm_ctx_destroy", "pm_last_error", "pm_last_timings", "pm_ntt",
+    "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
+    "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
+    "pm_pk_info", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase2", "pm_prove_phase3",
+    "pm_prove_tap",
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads the HIP library or raises -- the product never falls back to a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libpolymath_hip.so not built: run `python -m polymath_amd.build` "
+                          "(__graft_entry__.build()).  There is no CPU fallback.")
+    L = ct.CDLL(LIB_PATH)
+    vp, sz, u64, i = ct.c_void_p, ct.c_size_t, ct.c_uint64, ct.c_int
+    L.pm_device_count.restype = i
+    L.pm_ctx_create.argtypes = [i, ct.POINTER(vp)]
+    L.pm_ctx_destroy.argtypes = [vp]
+    L.pm_ctx_destroy.restype = None
+    L.pm_last_error.argtypes = [vp]
+    L.pm_last_error.restype = ct.c_char_p
+    L.pm_last_timings.argtypes = [vp, ct.POINTER(ct.c_double), i]
+    L.pm_ntt.argtypes = [vp, i, u64p, ct.c_uint, i]
+    L.pm_ntt_device.argtypes = [vp, i, vp, ct.c_uint, i]
+    L.pm_msm_g1.argtypes = [vp, i, vp, sz, u64p, sz, u64p, intp]
+    L.pm_bases_upload.argtypes = [vp, i, vp, sz, sz, ct.POINTER(vp)]
+    L.pm_bases_generate_multiples.argtypes = [vp, i, sz, ct.POINTER(vp)]
+    L.pm_bases_download.argtypes = [vp, vp, sz, sz, u64p]
+    L.pm_bases_len.argtypes = [vp]
+    L.pm_bases_len.restype = sz
+    L.pm_bases_free.argtypes = [vp]
+    L.pm_bases_free.restype = None
+    L.pm_msm_g1_resident.argtypes = [vp, vp, sz, vp, i, sz, u64p, intp]
+    L.pm_g1_sum.argtypes = [i, u64p, intp, sz, u64p, intp]
+    L.pm_pk_load.argtypes = [vp, i, u64, u64, u64, u64, u64, ct.POINTER(PmCsr), ct.POINTER(PmCsr), ct.POINTER(PmCsr),
+                             ct.POINTER(PmBaseArray), i, i, ct.POINTER(vp)]
+    L.pm_pk_generate.argtypes = [vp, i, u64, u64, u64, ct.POINTER(PmCsr), ct.POINTER(PmCsr), ct.POINTER(PmCsr), u64p,
+                                 u64p, i, i, ct.POINTER(vp)]
+    L.pm_pk_info.argtypes = [vp, u64p, u64p, u64p, u64p, u64p]
+    L.pm_pk_export_bases.argtypes = [vp, vp, i, sz, sz, u64p]
+    L.pm_pk_free.argtypes = [vp]
+    L.pm_pk_free.restype = None
+    L.pm_prove_phase1.argtypes = [vp, vp, u64p, u64p, u64p, u64p, intp, u64p, intp]
+    L.pm_prove_phase2.argtypes = [vp, u64p, u64p]
+    L.pm_prove_phase3.argtypes = [vp, u64p, u64p, u64p, u64p, u64p, intp]
+    L.pm_prove_tap.argtypes = [vp, i, u64p, sz, ct.POINTER(sz)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(u64p)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Context:
+    """pm_ctx: one HIP stream + workspaces on one GPU; one proof in flight."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = ct.c_void_p()
+        st = self.L.pm_ctx_create(device, ct.byref(h))
+        if st:
+            raise PolymathError(st, "pm_ctx_create(device=%d)" % device)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pm_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, st):
+        if st:
+            raise PolymathError(st, self.L.pm_last_error(self.h).decode())
+
+    def timings(self):
+        arr = (ct.c_double * len(TIMING_SLOTS))()
+        self.L.pm_last_timings(self.h, arr, len(TIMING_SLOTS))
+        return dict(zip(TIMING_SLOTS, list(arr)))
+
+    # ---- standalone kernels
+    def ntt(self, curve, data, log_n, inverse=False):
+        data = _c(data).copy()
+        self.check(self.L.pm_ntt(self.h, CURVE_IDS[curve], _p(data), log_n, int(inverse)))
+        return data
+
+    def ntt_device(self, curve, dptr, log_n, inverse=False):
+        self.check(self.L.pm_ntt_device(self.h, CURVE_IDS[curve], ct.c_void_p(dptr), log_n, int(inverse)))
+
+    def msm(self, curve, bases, scalars):
+        cid = CURVE_IDS[curve]
+        bases, scalars = _c(bases), _c(scalars)
+        out = np.zeros(2 * FQ_LIMBS64[cid], dtype=np.uint64)
+        inf = ct.c_int(0)
+        self.check(self.L.pm_msm_g1(self.h, cid, bases.ctypes.data_as(ct.c_void_p), bases.strides[0] if bases.ndim > 1 else 16 * FQ_LIMBS64[cid],
+                                    _p(scalars), scalars.shape[0], _p(out), ct.byref(inf)))
+        return out, inf.value
+
+    def g1_sum(self, curve, pts, infs=None):
+        cid = CURVE_IDS[curve]
+        pts = _c(pts).reshape(-1, 2 * FQ_LIMBS64[cid])
+        out = np.zeros(2 * FQ_LIMBS64[cid], dtype=np.uint64)
+        inf = ct.c_int(0)
+        ia = np.ascontiguousarray(infs, dtype=np.int32) if infs is not None else None
+        st = self.L.pm_g1_sum(cid, _p(pts), ia.ctypes.data_as(intp) if ia is not None else None, len(pts), _p(out), ct.byref(inf))
+        self.check(st)
+        return out, inf.value
+
+
+class Bases:
+    """pm_bases: a G1 base vector resident in HBM."""
+
+    def __init__(self, ctx, curve, handle):
+        self.ctx, self.curve, self.cid, self.h = ctx, curve, CURVE_IDS[curve], handle
+
+    @classmethod
+    def upload(cls, ctx, curve, bases):
+        bases = _c(bases)
+        h = ct.c_void_p()
+        ctx.check(ctx.L.pm_bases_upload(ctx.h, CURVE_IDS[curve], bases.ctypes.data_as(ct.c_void_p), bases.strides[0],
+                                        bases.shape[0], ct.byref(h)))
+        return cls(ctx, curve, h)
+
+    @classmethod
+    def multiples(cls, ctx, curve, length):
+        h = ct.c_void_p()
+        ctx.check(ctx.L.pm_bases_generate_multiples(ctx.h, CURVE_IDS[curve], length, ct.byref(h)))
+        return cls(ctx, curve, h)
+
+    def __len__(self):
+        return int(self.ctx.L.pm_bases_len(self.h))
+
+    def download(self, offset=0, length=None):
+        if length is None:
+            length = len(self) - offset
+        out = np.zeros((length, 2 * FQ_LIMBS64[self.cid]), dtype=np.uint64)
+        self.ctx.check(self.ctx.L.pm_bases_download(self.ctx.h, self.h, offset, length, _p(out)))
+        return out
+
+    def msm(self, scalars, offset=0, length=None, device_ptr=None):
+        """scalars: host np.uint64 [len,4], or device_ptr (int) + length for scalars already in HBM."""
+        out = np.zeros(2 * FQ_LIMBS64[self.cid], dtype=np.uint64)
+        inf = ct.c_int(0)
+        if device_ptr is not None:
+            st = self.ctx.L.pm_msm_g1_resident(self.ctx.h, self.h, offset, ct.c_void_p(device_ptr), 1, length, _p(out), ct.byref(inf))
+        else:
+            scalars = _c(scalars)
+            length = scalars.shape[0] if length is None else length
+            st = self.ctx.L.pm_msm_g1_resident(self.ctx.h, self.h, offset, scalars.ctypes.data_as(ct.c_void_p), 0, length,
+                                               _p(out), ct.byref(inf))
+        self.ctx.check(st)
+        return out, inf.value
+
+    def free(self):
+        if self.h:
+            self.ctx.L.pm_bases_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CsrArrays:
+    """numpy-backed pm_csr.  rows: list of rows of (value_montgomery_limbs_or_index...)."""
+
+    def __init__(self, rowptr, col, val):
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        self.col = np.ascontiguousarray(col if len(col) else [0], dtype=np.uint32)
+        self.val = _c(val) if len(val) else np.zeros((1, 4), dtype=np.uint64)
+        self.struct = PmCsr(len(self.rowptr) - 1, _p(self.rowptr), self.col.ctypes.data_as(u32p), _p(self.val))
+
+
+class ProvingKey:
+    """pm_pk: R1CS matrices + the six base vectors resident on one GPU (optionally one shard)."""
+
+    def __init__(self, ctx, curve, handle, csrs):
+        self.ctx, self.curve, self.cid, self.h, self._csrs = ctx, curve, CURVE_IDS[curve], handle, csrs
+        n, m0, sigma = ct.c_uint64(), ct.c_uint64(), ct.c_uint64()
+        omega = np.zeros(4, dtype=np.uint64)
+        lens = np.zeros(6, dtype=np.uint64)
+        ctx.check(ctx.L.pm_pk_info(self.h, ct.byref(n), ct.byref(m0), ct.byref(sigma), _p(omega), _p(lens)))
+        self.n, self.m0, self.sigma, self.omega_limbs = n.value, m0.value, sigma.value, omega
+        self.base_lens = [int(v) for v in lens]
+        self.nq = FQ_LIMBS64[self.cid]
+
+    @classmethod
+    def generate(cls, ctx, curve, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1):
+        """a, b, c: CsrArrays; trapdoors: np.uint64[4] Montgomery (generator.rs:72,77 draws)."""
+        h = ct.c_void_p()
+        ctx.check(ctx.L.pm_pk_generate(ctx.h, CURVE_IDS[curve], m0, mw, nr, ct.byref(a.struct), ct.byref(b.struct),
+                                       ct.byref(c.struct), _p(_c(x_trapdoor)), _p(_c(z_trapdoor)), shard_rank, shard_count,
+                                       ct.byref(h)))
+        return cls(ctx, curve, h, (a, b, c))
+
+    @classmethod
+    def load(cls, ctx, curve, n, m0, mw, nr, sigma, a, b, c, base_arrays, shard_rank=0, shard_count=1):
+        """base_arrays: six np.uint64 2-D arrays in pm_base_vec order."""
+        arrs = [_c(x) for x in base_arrays]
+        BA = (PmBaseArray * 6)()
+        for k, x in enumerate(arrs):
+            BA[k] = PmBaseArray(x.ctypes.data_as(ct.c_void_p), x.shape[0], x.strides[0])
+        h = ct.c_void_p()
+        ctx.check(ctx.L.pm_pk_load(ctx.h, CURVE_IDS[curve], n, m0, mw, nr, sigma, ct.byref(a.struct), ct.byref(b.struct),
+                                   ct.byref(c.struct), BA, shard_rank, shard_count, ct.byref(h)))
+        return cls(ctx, curve, h, (a, b, c))
+
+    def export_bases(self, which, offset=0, length=None):
+        if length is None:
+            length = self.base_lens[which] - offset
+        out = np.zeros((length, 2 * self.nq), dtype=np.uint64)
+        self.ctx.check(self.ctx.L.pm_pk_export_bases(self.ctx.h, self.h, which, offset, length, _p(out)))
+        return out
+
+    # --- the three prover phases: (status, outputs...) tuples, status codes of pm_status
+    def phase1(self, x, w, r_a):
+        a = np.zeros(2 * self.nq, dtype=np.uint64)
+        c = np.zeros(2 * self.nq, dtype=np.uint64)
+        ai, ci = ct.c_int(0), ct.c_int(0)
+        w = _c(w) if len(w) else np.zeros((1, 4), dtype=np.uint64)
+        rc = self.ctx.L.pm_prove_phase1(self.ctx.h, self.h, _p(_c(x)), _p(w), _p(_c(r_a)), _p(a), ct.byref(ai), _p(c), ct.byref(ci))
+        return rc, a, ai.value, c, ci.value
+
+    def phase2(self, x1):
+        out = np.zeros(4, dtype=np.uint64)
+        rc = self.ctx.L.pm_prove_phase2(self.ctx.h, _p(_c(x1)), _p(out))
+        return rc, out
+
+    def phase3(self, x1, x2, a_at_x1, c_at_x1):
+        d = np.zeros(2 * self.nq, dtype=np.uint64)
+        di = ct.c_int(0)
+        rc = self.ctx.L.pm_prove_phase3(self.ctx.h, _p(_c(x1)), _p(_c(x2)), _p(_c(a_at_x1)), _p(_c(c_at_x1)), _p(d), ct.byref(di))
+        return rc, d, di.value
+
+    def tap(self, which, max_elems):
+        out = np.zeros((max_elems, 4), dtype=np.uint64)
+        n = ct.c_size_t(0)
+        self.ctx.check(self.ctx.L.pm_prove_tap(self.ctx.h, which, _p(out), max_elems, ct.byref(n)))
+        return out[:min(n.value, max_elems)]
+
+    def free(self):
+        if self.h:
+            self.ctx.L.pm_pk_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

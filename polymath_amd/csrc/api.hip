@@ -1,0 +1,619 @@
+// C ABI of libpolymath_hip.so (include/polymath_hip.h): context / key management and dispatch
+// on the curve.  All compute is in the .hip kernels; the host code here only moves buffers,
+// removes row-duplicate R1CS entries the reference cannot see (m_at, common.rs:100-105), and
+// prepares the O(nnz) setup scalars.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "internal.h"
+
+using namespace pm;
+
+// ------------------------------------------------------------------------------ helpers
+template <class C>
+static void repack_bases(const void *src, size_t stride, size_t len, Affine<C> *dst) {
+    const size_t PT = sizeof(Affine<C>);
+    const uint8_t *s = (const uint8_t *)src;
+    for (size_t i = 0; i < len; ++i) {
+        memcpy(&dst[i], s + i * stride, PT);
+        if (stride > PT && s[i * stride + PT] != 0) dst[i] = Affine<C>::infinity();  // arkworks `infinity: bool`
+    }
+}
+
+#define PM_DISPATCH(curve, CALL_BLS, CALL_BN) \
+    ((curve) == PM_BLS12_381 ? (CALL_BLS) : (curve) == PM_BN254 ? (CALL_BN) : (int)PM_ERR_INVALID_ARG)
+
+static int set_device(pm_ctx *ctx) {
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------ context
+extern "C" int pm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int pm_ctx_create(int device, pm_ctx **out) {
+    if (!out) return PM_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PM_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return PM_ERR_INVALID_ARG;
+    pm_ctx *ctx = new (std::nothrow) pm_ctx();
+    if (!ctx) return PM_ERR_INVALID_ARG;
+    ctx->device = device;
+    ctx->pk = nullptr;
+    ctx->phase = 0;
+    timing_reset(ctx);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PM_ERR_HIP;
+    }
+    *out = ctx;
+    return PM_OK;
+}
+
+extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    timing_flush(ctx);
+    MsmWorkspace &m = ctx->msm;
+    for (DevBuf *b : {&m.digits, &m.sorted, &m.counts, &m.bucket_off, &m.task_off, &m.cursor, &m.partials, &m.wsum,
+                      &m.result, &m.canon, &ctx->scratch, &ctx->flags, &ctx->xw, &ctx->ue, &ctx->we, &ctx->u, &ctx->w,
+                      &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra})
+        b->release();
+    for (auto &b : ctx->lvl) b.release();
+    for (auto &t : ctx->tw) { t.fwd.release(); t.inv.release(); }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *pm_last_error(const pm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int pm_last_timings(const pm_ctx *ctx, double *ms_out, int n_slots) {
+    if (!ctx || !ms_out) return PM_ERR_INVALID_ARG;
+    for (int i = 0; i < n_slots; ++i) ms_out[i] = i < T_NUM_SLOTS ? ctx->timing_ms[i] : 0.0;
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------- NTT
+template <class C>
+static int ntt_host(pm_ctx *ctx, uint64_t *data, unsigned log_n, int inverse) {
+    typedef Fp<typename C::FrP> Fr;
+    if (log_n > (unsigned)C::TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+    size_t bytes = sizeof(Fr) << log_n;
+    PM_HIP(ctx, ctx->scratch.reserve(bytes));
+    PM_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    timing_reset(ctx);
+    PM_TRY(ntt_run<C>(ctx, ctx->scratch.as<Fr>(), log_n, inverse != 0));
+    PM_HIP(ctx, hipMemcpyAsync(data, ctx->scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    timing_flush(ctx);
+    return PM_OK;
+}
+
+extern "C" int pm_ntt(pm_ctx *ctx, int curve, uint64_t *data, unsigned log_n, int inverse) {
+    if (!ctx || !data) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(curve, ntt_host<BlsCurve>(ctx, data, log_n, inverse), ntt_host<BnCurve>(ctx, data, log_n, inverse));
+}
+
+template <class C>
+static int ntt_dev(pm_ctx *ctx, uint64_t *d, unsigned log_n, int inverse) {
+    timing_reset(ctx);
+    PM_TRY(ntt_run<C>(ctx, (Fp<typename C::FrP> *)d, log_n, inverse != 0));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    timing_flush(ctx);
+    return PM_OK;
+}
+
+extern "C" int pm_ntt_device(pm_ctx *ctx, int curve, uint64_t *d_data, unsigned log_n, int inverse) {
+    if (!ctx || !d_data) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(curve, ntt_dev<BlsCurve>(ctx, d_data, log_n, inverse), ntt_dev<BnCurve>(ctx, d_data, log_n, inverse));
+}
+
+// ---------------------------------------------------------------------------------- MSM
+template <class C>
+static int bases_upload_impl(pm_ctx *ctx, const void *bases, size_t stride, size_t len, pm_bases **out) {
+    if (stride < sizeof(Affine<C>)) return PM_ERR_INVALID_ARG;
+    std::unique_ptr<pm_bases> b(new pm_bases{C::ID, ctx->device, len, nullptr});
+    if (len) {
+        std::vector<Affine<C>> packed(len);
+        repack_bases<C>(bases, stride, len, packed.data());
+        PM_HIP(ctx, hipMalloc(&b->d_points, len * sizeof(Affine<C>)));
+        PM_HIP(ctx, hipMemcpy(b->d_points, packed.data(), len * sizeof(Affine<C>), hipMemcpyHostToDevice));
+    }
+    *out = b.release();
+    return PM_OK;
+}
+
+extern "C" int pm_bases_upload(pm_ctx *ctx, int curve, const void *bases, size_t base_stride, size_t len, pm_bases **out) {
+    if (!ctx || !out || (len && !bases)) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(curve, bases_upload_impl<BlsCurve>(ctx, bases, base_stride, len, out),
+                       bases_upload_impl<BnCurve>(ctx, bases, base_stride, len, out));
+}
+
+template <class C>
+static int bases_multiples_impl(pm_ctx *ctx, size_t len, pm_bases **out) {
+    std::unique_ptr<pm_bases> b(new pm_bases{C::ID, ctx->device, len, nullptr});
+    if (len) {
+        PM_HIP(ctx, hipMalloc(&b->d_points, len * sizeof(Affine<C>)));
+        int st = bases_generate_multiples<C>(ctx, len, (Affine<C> *)b->d_points);
+        if (st != PM_OK) {
+            (void)hipFree(b->d_points);
+            return st;
+        }
+    }
+    *out = b.release();
+    return PM_OK;
+}
+
+extern "C" int pm_bases_generate_multiples(pm_ctx *ctx, int curve, size_t len, pm_bases **out) {
+    if (!ctx || !out) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(curve, bases_multiples_impl<BlsCurve>(ctx, len, out), bases_multiples_impl<BnCurve>(ctx, len, out));
+}
+
+extern "C" int pm_bases_download(pm_ctx *ctx, const pm_bases *b, size_t offset, size_t len, uint64_t *out_xy) {
+    if (!ctx || !b || !out_xy || offset + len > b->len) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    size_t pt = b->curve == PM_BLS12_381 ? sizeof(Affine<BlsCurve>) : sizeof(Affine<BnCurve>);
+    PM_HIP(ctx, hipMemcpy(out_xy, (const uint8_t *)b->d_points + offset * pt, len * pt, hipMemcpyDeviceToHost));
+    return PM_OK;
+}
+
+extern "C" size_t pm_bases_len(const pm_bases *b) { return b ? b->len : 0; }
+
+extern "C" void pm_bases_free(pm_bases *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->d_points) (void)hipFree(b->d_points);
+    delete b;
+}
+
+template <class C>
+static int msm_resident_impl(pm_ctx *ctx, const pm_bases *bases, size_t off, const uint64_t *scalars, int on_device,
+                             size_t len, uint64_t *out_xy, int *out_inf) {
+    typedef Fp<typename C::FrP> Fr;
+    const Fr *d_sc = (const Fr *)scalars;
+    if (!on_device && len) {
+        PM_HIP(ctx, ctx->scratch.reserve(len * sizeof(Fr)));
+        PM_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, scalars, len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        d_sc = ctx->scratch.as<Fr>();
+    }
+    Affine<C> r;
+    int inf = 1;
+    timing_reset(ctx);
+    PM_TRY(msm_run<C>(ctx, (const Affine<C> *)bases->d_points + off, d_sc, len, &r, &inf));
+    timing_flush(ctx);
+    if (inf) memset(out_xy, 0, sizeof(Affine<C>));
+    else memcpy(out_xy, &r, sizeof(Affine<C>));
+    *out_inf = inf;
+    return PM_OK;
+}
+
+extern "C" int pm_msm_g1_resident(pm_ctx *ctx, const pm_bases *bases, size_t base_offset, const uint64_t *scalars,
+                                  int scalars_on_device, size_t len, uint64_t *out_xy, int *out_inf) {
+    if (!ctx || !bases || !out_xy || !out_inf || (len && !scalars)) return PM_ERR_INVALID_ARG;
+    if (base_offset + len > bases->len) return PM_ERR_LEN_MISMATCH;  // prover.rs:381
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(bases->curve,
+                       msm_resident_impl<BlsCurve>(ctx, bases, base_offset, scalars, scalars_on_device, len, out_xy, out_inf),
+                       msm_resident_impl<BnCurve>(ctx, bases, base_offset, scalars, scalars_on_device, len, out_xy, out_inf));
+}
+
+extern "C" int pm_msm_g1(pm_ctx *ctx, int curve, const void *bases, size_t base_stride, const uint64_t *scalars,
+                         size_t len, uint64_t *out_xy, int *out_inf) {
+    if (!ctx || !out_xy || !out_inf || (len && (!bases || !scalars))) return PM_ERR_INVALID_ARG;
+    pm_bases *b = nullptr;
+    PM_TRY(pm_bases_upload(ctx, curve, bases, base_stride, len, &b));
+    int st = pm_msm_g1_resident(ctx, b, 0, scalars, 0, len, out_xy, out_inf);
+    pm_bases_free(b);
+    return st;
+}
+
+template <class C>
+static int g1_sum_impl(const uint64_t *pts, const int *infs, size_t count, uint64_t *out_xy, int *out_inf) {
+    XYZZ<C> acc = XYZZ<C>::identity();
+    for (size_t i = 0; i < count; ++i) {
+        Affine<C> a;
+        memcpy(&a, (const uint8_t *)pts + i * sizeof(Affine<C>), sizeof(Affine<C>));
+        if (infs && infs[i]) continue;
+        xyzz_madd<C>(acc, a, false);
+    }
+    Affine<C> r = xyzz_to_affine<C>(acc);
+    int inf = acc.is_identity() ? 1 : 0;
+    if (inf) memset(out_xy, 0, sizeof(Affine<C>));
+    else memcpy(out_xy, &r, sizeof(Affine<C>));
+    *out_inf = inf;
+    return PM_OK;
+}
+
+extern "C" int pm_g1_sum(int curve, const uint64_t *points_xy, const int *infs, size_t count, uint64_t *out_xy, int *out_inf) {
+    if (!out_xy || !out_inf || (count && !points_xy)) return PM_ERR_INVALID_ARG;
+    return PM_DISPATCH(curve, g1_sum_impl<BlsCurve>(points_xy, infs, count, out_xy, out_inf),
+                       g1_sum_impl<BnCurve>(points_xy, infs, count, out_xy, out_inf));
+}
+
+// ------------------------------------------------------------------------- proving key
+struct HostCsr {
+    std::vector<uint64_t> rowptr;
+    std::vector<uint32_t> col;
+    std::vector<uint64_t> val;
+};
+
+// m_at (common.rs:100-105) only ever sees the FIRST entry of a row with a given column.
+static int dedupe_csr(const pm_csr *m, uint64_t nr, uint64_t ncols, HostCsr &out) {
+    if (!m || m->nrows != nr || !m->rowptr) return PM_ERR_INVALID_ARG;
+    out.rowptr.assign(1, 0);
+    for (uint64_t r = 0; r < nr; ++r) {
+        size_t start = out.col.size();
+        for (uint64_t k = m->rowptr[r]; k < m->rowptr[r + 1]; ++k) {
+            if (m->col[k] >= ncols) return PM_ERR_INVALID_ARG;
+            bool dup = false;
+            for (size_t q = start; q < out.col.size(); ++q)
+                if (out.col[q] == m->col[k]) { dup = true; break; }
+            if (dup) continue;
+            out.col.push_back(m->col[k]);
+            for (int i = 0; i < 4; ++i) out.val.push_back(m->val[4 * k + i]);
+        }
+        out.rowptr.push_back(out.col.size());
+    }
+    return PM_OK;
+}
+
+static void pk_release(pm_pk *pk) {
+    if (!pk) return;
+    (void)hipSetDevice(pk->device);
+    for (int i = 0; i < 3; ++i) {
+        if (pk->d_rowptr[i]) (void)hipFree(pk->d_rowptr[i]);
+        if (pk->d_col[i]) (void)hipFree(pk->d_col[i]);
+        if (pk->d_val[i]) (void)hipFree(pk->d_val[i]);
+    }
+    if (pk->d_bases) (void)hipFree(pk->d_bases);
+    delete pk;
+}
+
+extern "C" void pm_pk_free(pm_pk *pk) { pk_release(pk); }
+
+// Shapes, domain, the logical base concatenation and this shard's resident ranges.
+template <class C>
+static int pk_init_layout(pm_ctx *ctx, pm_pk *pk, uint64_t m0, uint64_t mw, uint64_t nr, int shard_rank, int shard_count) {
+    typedef typename C::FrP P;
+    if (m0 < 1 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return PM_ERR_INVALID_ARG;
+    pk->curve = C::ID;
+    pk->device = ctx->device;
+    pk->m0 = m0; pk->mw = mw; pk->nr = nr;
+    uint64_t rows = 2 * (m0 + nr);                     // common.rs:131-135
+    uint64_t n = 1;
+    unsigned log_n = 0;
+    while (n < rows) { n <<= 1; ++log_n; }             // Radix2EvaluationDomain::new, generator.rs:60
+    if (log_n > (unsigned)C::TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;
+    pk->n = n; pk->log_n = log_n; pk->sigma = n + 3;   // generator.rs:66-70
+    Fp<P> w;
+    for (int i = 0; i < P::N; ++i) w.l[i] = C::ROOT_MONT[i];
+    for (unsigned i = log_n; i < (unsigned)C::TWO_ADICITY; ++i) w = sqr<P>(w);
+    memcpy(pk->omega, w.l, 32);
+    pk->shard_rank = shard_rank; pk->shard_count = shard_count;
+    const uint64_t Lz = 2 * m0 + mw + nr;
+    pk->base_len[PM_X_POWERS] = n + 1;
+    pk->base_len[PM_X_POWERS_Y_ALPHA] = 3;
+    pk->base_len[PM_X_POWERS_Y_GAMMA] = 2;
+    pk->base_len[PM_X_POWERS_Y_GAMMA_Z] = 2 * (n - 1) + 8 * pk->sigma + 1;
+    pk->base_len[PM_X_POWERS_ZH_BY_Y_ALPHA] = n - 1;
+    pk->base_len[PM_UJ_WJ_LCS_BY_Y_ALPHA] = Lz;
+    const int order[6] = {PM_UJ_WJ_LCS_BY_Y_ALPHA, PM_X_POWERS_ZH_BY_Y_ALPHA, PM_X_POWERS, PM_X_POWERS_Y_ALPHA,
+                          PM_X_POWERS_Y_GAMMA, PM_X_POWERS_Y_GAMMA_Z};
+    uint64_t off = 0;
+    for (int k = 0; k < 6; ++k) { pk->seg_off[order[k]] = off; off += pk->base_len[order[k]]; }
+    pk->total_points = off;
+    pk->msm_lo[0] = pk->seg_off[PM_X_POWERS];            pk->msm_len[0] = n + 3;
+    pk->msm_lo[1] = 0;                                   pk->msm_len[1] = pk->seg_off[PM_X_POWERS_Y_GAMMA_Z];
+    pk->msm_lo[2] = pk->seg_off[PM_X_POWERS_Y_GAMMA_Z];  pk->msm_len[2] = pk->base_len[PM_X_POWERS_Y_GAMMA_Z] - 1;
+    for (int k = 0; k < 3; ++k) {
+        pk->res_lo[k] = pk->msm_len[k] * (uint64_t)shard_rank / (uint64_t)shard_count;
+        pk->res_hi[k] = pk->msm_len[k] * (uint64_t)(shard_rank + 1) / (uint64_t)shard_count;
+    }
+    if (shard_count == 1) {
+        for (int k = 0; k < 3; ++k) pk->res_dev_off[k] = pk->msm_lo[k];
+    } else {  // device layout [c slice | a slice | d slice]
+        pk->res_dev_off[1] = 0;
+        pk->res_dev_off[0] = pk->res_hi[1] - pk->res_lo[1];
+        pk->res_dev_off[2] = pk->res_dev_off[0] + (pk->res_hi[0] - pk->res_lo[0]);
+    }
+    return PM_OK;
+}
+
+static uint64_t pk_resident_points(const pm_pk *pk) {
+    if (pk->shard_count == 1) return pk->total_points;
+    uint64_t t = 0;
+    for (int k = 0; k < 3; ++k) t += pk->res_hi[k] - pk->res_lo[k];
+    return t;
+}
+
+template <class C>
+static int pk_upload_matrices(pm_ctx *ctx, pm_pk *pk, const pm_csr *a, const pm_csr *b, const pm_csr *c, HostCsr host[3]) {
+    const pm_csr *m[3] = {a, b, c};
+    for (int i = 0; i < 3; ++i) {
+        PM_TRY(dedupe_csr(m[i], pk->nr, pk->m0 + pk->mw, host[i]));
+        pk->nnz[i] = host[i].col.size();
+        PM_HIP(ctx, hipMalloc((void **)&pk->d_rowptr[i], host[i].rowptr.size() * 8));
+        PM_HIP(ctx, hipMemcpy(pk->d_rowptr[i], host[i].rowptr.data(), host[i].rowptr.size() * 8, hipMemcpyHostToDevice));
+        size_t nz = host[i].col.size() ? host[i].col.size() : 1;
+        PM_HIP(ctx, hipMalloc((void **)&pk->d_col[i], nz * 4));
+        PM_HIP(ctx, hipMalloc((void **)&pk->d_val[i], nz * 32));
+        if (host[i].col.size()) {
+            PM_HIP(ctx, hipMemcpy(pk->d_col[i], host[i].col.data(), host[i].col.size() * 4, hipMemcpyHostToDevice));
+            PM_HIP(ctx, hipMemcpy(pk->d_val[i], host[i].val.data(), host[i].val.size() * 8, hipMemcpyHostToDevice));
+        }
+    }
+    return PM_OK;
+}
+
+// Apply `fill(vec, start, count, dst)` to every piece of the logical concatenation range [lo, hi).
+template <class C, class F>
+static int for_cat_range(const pm_pk *pk, uint64_t lo, uint64_t hi, Affine<C> *dst, F fill) {
+    const int order[6] = {PM_UJ_WJ_LCS_BY_Y_ALPHA, PM_X_POWERS_ZH_BY_Y_ALPHA, PM_X_POWERS, PM_X_POWERS_Y_ALPHA,
+                          PM_X_POWERS_Y_GAMMA, PM_X_POWERS_Y_GAMMA_Z};
+    for (int k = 0; k < 6; ++k) {
+        int v = order[k];
+        uint64_t s = pk->seg_off[v], e = s + pk->base_len[v];
+        uint64_t a = std::max(lo, s), b = std::min(hi, e);
+        if (a >= b) continue;
+        PM_TRY(fill(v, a - s, b - a, dst + (a - lo)));
+    }
+    return PM_OK;
+}
+
+template <class C, class F>
+static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
+    uint64_t resident = pk_resident_points(pk);
+    PM_HIP(ctx, hipMalloc(&pk->d_bases, resident * sizeof(Affine<C>)));
+    Affine<C> *d = (Affine<C> *)pk->d_bases;
+    if (pk->shard_count == 1) return for_cat_range<C>(pk, 0, pk->total_points, d, fill);
+    for (int k = 0; k < 3; ++k)
+        PM_TRY(for_cat_range<C>(pk, pk->msm_lo[k] + pk->res_lo[k], pk->msm_lo[k] + pk->res_hi[k], d + pk->res_dev_off[k], fill));
+    return PM_OK;
+}
+
+template <class C>
+static int pk_load_impl(pm_ctx *ctx, uint64_t n, uint64_t m0, uint64_t mw, uint64_t nr, uint64_t sigma, const pm_csr *a,
+                        const pm_csr *b, const pm_csr *c, const pm_base_array *bases, int shard_rank, int shard_count,
+                        pm_pk **out) {
+    pm_pk *pk = new pm_pk();
+    memset(pk, 0, sizeof(*pk));
+    auto guard = [&](int st) { if (st != PM_OK) pk_release(pk); return st; };
+    int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count);
+    if (st) return guard(st);
+    if (pk->n != n || pk->sigma != sigma) return guard(PM_ERR_INVALID_ARG);
+    for (int v = 0; v < PM_NUM_BASE_VECS; ++v)
+        if (bases[v].len < pk->base_len[v] || bases[v].stride < sizeof(Affine<C>) || !bases[v].points)
+            return guard(PM_ERR_LEN_MISMATCH);
+    HostCsr host[3];
+    st = pk_upload_matrices<C>(ctx, pk, a, b, c, host);
+    if (st) return guard(st);
+    std::vector<Affine<C>> tmp;
+    st = pk_fill_bases<C>(ctx, pk, [&](int v, uint64_t start, uint64_t count, Affine<C> *dst) -> int {
+        tmp.resize(count);
+        repack_bases<C>((const uint8_t *)bases[v].points + start * bases[v].stride, bases[v].stride, count, tmp.data());
+        PM_HIP(ctx, hipMemcpy(dst, tmp.data(), count * sizeof(Affine<C>), hipMemcpyHostToDevice));
+        return PM_OK;
+    });
+    if (st) return guard(st);
+    *out = pk;
+    return PM_OK;
+}
+
+extern "C" int pm_pk_load(pm_ctx *ctx, int curve, uint64_t n, uint64_t m0, uint64_t mw, uint64_t nr, uint64_t sigma,
+                          const pm_csr *a, const pm_csr *b, const pm_csr *c, const pm_base_array bases[PM_NUM_BASE_VECS],
+                          int shard_rank, int shard_count, pm_pk **out) {
+    if (!ctx || !a || !b || !c || !bases || !out) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(curve, pk_load_impl<BlsCurve>(ctx, n, m0, mw, nr, sigma, a, b, c, bases, shard_rank, shard_count, out),
+                       pk_load_impl<BnCurve>(ctx, n, m0, mw, nr, sigma, a, b, c, bases, shard_rank, shard_count, out));
+}
+
+// generate_proving_key (generator.rs:24-167) with the trapdoors supplied.  The dense uj_wj_lcs loop
+// (:112-136) becomes one sparse pass over A, B, C:
+//   column j' of z_tail (j = j' + m0), L1 = L[2m0+r], L2 = L[2m0+nr+r]:
+//     R1CS column k = j' < m0+mw:  u = sum_r A[r][k](L1+L2) + B[r][k](L1-L2)
+//                                  w = 4 sum_r C[r][k] L1  (+ 4 L[k] if k < m0)
+//     y column t = j' - (m0+mw):   u = 0, w = L[t] + L[t+m0] (t < m0) | L1 + L2 (t = m0 + r)
+template <class C>
+static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a, const pm_csr *b,
+                            const pm_csr *c, const uint64_t *x_trap, const uint64_t *z_trap, int shard_rank,
+                            int shard_count, pm_pk **out) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    pm_pk *pk = new pm_pk();
+    memset(pk, 0, sizeof(*pk));
+    auto guard = [&](int st) { if (st != PM_OK) pk_release(pk); return st; };
+    int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count);
+    if (st) return guard(st);
+    HostCsr host[3];
+    st = pk_upload_matrices<C>(ctx, pk, a, b, c, host);
+    if (st) return guard(st);
+    const uint64_t n = pk->n, sigma = pk->sigma, mcols = m0 + mw, Lz = 2 * m0 + mw + nr;
+    Fr x, z, omega;
+    memcpy(x.l, x_trap, 32);
+    memcpy(z.l, z_trap, 32);
+    memcpy(omega.l, pk->omega, 32);
+    Fr xn = pow_u64<P>(x, n), one = Fr::one();
+    if (xn.eq(one) || pow_u64<P>(z, n).eq(one)) return guard(PM_ERR_INVALID_ARG);  // sample_element_outside_domain
+    Fr y = pow_u64<P>(x, sigma), yinv = inverse<P>(y);                            // generator.rs:73
+    Fr y_alpha = pow_u64<P>(yinv, 3), y_to_minus_alpha = pow_u64<P>(y, 3), y_gamma = pow_u64<P>(yinv, 5);
+    Fr zh = sub<P>(xn, one);                                                       // :106
+    // Lagrange coefficients at x (:113): L_i = zh/n * w^i / (x - w^i), host batch inversion
+    std::vector<Fr> L(n), den(n), pre(n);
+    {
+        Fr wi = one, run = one;
+        for (uint64_t i = 0; i < n; ++i) {
+            den[i] = sub<P>(x, wi);
+            L[i] = wi;
+            pre[i] = run;
+            run = mul<P>(run, den[i]);
+            wi = mul<P>(wi, omega);
+        }
+        Fr inv = inverse<P>(run), k = mul<P>(zh, inverse<P>(from_u64<P>(n)));
+        for (uint64_t i = n; i-- > 0;) {
+            Fr di = mul<P>(inv, pre[i]);
+            inv = mul<P>(inv, den[i]);
+            L[i] = mul<P>(mul<P>(L[i], di), k);
+        }
+    }
+    std::vector<Fr> ucol(mcols, Fr::zero()), wcol(Lz, Fr::zero());
+    for (uint64_t r = 0; r < nr; ++r) {
+        Fr L1 = L[2 * m0 + r], L2 = L[2 * m0 + nr + r], sp = add<P>(L1, L2), sm = sub<P>(L1, L2), L1x4 = dbl<P>(dbl<P>(L1));
+        for (uint64_t k = host[0].rowptr[r]; k < host[0].rowptr[r + 1]; ++k) {
+            Fr v; memcpy(v.l, &host[0].val[4 * k], 32);
+            ucol[host[0].col[k]] = add<P>(ucol[host[0].col[k]], mul<P>(v, sp));
+        }
+        for (uint64_t k = host[1].rowptr[r]; k < host[1].rowptr[r + 1]; ++k) {
+            Fr v; memcpy(v.l, &host[1].val[4 * k], 32);
+            ucol[host[1].col[k]] = add<P>(ucol[host[1].col[k]], mul<P>(v, sm));
+        }
+        for (uint64_t k = host[2].rowptr[r]; k < host[2].rowptr[r + 1]; ++k) {
+            Fr v; memcpy(v.l, &host[2].val[4 * k], 32);
+            wcol[host[2].col[k]] = add<P>(wcol[host[2].col[k]], mul<P>(v, L1x4));
+        }
+        wcol[mcols + m0 + r] = sp;
+    }
+    for (uint64_t i = 0; i < m0; ++i) {
+        wcol[i] = add<P>(wcol[i], dbl<P>(dbl<P>(L[i])));
+        wcol[mcols + i] = add<P>(L[i], L[i + m0]);
+    }
+    std::vector<Fr> lcs(Lz);
+    for (uint64_t j = 0; j < Lz; ++j) {
+        Fr u = j < mcols ? ucol[j] : Fr::zero();
+        lcs[j] = mul<P>(add<P>(mul<P>(u, y_gamma), wcol[j]), y_to_minus_alpha);  // :134
+    }
+    // per-vector scale of the x-power vectors (generator.rs:82-109)
+    Fr scale[PM_NUM_BASE_VECS];
+    scale[PM_X_POWERS] = one;
+    scale[PM_X_POWERS_Y_ALPHA] = y_alpha;
+    scale[PM_X_POWERS_Y_GAMMA] = y_gamma;
+    scale[PM_X_POWERS_Y_GAMMA_Z] = mul<P>(y_gamma, z);
+    scale[PM_X_POWERS_ZH_BY_Y_ALPHA] = mul<P>(zh, y_to_minus_alpha);
+    const uint64_t CH = (uint64_t)1 << 22;
+    st = pk_fill_bases<C>(ctx, pk, [&](int v, uint64_t start, uint64_t count, Affine<C> *dst) -> int {
+        PM_HIP(ctx, ctx->scratch.reserve(std::min(count, CH) * sizeof(Fr)));
+        Fr *d_sc = ctx->scratch.as<Fr>();
+        for (uint64_t s = 0; s < count; s += CH) {
+            uint64_t cnt = std::min(CH, count - s);
+            if (v == PM_UJ_WJ_LCS_BY_Y_ALPHA) {
+                PM_HIP(ctx, hipMemcpyAsync(d_sc, &lcs[start + s], cnt * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+            } else {
+                Fr first = mul<P>(scale[v], pow_u64<P>(x, start + s));
+                PM_TRY(powers_fill<C>(ctx, d_sc, cnt, first, x));
+            }
+            PM_TRY(fixed_base_batch<C>(ctx, d_sc, cnt, dst + s));
+            PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return PM_OK;
+    });
+    if (st) return guard(st);
+    *out = pk;
+    return PM_OK;
+}
+
+extern "C" int pm_pk_generate(pm_ctx *ctx, int curve, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a,
+                              const pm_csr *b, const pm_csr *c, const uint64_t *x_trapdoor, const uint64_t *z_trapdoor,
+                              int shard_rank, int shard_count, pm_pk **out) {
+    if (!ctx || !a || !b || !c || !x_trapdoor || !z_trapdoor || !out) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(curve, pk_generate_impl<BlsCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, out),
+                       pk_generate_impl<BnCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, out));
+}
+
+extern "C" int pm_pk_info(const pm_pk *pk, uint64_t *n, uint64_t *m0, uint64_t *sigma, uint64_t *omega,
+                          uint64_t base_lens[PM_NUM_BASE_VECS]) {
+    if (!pk) return PM_ERR_INVALID_ARG;
+    if (n) *n = pk->n;
+    if (m0) *m0 = pk->m0;
+    if (sigma) *sigma = pk->sigma;
+    if (omega) memcpy(omega, pk->omega, 32);
+    if (base_lens) for (int i = 0; i < PM_NUM_BASE_VECS; ++i) base_lens[i] = pk->base_len[i];
+    return PM_OK;
+}
+
+extern "C" int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_t offset, size_t len, uint64_t *out_xy) {
+    if (!ctx || !pk || !out_xy || which < 0 || which >= PM_NUM_BASE_VECS) return PM_ERR_INVALID_ARG;
+    if (offset + len > pk->base_len[which]) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    size_t pt = pk->curve == PM_BLS12_381 ? sizeof(Affine<BlsCurve>) : sizeof(Affine<BnCurve>);
+    uint64_t lo = pk->seg_off[which] + offset, hi = lo + len;
+    uint64_t dev_off = 0;
+    bool found = false;
+    if (pk->shard_count == 1) {
+        dev_off = lo;
+        found = true;
+    } else {
+        for (int k = 0; k < 3 && !found; ++k) {
+            uint64_t rl = pk->msm_lo[k] + pk->res_lo[k], rh = pk->msm_lo[k] + pk->res_hi[k];
+            if (lo >= rl && hi <= rh) { dev_off = pk->res_dev_off[k] + (lo - rl); found = true; }
+        }
+    }
+    if (!found) return PM_ERR_INVALID_ARG;  // not resident on this shard
+    PM_HIP(ctx, hipMemcpy(out_xy, (const uint8_t *)pk->d_bases + dev_off * pt, len * pt, hipMemcpyDeviceToHost));
+    return PM_OK;
+}
+
+// -------------------------------------------------------------------------------- prove
+extern "C" int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
+                               uint64_t *a_g1_xy, int *a_inf, uint64_t *c_g1_xy, int *c_inf) {
+    if (!ctx || !pk || !x || !r_a || !a_g1_xy || !a_inf || !c_g1_xy || !c_inf || (pk->mw && !w)) return PM_ERR_INVALID_ARG;
+    if (pk->device != ctx->device) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf),
+                       prove_phase1_impl<BnCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf));
+}
+
+extern "C" int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1) {
+    if (!ctx || !x1 || !u_at_x1) return PM_ERR_INVALID_ARG;
+    if (!ctx->pk) return PM_ERR_STATE;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(ctx->pk->curve, prove_phase2_impl<BlsCurve>(ctx, x1, u_at_x1), prove_phase2_impl<BnCurve>(ctx, x1, u_at_x1));
+}
+
+extern "C" int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
+                               const uint64_t *c_at_x1, uint64_t *d_g1_xy, int *d_inf) {
+    if (!ctx || !x1 || !x2 || !a_at_x1 || !c_at_x1 || !d_g1_xy || !d_inf) return PM_ERR_INVALID_ARG;
+    if (!ctx->pk) return PM_ERR_STATE;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(ctx->pk->curve, prove_phase3_impl<BlsCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf),
+                       prove_phase3_impl<BnCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf));
+}
+
+extern "C" int pm_prove_tap(pm_ctx *ctx, int which, uint64_t *out, size_t max_elems, size_t *n_elems) {
+    if (!ctx || !out || !n_elems) return PM_ERR_INVALID_ARG;
+    if (!ctx->pk || ctx->phase < 1) return PM_ERR_STATE;
+    PM_TRY(set_device(ctx));
+    const pm_pk *pk = ctx->pk;
+    const uint64_t n = pk->n, Lz = 2 * pk->m0 + pk->mw + pk->nr;
+    const void *src = nullptr;
+    size_t cnt = 0;
+    switch (which) {
+        case 0: src = ctx->ue.p; cnt = n; break;
+        case 1: src = ctx->we.p; cnt = n; break;
+        case 2: src = ctx->u.p; cnt = n; break;
+        case 3: src = ctx->w.p; cnt = n; break;
+        case 4: src = (const uint8_t *)ctx->sc_c.p + Lz * 32; cnt = n - 1; break;
+        case 5: src = ctx->wit_u.p; cnt = n; break;
+        case 6: src = ctx->sc_c.p; cnt = Lz; break;
+        case 7:
+            if (ctx->phase < 3) return PM_ERR_STATE;
+            src = ctx->quotient.p; cnt = 8 * pk->sigma + 2 * n - 2; break;
+        default: return PM_ERR_INVALID_ARG;
+    }
+    *n_elems = cnt;
+    size_t k = std::min(cnt, max_elems);
+    PM_HIP(ctx, hipMemcpy(out, src, k * 32, hipMemcpyDeviceToHost));
+    return PM_OK;
+}

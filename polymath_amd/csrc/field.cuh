@@ -1,0 +1,231 @@
+// Prime-field arithmetic for CDNA4 (gfx950): Montgomery form on 32-bit limbs.
+//
+// gfx950 has no 64x64 multiplier; the widest integer multiply-add is v_mad_u64_u32
+// (32x32 + 64 -> 64, carry-out).  A field element is therefore N x u32 limbs in VGPRs
+// (N = 8 for the 255/254-bit scalar fields, 12 for BLS12-381's 381-bit base field), which is
+// byte-identical to arkworks' N/2 x u64 little-endian Montgomery limbs in memory
+// (ark-ff MontBackend) -- no conversion at the FFI boundary.
+//
+// The same templates compile for the host (plain C++), where the library needs a handful of
+// field operations for glue (pm_g1_sum, setup scalars).
+#pragma once
+#include <stdint.h>
+
+#include "constants.cuh"
+
+#if defined(__HIPCC__)
+#define PM_HD __host__ __device__ __forceinline__
+// cold paths (inversions, full additions, doublings): real function calls keep the hot kernels'
+// code size and the build time down
+#define PM_HD_COLD __host__ __device__ __noinline__
+#else
+#define PM_HD inline
+#define PM_HD_COLD inline
+#endif
+
+namespace pm {
+
+template <class P>
+struct Fp {
+    static constexpr int N = P::N;
+    uint32_t l[N];
+
+    PM_HD static Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.l[i] = 0;
+        return r;
+    }
+    PM_HD static Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.l[i] = P::ONE[i];
+        return r;
+    }
+    PM_HD static Fp r2() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.l[i] = P::R2[i];
+        return r;
+    }
+    PM_HD bool is_zero() const {
+        uint32_t a = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) a |= l[i];
+        return a == 0;
+    }
+    PM_HD bool eq(const Fp &o) const {
+        uint32_t a = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) a |= l[i] ^ o.l[i];
+        return a == 0;
+    }
+};
+
+// r = a - MOD if a >= MOD else a   (a < 2*MOD, optional incoming carry bit `hi`)
+template <class P>
+PM_HD void reduce_once(uint32_t *r, const uint32_t *a, uint32_t hi) {
+    constexpr int N = P::N;
+    uint32_t t[N];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        uint64_t d = (uint64_t)a[i] - P::MOD[i] - borrow;
+        t[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+    // a >= MOD  <=>  no final borrow, or the incoming carry covers it
+    bool ge = (borrow == 0) || (hi != 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = ge ? t[i] : a[i];
+}
+
+template <class P>
+PM_HD Fp<P> add(const Fp<P> &a, const Fp<P> &b) {
+    constexpr int N = P::N;
+    uint32_t s[N];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        c += (uint64_t)a.l[i] + b.l[i];
+        s[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    Fp<P> r;
+    reduce_once<P>(r.l, s, (uint32_t)c);
+    return r;
+}
+
+template <class P>
+PM_HD Fp<P> sub(const Fp<P> &a, const Fp<P> &b) {
+    constexpr int N = P::N;
+    uint32_t d[N];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        uint64_t t = (uint64_t)a.l[i] - b.l[i] - borrow;
+        d[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    uint32_t mask = (uint32_t)0 - (uint32_t)borrow;
+    Fp<P> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        c += (uint64_t)d[i] + (P::MOD[i] & mask);
+        r.l[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+template <class P>
+PM_HD Fp<P> neg(const Fp<P> &a) {
+    return a.is_zero() ? a : sub<P>(Fp<P>::zero(), a);
+}
+
+template <class P>
+PM_HD Fp<P> dbl(const Fp<P> &a) {
+    return add<P>(a, a);
+}
+
+// Montgomery multiplication, CIOS over 32-bit limbs: every inner step is one
+// v_mad_u64_u32 (a_j * b_i + t_j) plus the carry add.  Result fully reduced (< MOD).
+template <class P>
+PM_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
+    constexpr int N = P::N;
+    uint32_t t[N + 2];
+#pragma unroll
+    for (int i = 0; i < N + 2; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        uint64_t c = 0;
+        const uint32_t bi = b.l[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            c += (uint64_t)a.l[j] * bi + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[N];
+        t[N] = (uint32_t)c;
+        t[N + 1] = (uint32_t)(c >> 32);
+        const uint32_t m = t[0] * P::INV;
+        c = (uint64_t)m * P::MOD[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            c += (uint64_t)m * P::MOD[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[N];
+        t[N - 1] = (uint32_t)c;
+        t[N] = t[N + 1] + (uint32_t)(c >> 32);
+    }
+    Fp<P> r;
+    reduce_once<P>(r.l, t, t[N]);
+    return r;
+}
+
+template <class P>
+PM_HD Fp<P> sqr(const Fp<P> &a) {
+    return mul<P>(a, a);
+}
+
+// Montgomery form -> canonical integer limbs (multiply by 1).
+template <class P>
+PM_HD Fp<P> from_mont(const Fp<P> &a) {
+    Fp<P> o = Fp<P>::zero();
+    o.l[0] = 1;
+    return mul<P>(a, o);
+}
+template <class P>
+PM_HD Fp<P> to_mont(const Fp<P> &a) {
+    return mul<P>(a, Fp<P>::r2());
+}
+
+template <class P>
+PM_HD_COLD Fp<P> pow_u64(const Fp<P> &a, uint64_t e) {
+    Fp<P> acc = Fp<P>::one(), base = a;
+    while (e) {
+        if (e & 1) acc = mul<P>(acc, base);
+        base = sqr<P>(base);
+        e >>= 1;
+    }
+    return acc;
+}
+
+// a^(MOD-2): Fermat inverse (host glue and one-off device normalisations only).
+template <class P>
+PM_HD_COLD Fp<P> inverse(const Fp<P> &a) {
+    constexpr int N = P::N;
+    uint32_t e[N];
+    uint64_t borrow = 2;
+    for (int i = 0; i < N; ++i) {
+        uint64_t d = (uint64_t)P::MOD[i] - borrow;
+        e[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+    Fp<P> acc = Fp<P>::one();
+    bool started = false;
+    for (int i = N - 1; i >= 0; --i)
+        for (int b = 31; b >= 0; --b) {
+            if (started) acc = sqr<P>(acc);
+            if ((e[i] >> b) & 1) {
+                acc = started ? mul<P>(acc, a) : a;
+                started = true;
+            }
+        }
+    return acc;
+}
+
+template <class P>
+PM_HD Fp<P> from_u64(uint64_t v) {
+    Fp<P> r = Fp<P>::zero();
+    r.l[0] = (uint32_t)v;
+    r.l[1] = (uint32_t)(v >> 32);
+    return to_mont<P>(r);
+}
+
+}  // namespace pm

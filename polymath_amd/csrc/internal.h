@@ -1,0 +1,208 @@
+// Internal declarations shared by the translation units of libpolymath_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/polymath_hip.h"
+#include "ec.cuh"
+
+namespace pm {
+
+// ---- error plumbing: every HIP failure becomes PM_ERR_HIP with a message, never an abort ----
+struct pm_error_sink {
+    std::string msg;
+};
+
+#define PM_HIP(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + \
+                         std::to_string(__LINE__);                                               \
+            return PM_ERR_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)
+
+#define PM_TRY(expr)                  \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != PM_OK) return _s;   \
+    } while (0)
+
+// Growable device buffer owned by a context (never shrinks: the prover reuses its workspaces).
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            if (e != hipSuccess) return e;
+            p = nullptr;
+            bytes = 0;
+        }
+        size_t want = need + need / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, need);
+            want = need;
+        }
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T *as() const { return (T *)p; }
+};
+
+enum TimingSlot {
+    T_WITNESS_MAP = 0,
+    T_NTT = 1,
+    T_POLY = 2,
+    T_MSM_SORT = 3,
+    T_MSM_ACCUMULATE = 4,
+    T_MSM_REDUCE = 5,
+    T_MSM_TOTAL = 6,
+    T_PHASE = 7,
+    T_NUM_SLOTS = 8
+};
+
+struct MsmWorkspace {
+    DevBuf digits, sorted, counts, bucket_off, task_off, cursor, partials, wsum, result, canon;
+};
+
+struct TwiddleCache {
+    int curve = -1;
+    unsigned log_n = 0;
+    DevBuf fwd, inv;  // n/2 twiddles each
+};
+
+}  // namespace pm
+
+struct pm_bases {
+    int curve;
+    int device;
+    size_t len;
+    void *d_points;  // Affine<C>[len]
+};
+
+struct pm_pk {
+    int curve, device;
+    uint64_t n, m0, mw, nr, sigma;
+    unsigned log_n;
+    uint64_t omega[4];
+    int shard_rank, shard_count;
+    // R1CS matrices on the device (CSR; duplicates of a column inside a row removed, see api)
+    uint64_t *d_rowptr[3];
+    uint32_t *d_col[3];
+    uint64_t *d_val[3];
+    uint64_t nnz[3];
+    // all base vectors in one device allocation, ordered
+    //   [uj_wj_lcs | x_powers_zh | x_powers | y_alpha | y_gamma | y_gamma_z]
+    // so that the pair ranges of the merged MSMs are contiguous (DESIGN.md "MSM merging").
+    void *d_bases;
+    uint64_t base_len[PM_NUM_BASE_VECS];  // logical lengths (whole key)
+    uint64_t seg_off[PM_NUM_BASE_VECS];   // element offset of each vector inside the LOGICAL concatenation
+    uint64_t total_points;                // logical
+    // shard: this device holds logical points [res_lo[k], res_hi[k]) of MSM k (0 = a, 1 = c, 2 = d)
+    // stored at d_bases + res_dev_off[k]
+    uint64_t res_lo[3], res_hi[3], res_dev_off[3];
+    uint64_t msm_lo[3], msm_len[3];  // logical pair range of each merged MSM inside the concatenation
+};
+
+struct PendingTimer {
+    int slot;
+    hipEvent_t a, b;
+};
+
+struct pm_ctx {
+    int device;
+    std::vector<PendingTimer> pending_timers;
+    hipStream_t stream;
+    std::string err;
+    double timing_ms[pm::T_NUM_SLOTS];
+    hipEvent_t ev[4];
+    pm::MsmWorkspace msm;
+    pm::TwiddleCache tw[4];
+    pm::DevBuf scratch, flags;
+    // proof in flight
+    const pm_pk *pk;
+    int phase;
+    pm::DevBuf xw, ue, we, u, w, wit_u, u2, sc_a, sc_c, quotient, ztail, lvl[4], ra;
+};
+
+namespace pm {
+
+// ---- per-curve entry points implemented in the .hip translation units -----------------------
+template <class C>
+int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d_data, unsigned log_n, bool inverse);
+
+template <class C>
+int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len,
+            Affine<C> *h_out, int *h_inf);
+
+template <class C>
+int bases_generate_multiples(pm_ctx *ctx, size_t len, Affine<C> *d_out);
+
+template <class C>
+int fixed_base_batch(pm_ctx *ctx, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *d_out);
+
+template <class C>
+int powers_fill(pm_ctx *ctx, Fp<typename C::FrP> *d_out, size_t count, const Fp<typename C::FrP> &scale,
+                const Fp<typename C::FrP> &x);
+
+template <class C>
+int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
+                      uint64_t *a_xy, int *a_inf, uint64_t *c_xy, int *c_inf);
+template <class C>
+int prove_phase2_impl(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
+template <class C>
+int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
+                      const uint64_t *c_at_x1, uint64_t *d_xy, int *d_inf);
+
+inline void timing_reset(pm_ctx *ctx) {
+    for (int i = 0; i < T_NUM_SLOTS; ++i) ctx->timing_ms[i] = 0;
+}
+
+// hipEvent stage timers (replace start_timer!/end_timer!, prover.rs:32-61).  Events are only
+// recorded while a call runs; elapsed times are read in timing_flush() after the call's final
+// stream synchronisation, so timing adds no host round trips.
+struct StageTimer {
+    pm_ctx *ctx;
+    int slot;
+    hipEvent_t a, b;
+    bool ok;
+    StageTimer(pm_ctx *c, int s) : ctx(c), slot(s), ok(false) {
+        if (hipEventCreate(&a) != hipSuccess) return;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+        ok = hipEventRecord(a, ctx->stream) == hipSuccess;
+        if (!ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    }
+    void stop() {
+        if (!ok) return;
+        ok = false;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->pending_timers.push_back(PendingTimer{slot, a, b});
+    }
+    ~StageTimer() { stop(); }
+};
+
+inline void timing_flush(pm_ctx *ctx) {
+    for (auto &t : ctx->pending_timers) {
+        float ms = 0;
+        if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess)
+            ctx->timing_ms[t.slot] += ms;
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    ctx->pending_timers.clear();
+}
+
+}  // namespace pm

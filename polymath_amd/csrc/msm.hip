@@ -1,0 +1,373 @@
+// G1 variable-base multi-scalar multiplication for gfx950 (Pippenger bucket method).
+//
+// Replaces E::G1::msm_unchecked as the reference calls it (/root/reference/src/prover.rs:380-384,
+// call sites :118,:121,:229,:335-354): result = sum_i scalar_i * base_i.  The result is a canonical
+// group element, so the schedule below is free to differ from ark-ec's.
+//
+// Pipeline, all on one HIP stream, no host round trip until the final point:
+//   k_digits      scalar (Montgomery) -> canonical -> W signed c-bit digits, one u32 per
+//                 (window, scalar): (bucket << 1 | negate), NONE for zero digits / infinity bases.
+//   k_hist        LDS-staged histogram: a workgroup owns one (chunk, window) and counts into a
+//                 2^(c-1)-entry LDS table (128 KiB at c = 16 -- this is what CDNA4's 160 KiB LDS
+//                 buys), then flushes its non-zero bins with coalesced global atomics.
+//   k_scan        exclusive scans: bucket offsets, and task offsets after splitting buckets
+//                 longer than SEG entries into SEG-sized tasks (skewed scalars -> hot buckets).
+//   k_scatter     same LDS staging: claim a range per (workgroup, bucket) with one global atomic,
+//                 then place entries with LDS atomics -> base indices grouped by bucket.
+//   k_accumulate  one lane per task: XYZZ mixed adds (8M+2S each) over its <= SEG entries;
+//                 bases are gathered from HBM by index (96 B affine points).
+//   k_bucket_reduce  per window sum_b (b+1) * B_b by per-lane running sums over K buckets, a
+//                 small scalar multiple, and an LDS tree reduction per workgroup.
+//   k_finish      Horner over the windows (c doublings each) and one inversion to affine.
+#include <cstring>
+
+#include "internal.h"
+
+namespace pm {
+
+constexpr uint32_t DIGIT_NONE = 0xFFFFFFFFu;
+
+struct MsmPlan {
+    unsigned c, nwin, nbuckets;  // nbuckets = 2^(c-1) per window
+    unsigned seg;                // max entries per accumulate task
+    size_t len;
+    unsigned chunk, nchunks;     // scalars per histogram workgroup
+    unsigned red_threads, red_k; // bucket-reduce geometry per window
+    size_t max_tasks;
+};
+
+static MsmPlan make_plan(size_t len, unsigned scalar_bits) {
+    MsmPlan p;
+    p.len = len;
+    // choose c minimising  W(c) * (len + 6 * 2^(c-1))   (6 ~ cost of the reduce per bucket in madds)
+    double best = 1e300;
+    unsigned bc = 4;
+    for (unsigned c = 4; c <= 16; ++c) {
+        unsigned w = (scalar_bits + 1 + c - 1) / c;
+        double cost = (double)w * ((double)len + 6.0 * (double)(1u << (c - 1)));
+        if (cost < best) { best = cost; bc = c; }
+    }
+    p.c = bc;
+    p.nwin = (scalar_bits + 1 + bc - 1) / bc;
+    p.nbuckets = 1u << (bc - 1);
+    size_t avg = len / p.nbuckets + 1;
+    size_t seg = 2 * avg;
+    if (seg < 64) seg = 64;
+    p.seg = (unsigned)seg;
+    p.chunk = 1u << 16;
+    if (len < p.chunk) p.chunk = (unsigned)(len ? len : 1);
+    p.nchunks = (unsigned)((len + p.chunk - 1) / p.chunk);
+    p.red_threads = p.nbuckets < 2048 ? p.nbuckets : 2048;
+    p.red_k = p.nbuckets / p.red_threads;
+    p.max_tasks = (size_t)p.nwin * p.nbuckets + ((size_t)p.nwin * len) / p.seg + 1;
+    return p;
+}
+
+// ------------------------------------------------------------------------------ digits
+template <class C>
+__global__ void k_digits(const Fp<typename C::FrP> *scalars, const Affine<C> *bases, uint32_t *digits, size_t len,
+                         unsigned c, unsigned nwin) {
+    typedef typename C::FrP P;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    Fp<P> k = from_mont<P>(scalars[i]);
+    // a base at infinity contributes nothing (ark: msm adds the identity); drop it here so it
+    // never reaches a bucket
+    const uint32_t *bx = (const uint32_t *)&bases[i];
+    uint32_t any = 0;
+#pragma unroll
+    for (int t = 0; t < 2 * C::FqP::N; ++t) any |= bx[t];
+    const bool skip = (any == 0);
+    uint32_t carry = 0;
+    const uint32_t half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+    for (unsigned w = 0; w < nwin; ++w) {
+        unsigned lo = w * c, limb = lo >> 5, off = lo & 31;
+        uint32_t v = 0;
+        if (limb < (unsigned)P::N) {
+            uint64_t two = k.l[limb];
+            if (limb + 1 < (unsigned)P::N) two |= (uint64_t)k.l[limb + 1] << 32;
+            v = (uint32_t)(two >> off) & mask;
+        }
+        uint32_t d = v + carry;
+        uint32_t out;
+        if (d > half) {  // negative digit d - 2^c, magnitude m = 2^c - d in [0, 2^(c-1))
+            uint32_t m = full - d;
+            out = m ? (((m - 1) << 1) | 1u) : DIGIT_NONE;
+            carry = 1;
+        } else {
+            out = d ? ((d - 1) << 1) : DIGIT_NONE;
+            carry = 0;
+        }
+        digits[(size_t)w * len + i] = skip ? DIGIT_NONE : out;
+    }
+}
+
+// --------------------------------------------------------------------- LDS-staged counting sort
+__global__ __launch_bounds__(1024) void k_hist(const uint32_t *digits, uint32_t *counts, size_t len, unsigned chunk,
+                                               unsigned nbuckets) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *h = (uint32_t *)smem_raw;
+    const unsigned w = blockIdx.y;
+    for (unsigned b = threadIdx.x; b < nbuckets; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk;
+    if (hi > len) hi = len;
+    const uint32_t *d = digits + (size_t)w * len;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t v = d[i];
+        if (v != DIGIT_NONE) atomicAdd(&h[v >> 1], 1u);
+    }
+    __syncthreads();
+    uint32_t *cw = counts + (size_t)w * nbuckets;
+    for (unsigned b = threadIdx.x; b < nbuckets; b += blockDim.x) {
+        uint32_t v = h[b];
+        if (v) atomicAdd(&cw[b], v);
+    }
+}
+
+// Single-workgroup exclusive scans over all nwin*nbuckets buckets:
+//   bucket_off[g] = sum_{g' < g} counts[g'],   task_off[g] = sum_{g' < g} ceil(counts[g'] / seg)
+// (+ totals at index G).  G <= 2^20, so one 1024-thread workgroup with a sequential tile per lane.
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t *counts, uint32_t *bucket_off, uint32_t *task_off,
+                                               size_t G, unsigned seg) {
+    __shared__ uint32_t s_a[1024], s_b[1024];
+    const unsigned tid = threadIdx.x, T = blockDim.x;
+    size_t per = (G + T - 1) / T, lo = (size_t)tid * per, hi = lo + per;
+    if (lo > G) lo = G;
+    if (hi > G) hi = G;
+    uint32_t sa = 0, sb = 0;
+    for (size_t g = lo; g < hi; ++g) {
+        uint32_t cnt = counts[g];
+        sa += cnt;
+        sb += (cnt + seg - 1) / seg;
+    }
+    s_a[tid] = sa;
+    s_b[tid] = sb;
+    __syncthreads();
+    for (unsigned off = 1; off < T; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t va = 0, vb = 0;
+        if (tid >= off) { va = s_a[tid - off]; vb = s_b[tid - off]; }
+        __syncthreads();
+        s_a[tid] += va;
+        s_b[tid] += vb;
+        __syncthreads();
+    }
+    uint32_t ra = s_a[tid] - sa, rb = s_b[tid] - sb;  // exclusive prefix of this lane's tile
+    for (size_t g = lo; g < hi; ++g) {
+        uint32_t cnt = counts[g];
+        bucket_off[g] = ra;
+        task_off[g] = rb;
+        ra += cnt;
+        rb += (cnt + seg - 1) / seg;
+    }
+    if (tid == T - 1) {
+        bucket_off[G] = s_a[T - 1];
+        task_off[G] = s_b[T - 1];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scatter(const uint32_t *digits, const uint32_t *bucket_off, uint32_t *cursor,
+                                                  uint32_t *sorted, size_t len, unsigned chunk, unsigned nbuckets) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *h = (uint32_t *)smem_raw;
+    const unsigned w = blockIdx.y;
+    for (unsigned b = threadIdx.x; b < nbuckets; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk;
+    if (hi > len) hi = len;
+    const uint32_t *d = digits + (size_t)w * len;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t v = d[i];
+        if (v != DIGIT_NONE) atomicAdd(&h[v >> 1], 1u);
+    }
+    __syncthreads();
+    const size_t gbase = (size_t)w * nbuckets;
+    for (unsigned b = threadIdx.x; b < nbuckets; b += blockDim.x) {
+        uint32_t v = h[b];
+        if (v) h[b] = bucket_off[gbase + b] + atomicAdd(&cursor[gbase + b], v);
+    }
+    __syncthreads();
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint32_t v = d[i];
+        if (v != DIGIT_NONE) {
+            uint32_t pos = atomicAdd(&h[v >> 1], 1u);
+            sorted[pos] = ((uint32_t)i << 1) | (v & 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- accumulate
+template <class C>
+__global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, const uint32_t *counts,
+                                                    const uint32_t *bucket_off, const uint32_t *task_off,
+                                                    const Affine<C> *bases, XYZZ<C> *partials, size_t G, unsigned seg) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = task_off[G];
+    if (t >= total) return;
+    // bucket of task t: largest g with task_off[g] <= t  (empty buckets have zero tasks)
+    size_t lo = 0, hi = G;
+    while (hi - lo > 1) {
+        size_t mid = (lo + hi) >> 1;
+        if (task_off[mid] <= t) lo = mid; else hi = mid;
+    }
+    const size_t g = lo;
+    const uint32_t k = (uint32_t)t - task_off[g];
+    const uint32_t start = bucket_off[g] + k * seg;
+    uint32_t end = bucket_off[g] + counts[g];
+    if (start + seg < end) end = start + seg;
+    XYZZ<C> acc = XYZZ<C>::identity();
+    for (uint32_t e = start; e < end; ++e) {
+        uint32_t v = sorted[e];
+        Affine<C> p = bases[v >> 1];
+        xyzz_madd<C>(acc, p, (v & 1u) != 0);
+    }
+    partials[t] = acc;
+}
+
+// ------------------------------------------------------------------------- bucket reduce
+// Window sum S_w = sum_b (b+1) * B_b, B_b = sum of the bucket's task partials.
+// Lane j of the window owns buckets [jK, jK+K):  sum (b+1) B_b = jK * A + sum_i (i+1) B_{jK+i},
+// the second term by the descending running-sum trick, A = run.  Workgroup tree-reduces in LDS.
+template <class C>
+__global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off,
+                                                       XYZZ<C> *wsum, unsigned nbuckets, unsigned K,
+                                                       unsigned threads_per_window, unsigned blocks_per_window) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ<C> *sh = (XYZZ<C> *)smem_raw;
+    const unsigned w = blockIdx.x / blocks_per_window, bw = blockIdx.x % blocks_per_window;
+    const unsigned j = bw * blockDim.x + threadIdx.x;
+    XYZZ<C> res = XYZZ<C>::identity();
+    if (j < threads_per_window) {
+        XYZZ<C> run = XYZZ<C>::identity(), acc = XYZZ<C>::identity();
+        const size_t gbase = (size_t)w * nbuckets + (size_t)j * K;
+        for (int i = (int)K - 1; i >= 0; --i) {
+            uint32_t t0 = task_off[gbase + i], t1 = task_off[gbase + i + 1];
+            for (uint32_t t = t0; t < t1; ++t) run = xyzz_add<C>(run, partials[t]);
+            acc = xyzz_add<C>(acc, run);
+        }
+        // acc += (j*K) * run   (double-and-add, j*K < 2^15)
+        uint32_t s = j * K;
+        XYZZ<C> m = XYZZ<C>::identity();
+        for (int b = 31 - __clz((int)(s | 1)); b >= 0; --b) {
+            m = xyzz_dbl<C>(m);
+            if ((s >> b) & 1) m = xyzz_add<C>(m, run);
+        }
+        res = s ? xyzz_add<C>(acc, m) : acc;
+    }
+    sh[threadIdx.x] = res;
+    __syncthreads();
+    for (unsigned off = blockDim.x >> 1; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = xyzz_add<C>(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wsum[blockIdx.x] = sh[0];
+}
+
+template <class C>
+struct MsmResult {
+    Affine<C> p;
+    int inf;
+    int pad[3];
+};
+
+// Final combine: S = sum_w 2^(c w) S_w by Horner, then one inversion to affine.
+template <class C>
+__global__ void k_finish(const XYZZ<C> *wsum, unsigned nwin, unsigned blocks_per_window, unsigned c, MsmResult<C> *out) {
+    __shared__ XYZZ<C> sw[64];
+    const unsigned w = threadIdx.x;
+    if (w < nwin) {
+        XYZZ<C> s = XYZZ<C>::identity();
+        for (unsigned b = 0; b < blocks_per_window; ++b) s = xyzz_add<C>(s, wsum[w * blocks_per_window + b]);
+        sw[w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        XYZZ<C> acc = sw[nwin - 1];
+        for (int ww = (int)nwin - 2; ww >= 0; --ww) {
+            for (unsigned k = 0; k < c; ++k) acc = xyzz_dbl<C>(acc);
+            acc = xyzz_add<C>(acc, sw[ww]);
+        }
+        Affine<C> a = xyzz_to_affine<C>(acc);
+        out->p = a;
+        out->inf = acc.is_identity() ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------- driver
+template <class C>
+int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *h_out,
+            int *h_inf) {
+    typedef typename C::FrP FrP;
+    if (len == 0) {
+        *h_out = Affine<C>::infinity();
+        *h_inf = 1;
+        return PM_OK;
+    }
+    if (len >= ((size_t)1 << 31)) return PM_ERR_INVALID_ARG;
+    StageTimer t_total(ctx, T_MSM_TOTAL);
+    MsmPlan p = make_plan(len, (unsigned)FrP::BITS);
+    MsmWorkspace &ws = ctx->msm;
+    const size_t G = (size_t)p.nwin * p.nbuckets;
+    PM_HIP(ctx, ws.digits.reserve((size_t)p.nwin * len * 4));
+    PM_HIP(ctx, ws.sorted.reserve((size_t)p.nwin * len * 4));
+    PM_HIP(ctx, ws.counts.reserve(2 * G * 4));  // counts | cursor, one memset
+    PM_HIP(ctx, ws.bucket_off.reserve((G + 1) * 4));
+    PM_HIP(ctx, ws.task_off.reserve((G + 1) * 4));
+    PM_HIP(ctx, ws.partials.reserve(p.max_tasks * sizeof(XYZZ<C>)));
+    unsigned bpw = (p.red_threads + 255) / 256;
+    unsigned red_block = p.red_threads < 256 ? p.red_threads : 256;
+    if (red_block < 64) red_block = 64;
+    PM_HIP(ctx, ws.wsum.reserve((size_t)p.nwin * bpw * sizeof(XYZZ<C>)));
+    PM_HIP(ctx, ws.result.reserve(sizeof(MsmResult<C>)));
+    uint32_t *counts = ws.counts.as<uint32_t>(), *cursor = counts + G;
+    {
+        StageTimer t(ctx, T_MSM_SORT);
+        PM_HIP(ctx, hipMemsetAsync(counts, 0, 2 * G * 4, ctx->stream));
+        hipLaunchKernelGGL(k_digits<C>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, d_scalars, d_bases,
+                           ws.digits.as<uint32_t>(), len, p.c, p.nwin);
+        PM_HIP(ctx, hipGetLastError());
+        size_t lds = (size_t)p.nbuckets * 4;
+        if (lds > 48 * 1024) {  // CDNA4: up to 160 KiB of LDS per workgroup, opt in above the default cap
+            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        hipLaunchKernelGGL(k_hist, dim3(p.nchunks, p.nwin), dim3(1024), lds, ctx->stream, ws.digits.as<uint32_t>(), counts,
+                           len, p.chunk, p.nbuckets);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, counts, ws.bucket_off.as<uint32_t>(),
+                           ws.task_off.as<uint32_t>(), G, p.seg);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_scatter, dim3(p.nchunks, p.nwin), dim3(1024), lds, ctx->stream, ws.digits.as<uint32_t>(),
+                           ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>(), len, p.chunk, p.nbuckets);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    {
+        StageTimer t(ctx, T_MSM_ACCUMULATE);
+        size_t blocks = (p.max_tasks + 127) / 128;
+        hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(),
+                           counts, ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), d_bases,
+                           ws.partials.as<XYZZ<C>>(), G, p.seg);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    {
+        StageTimer t(ctx, T_MSM_REDUCE);
+        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ<C>),
+                           ctx->stream, ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.wsum.as<XYZZ<C>>(),
+                           p.nbuckets, p.red_k, p.red_threads, bpw);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_finish<C>, dim3(1), dim3(64), 0, ctx->stream, ws.wsum.as<XYZZ<C>>(), p.nwin, bpw, p.c,
+                           ws.result.as<MsmResult<C>>());
+        PM_HIP(ctx, hipGetLastError());
+    }
+    MsmResult<C> res;
+    PM_HIP(ctx, hipMemcpyAsync(&res, ws.result.p, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *h_out = res.p;
+    *h_inf = res.inf;
+    return PM_OK;
+}
+
+template int msm_run<BlsCurve>(pm_ctx *, const Affine<BlsCurve> *, const Fp<BlsFrP> *, size_t, Affine<BlsCurve> *, int *);
+template int msm_run<BnCurve>(pm_ctx *, const Affine<BnCurve> *, const Fp<BnFrP> *, size_t, Affine<BnCurve> *, int *);
+
+}  // namespace pm

@@ -1,0 +1,172 @@
+// Radix-2 NTT / iNTT over the scalar field Fr for gfx950.
+//
+// Replaces ark-poly Radix2EvaluationDomain::{fft_in_place, ifft_in_place} as the reference calls
+// them (/root/reference/src/prover.rs:241,319,325): natural order in, natural order out, omega =
+// two_adic_root^(2^(s - log n)), inverse scaled by n^-1.
+//
+// Kernel plan: the transform is split into passes of up to LOG_TILE = 8 butterfly
+// stages.  In one pass a 256-thread workgroup owns a tile of 2^8 rows x 8 columns of Fr
+// (64 KiB of LDS out of CDNA4's 160 KiB), loads it with 256-byte-contiguous segments (8 x 32 B),
+// runs its 8 stages out of LDS, and stores it back, so a 2^22-point transform touches HBM 3 times
+// instead of 22.  Twiddles come from one n/2-entry table per (curve, log n, direction), built
+// once per context and L2/MALL resident across passes.
+#include <cstring>
+
+#include "internal.h"
+
+namespace pm {
+
+template <class P>
+struct PowTable {
+    Fp<P> w[33];  // w[k] = omega^(2^k)
+};
+
+template <class P>
+__global__ void k_twiddles(Fp<P> *out, size_t count, PowTable<P> tab, unsigned nbits) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fp<P> acc = Fp<P>::one();
+    for (unsigned k = 0; k < nbits; ++k)
+        if ((j >> k) & 1) acc = mul<P>(acc, tab.w[k]);
+    out[j] = acc;
+}
+
+template <class P>
+__global__ void k_bitrev(Fp<P> *a, unsigned log_n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)1 << log_n;
+    if (i >= n) return;
+    size_t j = __brevll((unsigned long long)i) >> (64 - log_n);
+    if (i < j) {
+        Fp<P> x = a[i], y = a[j];
+        a[i] = y;
+        a[j] = x;
+    }
+}
+
+// One pass = stages [s0, s0+ns) of the DIT network on bit-reversed input.  Stage s (1-based)
+// pairs indices differing in bit s-1; the twiddle of butterfly (blk, j) is tw[j << (log_n - s)].
+// Decompose index i = (hi, mid, lo): lo = s0 bits (already-processed strides), mid = ns bits
+// (this pass), hi = the rest.  A workgroup takes one `hi`, COLS consecutive `lo`, all 2^ns `mid`.
+constexpr int LOG_TILE = 8;
+constexpr int COLS = 8;
+
+template <class P>
+__global__ __launch_bounds__(256) void k_ntt_pass(Fp<P> *a, const Fp<P> *tw, unsigned log_n, unsigned s0, unsigned ns,
+                                                   unsigned log_cols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Fp<P> *tile = (Fp<P> *)smem_raw;  // [2^ns][cols]
+    const unsigned cols = 1u << log_cols, rows = 1u << ns;
+    const size_t lo_groups = ((size_t)1 << s0) >> log_cols;  // groups of `cols` consecutive lo values
+    const size_t g = blockIdx.x;
+    const size_t hi = g / lo_groups, lo0 = (g % lo_groups) << log_cols;
+    const size_t base = (hi << (s0 + ns)) + lo0;
+    const unsigned tid = threadIdx.x;
+    // load: element (r, c) lives at base + (r << s0) + c
+    for (unsigned e = tid; e < rows * cols; e += blockDim.x) {
+        unsigned r = e >> log_cols, c = e & (cols - 1);
+        tile[e] = a[base + ((size_t)r << s0) + c];
+    }
+    __syncthreads();
+    for (unsigned t = 0; t < ns; ++t) {
+        const unsigned s = s0 + t + 1;          // global stage, 1-based
+        const unsigned half = 1u << t;          // distance in rows
+        for (unsigned e = tid; e < (rows >> 1) * cols; e += blockDim.x) {
+            unsigned c = e & (cols - 1), k = e >> log_cols;
+            unsigned r0 = ((k >> t) << (t + 1)) | (k & (half - 1)), r1 = r0 + half;
+            // position of the butterfly inside its size-2^s block: j = (r0 mod 2^(t+1)) * 2^s0 + lo
+            size_t j = ((size_t)(r0 & (half - 1)) << s0) + lo0 + c;
+            Fp<P> w = tw[j << (log_n - s)];
+            Fp<P> x = tile[r0 * cols + c], y = mul<P>(tile[r1 * cols + c], w);
+            tile[r0 * cols + c] = add<P>(x, y);
+            tile[r1 * cols + c] = sub<P>(x, y);
+        }
+        __syncthreads();
+    }
+    for (unsigned e = tid; e < rows * cols; e += blockDim.x) {
+        unsigned r = e >> log_cols, c = e & (cols - 1);
+        a[base + ((size_t)r << s0) + c] = tile[e];
+    }
+}
+
+template <class P>
+__global__ void k_scale(Fp<P> *a, size_t n, Fp<P> s) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = mul<P>(a[i], s);
+}
+
+template <class C>
+static int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    const int cid = C::ID;
+    TwiddleCache *slot = nullptr;
+    for (auto &t : ctx->tw)
+        if (t.curve == cid && t.log_n == log_n) slot = &t;
+    if (!slot) {
+        // evict round-robin: slot index by log_n parity keeps n and 2n tables both resident
+        slot = &ctx->tw[(log_n & 1) + 2 * (cid & 1)];
+        slot->curve = cid;
+        slot->log_n = log_n;
+        size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
+        PM_HIP(ctx, slot->fwd.reserve(half * sizeof(Fr)));
+        PM_HIP(ctx, slot->inv.reserve(half * sizeof(Fr)));
+        Fr root;
+        for (int i = 0; i < P::N; ++i) root.l[i] = C::ROOT_MONT[i];
+        for (unsigned i = log_n; i < (unsigned)C::TWO_ADICITY; ++i) root = sqr<P>(root);
+        Fr rinv = inverse<P>(root);
+        for (int dir = 0; dir < 2; ++dir) {
+            PowTable<P> tab;
+            Fr w = dir ? rinv : root;
+            for (unsigned k = 0; k < 33; ++k) {
+                tab.w[k] = w;
+                w = sqr<P>(w);
+            }
+            Fr *dst = dir ? slot->inv.as<Fr>() : slot->fwd.as<Fr>();
+            unsigned blocks = (unsigned)((half + 255) / 256);
+            hipLaunchKernelGGL(k_twiddles<P>, dim3(blocks), dim3(256), 0, ctx->stream, dst, half, tab,
+                               log_n ? log_n - 1 : 0);
+            PM_HIP(ctx, hipGetLastError());
+        }
+    }
+    *out = inv_dir ? slot->inv.as<Fr>() : slot->fwd.as<Fr>();
+    return PM_OK;
+}
+
+template <class C>
+int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    if (log_n > (unsigned)C::TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;  // D::new(..) None, prover.rs:83,317
+    if (log_n == 0) return PM_OK;
+    StageTimer timer(ctx, T_NTT);
+    const size_t n = (size_t)1 << log_n;
+    const Fr *tw = nullptr;
+    PM_TRY(twiddles_get<C>(ctx, log_n, inv_dir, &tw));
+    hipLaunchKernelGGL(k_bitrev<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, log_n);
+    PM_HIP(ctx, hipGetLastError());
+    unsigned s0 = 0;
+    while (s0 < log_n) {
+        unsigned ns = log_n - s0 < (unsigned)LOG_TILE ? log_n - s0 : (unsigned)LOG_TILE;
+        // columns: consecutive `lo` values (contiguous in memory); needs s0 >= log_cols
+        unsigned log_cols = 3;
+        if (s0 < log_cols) log_cols = s0;
+        size_t tiles = n >> (ns + log_cols);
+        size_t lds = ((size_t)1 << (ns + log_cols)) * sizeof(Fr);
+        hipLaunchKernelGGL(k_ntt_pass<P>, dim3((unsigned)tiles), dim3(256), lds, ctx->stream, d, tw, log_n, s0, ns,
+                           log_cols);
+        PM_HIP(ctx, hipGetLastError());
+        s0 += ns;
+    }
+    if (inv_dir) {
+        Fr ninv = inverse<P>(from_u64<P>((uint64_t)n));
+        hipLaunchKernelGGL(k_scale<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, n, ninv);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    return PM_OK;
+}
+
+template int ntt_run<BlsCurve>(pm_ctx *, Fp<BlsFrP> *, unsigned, bool);
+template int ntt_run<BnCurve>(pm_ctx *, Fp<BnFrP> *, unsigned, bool);
+
+}  // namespace pm

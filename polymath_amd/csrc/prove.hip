@@ -1,0 +1,535 @@
+// The three GPU phases of create_proof_with_assignment (/root/reference/src/prover.rs:66-237),
+// split at its two Fiat-Shamir calls (:126, :189).  Everything between the FFI and the three
+// output points stays in HBM.
+//
+// The reference materialises U and W densely (prover.rs:87-96, O(n*M)); here the same u_evals /
+// w_evals come from the closed form of SURVEY.md App. A in O(nnz): one lane per R1CS row.
+#include <cstring>
+
+#include "internal.h"
+
+namespace pm {
+
+// --------------------------------------------------------------------------- witness map
+// rows 2m0+r and 2m0+nr+r of (U z, W z) and y_{m0+r} = ((A-B) xw)_r^2  (prover.rs:279-302,
+// common.rs:138-207).  CSR values are Montgomery Fr.
+template <class P>
+__device__ __forceinline__ Fp<P> csr_row_dot(const uint64_t *rowptr, const uint32_t *col, const uint64_t *val,
+                                             const Fp<P> *z, uint64_t r) {
+    Fp<P> acc = Fp<P>::zero();
+    for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        Fp<P> v = *(const Fp<P> *)(val + 4 * k);
+        acc = add<P>(acc, mul<P>(v, z[col[k]]));
+    }
+    return acc;
+}
+
+struct CsrDev {
+    const uint64_t *rowptr;
+    const uint32_t *col;
+    const uint64_t *val;
+};
+
+template <class P>
+__global__ void k_witness_rows(CsrDev A, CsrDev B, CsrDev Cm, const Fp<P> *xw, Fp<P> *ue, Fp<P> *we, Fp<P> *y,
+                               uint64_t m0, uint64_t nr) {
+    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nr) return;
+    Fp<P> az = csr_row_dot<P>(A.rowptr, A.col, A.val, xw, r);
+    Fp<P> bz = csr_row_dot<P>(B.rowptr, B.col, B.val, xw, r);
+    Fp<P> cz = csr_row_dot<P>(Cm.rowptr, Cm.col, Cm.val, xw, r);
+    Fp<P> d = sub<P>(az, bz), d2 = sqr<P>(d);
+    Fp<P> c4 = dbl<P>(dbl<P>(cz));
+    y[m0 + r] = d2;
+    ue[2 * m0 + r] = add<P>(az, bz);
+    we[2 * m0 + r] = add<P>(c4, d2);
+    ue[2 * m0 + nr + r] = d;
+    we[2 * m0 + nr + r] = d2;
+}
+
+// rows < 2 m0 (public-input rows), the x||w prefix of z_tail, and zero padding rows >= 2(m0+nr)
+template <class P>
+__global__ void k_witness_head(const Fp<P> *xw, Fp<P> *ue, Fp<P> *we, Fp<P> *ztail, uint64_t m0, uint64_t mw,
+                               uint64_t nr, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const Fp<P> one = Fp<P>::one();
+    if (i < m0 + mw) ztail[i] = xw[i];
+    Fp<P> *y = ztail + m0 + mw;
+    if (i < m0) {
+        Fp<P> xi = xw[i];
+        Fp<P> omx = sub<P>(one, xi), yi = i ? sqr<P>(omx) : Fp<P>::zero();
+        y[i] = yi;
+        if (i == 0) {
+            ue[0] = dbl<P>(one);
+            we[0] = dbl<P>(dbl<P>(one));
+            ue[m0] = Fp<P>::zero();
+            we[m0] = Fp<P>::zero();
+        } else {
+            ue[i] = add<P>(one, xi);
+            we[i] = add<P>(dbl<P>(dbl<P>(xi)), yi);
+            ue[m0 + i] = omx;
+            we[m0 + i] = yi;
+        }
+    }
+    uint64_t rows = 2 * (m0 + nr);
+    if (i >= rows && i < n) {
+        ue[i] = Fp<P>::zero();
+        we[i] = Fp<P>::zero();
+    }
+}
+
+// flags: bit0 = (Uz)^2 != Wz somewhere (== rem != 0, prover.rs:108), bit1 = h[n-1] != 0 (deg h > n-2),
+// bit2 = h has a non-zero coefficient (cleared means h == 0, prover.rs:107), bit3 = division remainder != 0
+template <class P>
+__global__ void k_check_sap(const Fp<P> *ue, const Fp<P> *we, uint64_t n, unsigned *flags) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!sqr<P>(ue[i]).eq(we[i])) atomicOr(flags, 1u);
+}
+
+template <class P>
+__global__ void k_copy_zero_head(const Fp<P> *src, Fp<P> *dst, uint64_t n, uint64_t zero_rows) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = i < zero_rows ? Fp<P>::zero() : src[i];
+}
+
+template <class P>
+__global__ void k_pad_copy(const Fp<P> *src, Fp<P> *dst, uint64_t n_src, uint64_t n_dst) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_dst) dst[i] = i < n_src ? src[i] : Fp<P>::zero();
+}
+
+template <class P>
+__global__ void k_square(Fp<P> *a, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = sqr<P>(a[i]);
+}
+
+// Scalar vectors of the two phase-1 MSMs, laid out to match the pk's base concatenation:
+//   sc_c = [ z_tail (Lz) | h (n-1) | 2 r_a(X) u(X) (n+1) | r_a^2 (3) | r_a (2) ]     prover.rs:118-123,340-357
+//   sc_a = [ u (n) | 0 | r_a (2) ]                                                   prover.rs:330-338
+// h = u2[n .. 2n-1)  (divide_by_vanishing_poly, prover.rs:105); also the degree checks.
+template <class P>
+__global__ void k_phase1_scalars(const Fp<P> *u, const Fp<P> *u2, const Fp<P> *ra /*r0,r1*/, Fp<P> *sc_c_after_z,
+                                 Fp<P> *sc_a, uint64_t n, unsigned *flags) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const Fp<P> r0 = ra[0], r1 = ra[1];
+    if (i < n) {
+        Fp<P> hi = u2[n + i];
+        if (i < n - 1) {
+            sc_c_after_z[i] = hi;
+            if (!hi.is_zero()) atomicOr(flags, 4u);
+        } else if (!hi.is_zero()) {
+            atomicOr(flags, 2u);
+        }
+        sc_a[i] = u[i];
+    }
+    if (i <= n) {  // coefficient i of 2 r_a(X) u(X) = 2 (r0 u_i + r1 u_{i-1})
+        Fp<P> t = Fp<P>::zero();
+        if (i < n) t = mul<P>(r0, u[i]);
+        if (i > 0) t = add<P>(t, mul<P>(r1, u[i - 1]));
+        sc_c_after_z[(n - 1) + i] = dbl<P>(t);
+    }
+    if (i == 0) {
+        Fp<P> *tail = sc_c_after_z + (n - 1) + (n + 1);
+        tail[0] = sqr<P>(r0);
+        tail[1] = dbl<P>(mul<P>(r0, r1));
+        tail[2] = sqr<P>(r1);
+        tail[3] = r0;
+        tail[4] = r1;
+        sc_a[n] = Fp<P>::zero();
+        sc_a[n + 1] = r0;
+        sc_a[n + 2] = r1;
+    }
+}
+
+// ------------------------------------------------------------------------ Horner (phase 2)
+// u(x1) = sum_k u_k x1^k.  Lane t owns L consecutive coefficients: local Horner, times x1^(tL),
+// workgroup LDS tree sum; one partial per workgroup, summed by the last tiny launch.
+template <class P>
+__global__ __launch_bounds__(256) void k_horner_partial(const Fp<P> *u, uint64_t n, Fp<P> x1, unsigned L, Fp<P> *partials) {
+    __shared__ Fp<P> sh[256];
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t lo = t * L, hi = lo + L;
+    if (hi > n) hi = n;
+    Fp<P> acc = Fp<P>::zero();
+    if (lo < n) {
+        for (uint64_t k = hi; k-- > lo;) acc = add<P>(mul<P>(acc, x1), u[k]);
+        acc = mul<P>(acc, pow_u64<P>(x1, lo));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = add<P>(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+template <class P>
+__global__ void k_sum_small(const Fp<P> *in, unsigned count, Fp<P> *out) {
+    if (threadIdx.x || blockIdx.x) return;
+    Fp<P> acc = Fp<P>::zero();
+    for (unsigned i = 0; i < count; ++i) acc = add<P>(acc, in[i]);
+    out[0] = acc;
+}
+
+// ------------------------------------------------------------- numerator + division (phase 3)
+// Numerator of prover.rs:211-216, multiplied through by Y^-gamma = X^(5 sigma), as a function of
+// the coefficient index k (never materialised):
+//   [0,2)            x2 r_a
+//   2s + [0,3)       r_a + x2 r_a^2
+//   3s + [0,n)       x2 * witness_u                          (prover.rs:168-171)
+//   5s + [0,n+1)     u + x2 * 2 r_a u  - (a + x2 c) at +0    (prover.rs:145-152,366-368,196-197)
+//   8s + [0,2n-1)    x2 * u^2     (witness_w + (u^2 - w) = u^2: N6 == N2)
+struct NumParams {
+    uint64_t n, sigma, len;
+};
+
+template <class P>
+struct NumConsts {
+    Fp<P> x2, r0, r1, x2r0, x2r1, b2[3], two_x2_r0, two_x2_r1, minus_const;
+};
+
+template <class P>
+__device__ __forceinline__ Fp<P> numerator_at(uint64_t k, const NumParams &np, const NumConsts<P> &nc, const Fp<P> *u,
+                                              const Fp<P> *wit_u, const Fp<P> *u2) {
+    const uint64_t s = np.sigma, n = np.n;
+    if (k >= 8 * s) {
+        uint64_t i = k - 8 * s;
+        return i < 2 * n - 1 ? mul<P>(nc.x2, u2[i]) : Fp<P>::zero();
+    }
+    if (k >= 5 * s) {
+        uint64_t i = k - 5 * s;
+        if (i > n) return Fp<P>::zero();
+        Fp<P> t = Fp<P>::zero();
+        if (i < n) t = add<P>(u[i], mul<P>(nc.two_x2_r0, u[i]));
+        if (i > 0) t = add<P>(t, mul<P>(nc.two_x2_r1, u[i - 1]));
+        if (i == 0) t = add<P>(t, nc.minus_const);
+        return t;
+    }
+    if (k >= 3 * s) {
+        uint64_t i = k - 3 * s;
+        return i < n ? mul<P>(nc.x2, wit_u[i]) : Fp<P>::zero();
+    }
+    if (k >= 2 * s) {
+        uint64_t i = k - 2 * s;
+        return i < 3 ? nc.b2[i] : Fp<P>::zero();
+    }
+    if (k == 0) return nc.x2r0;
+    if (k == 1) return nc.x2r1;
+    return Fp<P>::zero();
+}
+
+// Synthetic division by (X - x1): H_k = N_k + x1 H_{k+1}, quotient q_{k-1} = H_k, remainder H_0.
+// Level 0: lane t owns coefficients [tL, tL+L): V_t = local Horner value (carry-in 0).
+// Then carry_t = V_t + x1^L carry_{t+1} is the same recurrence on V with multiplier x1^L: recurse.
+template <class P>
+__global__ void k_div_level0(NumParams np, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2,
+                             Fp<P> x1, unsigned L, uint64_t nchunks, Fp<P> *V) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint64_t lo = t * L, hi = lo + L;
+    if (hi > np.len) hi = np.len;
+    Fp<P> acc = Fp<P>::zero();
+    for (uint64_t k = hi; k-- > lo;) acc = add<P>(mul<P>(acc, x1), numerator_at<P>(k, np, nc, u, wit_u, u2));
+    V[t] = acc;
+}
+
+template <class P>
+__global__ void k_div_levelN(const Fp<P> *in, uint64_t count, Fp<P> xp, unsigned L, uint64_t nchunks, Fp<P> *V) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint64_t lo = t * L, hi = lo + L;
+    if (hi > count) hi = count;
+    Fp<P> acc = Fp<P>::zero();
+    for (uint64_t k = hi; k-- > lo;) acc = add<P>(mul<P>(acc, xp), in[k]);
+    V[t] = acc;
+}
+
+// top level: sequential over <= L values; out[k] = H_k (suffix value INCLUDING element k), out[count] = 0
+template <class P>
+__global__ void k_div_top(const Fp<P> *in, uint64_t count, Fp<P> xp, Fp<P> *H) {
+    if (threadIdx.x || blockIdx.x) return;
+    Fp<P> acc = Fp<P>::zero();
+    H[count] = acc;
+    for (uint64_t k = count; k-- > 0;) {
+        acc = add<P>(mul<P>(acc, xp), in[k]);
+        H[k] = acc;
+    }
+}
+
+// Expand one level down: given Hup[t] = true suffix value at the START of chunk t (and Hup[nchunks] = 0),
+// recompute chunk t of `in` with carry-in Hup[t+1] and write H[k] for every k in the chunk.
+template <class P>
+__global__ void k_div_expandN(const Fp<P> *in, uint64_t count, Fp<P> xp, unsigned L, uint64_t nchunks, const Fp<P> *Hup,
+                              Fp<P> *H) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint64_t lo = t * L, hi = lo + L;
+    if (hi > count) hi = count;
+    Fp<P> acc = Hup[t + 1];
+    for (uint64_t k = hi; k-- > lo;) {
+        acc = add<P>(mul<P>(acc, xp), in[k]);
+        H[k] = acc;
+    }
+    if (t == nchunks - 1) H[count] = Fp<P>::zero();
+}
+
+// Level 0 expansion writes the quotient: q_{k-1} = H_k for k >= 1; H_0 is the remainder.
+template <class P>
+__global__ void k_div_expand0(NumParams np, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2,
+                              Fp<P> x1, unsigned L, uint64_t nchunks, const Fp<P> *Hup, Fp<P> *q, unsigned *flags) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    uint64_t lo = t * L, hi = lo + L;
+    if (hi > np.len) hi = np.len;
+    Fp<P> acc = Hup[t + 1];
+    for (uint64_t k = hi; k-- > lo;) {
+        acc = add<P>(mul<P>(acc, x1), numerator_at<P>(k, np, nc, u, wit_u, u2));
+        if (k > 0) q[k - 1] = acc;
+        else if (!acc.is_zero()) atomicOr(flags, 8u);  // rem != 0, prover.rs:221
+    }
+}
+
+// ------------------------------------------------------------------------------- helpers
+template <class P>
+static Fp<P> load_fr(const uint64_t *p) {
+    Fp<P> r;
+    memcpy(r.l, p, sizeof(r.l));
+    return r;
+}
+template <class C>
+static void store_affine_host(const Affine<C> &a, int inf, uint64_t *xy, int *out_inf) {
+    if (inf) memset(xy, 0, sizeof(Affine<C>));
+    else memcpy(xy, &a, sizeof(Affine<C>));
+    *out_inf = inf;
+}
+
+static inline unsigned nblk(uint64_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
+
+template <class C>
+static int msm_shard(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars, uint64_t *out_xy,
+                     int *out_inf) {
+    // logical pair range [0, msm_len) of MSM `which`; this device holds [res_lo, res_hi)
+    uint64_t lo = pk->res_lo[which], hi = pk->res_hi[which];
+    const Affine<C> *bases = (const Affine<C> *)pk->d_bases + pk->res_dev_off[which];
+    Affine<C> r;
+    int inf = 1;
+    PM_TRY(msm_run<C>(ctx, bases, d_scalars + lo, (size_t)(hi - lo), &r, &inf));
+    store_affine_host<C>(r, inf, out_xy, out_inf);
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------- phase 1
+template <class C>
+int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
+                      uint64_t *a_xy, int *a_inf, uint64_t *c_xy, int *c_inf) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    const uint64_t n = pk->n, m0 = pk->m0, mw = pk->mw, nr = pk->nr;
+    const uint64_t Lz = 2 * m0 + mw + nr;  // |z_tail| = M - m0
+    if (pk->log_n + 1 > (unsigned)C::TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;  // prover.rs:317
+    hipStream_t st = ctx->stream;
+    timing_reset(ctx);
+    ctx->pk = pk;
+    ctx->phase = 0;
+    StageTimer t_phase(ctx, T_PHASE);
+    const uint64_t len_c = Lz + (n - 1) + (n + 1) + 3 + 2, len_a = n + 3;
+    PM_HIP(ctx, ctx->xw.reserve((m0 + mw) * sizeof(Fr)));
+    PM_HIP(ctx, ctx->ue.reserve(n * sizeof(Fr)));
+    PM_HIP(ctx, ctx->we.reserve(n * sizeof(Fr)));
+    PM_HIP(ctx, ctx->u.reserve(n * sizeof(Fr)));
+    PM_HIP(ctx, ctx->w.reserve(n * sizeof(Fr)));
+    PM_HIP(ctx, ctx->wit_u.reserve(n * sizeof(Fr)));
+    PM_HIP(ctx, ctx->u2.reserve(2 * n * sizeof(Fr)));
+    PM_HIP(ctx, ctx->sc_c.reserve(len_c * sizeof(Fr)));
+    PM_HIP(ctx, ctx->sc_a.reserve(len_a * sizeof(Fr)));
+    PM_HIP(ctx, ctx->ra.reserve(2 * sizeof(Fr)));
+    PM_HIP(ctx, ctx->flags.reserve(64));
+    Fr *xw = ctx->xw.as<Fr>(), *ue = ctx->ue.as<Fr>(), *we = ctx->we.as<Fr>(), *u = ctx->u.as<Fr>(), *wv = ctx->w.as<Fr>();
+    Fr *wit_u = ctx->wit_u.as<Fr>(), *u2 = ctx->u2.as<Fr>(), *sc_c = ctx->sc_c.as<Fr>(), *sc_a = ctx->sc_a.as<Fr>();
+    Fr *ra = ctx->ra.as<Fr>();
+    unsigned *flags = ctx->flags.as<unsigned>();
+    PM_HIP(ctx, hipMemsetAsync(flags, 0, 64, st));
+    PM_HIP(ctx, hipMemcpyAsync(xw, x, m0 * sizeof(Fr), hipMemcpyHostToDevice, st));
+    if (mw) PM_HIP(ctx, hipMemcpyAsync(xw + m0, w, mw * sizeof(Fr), hipMemcpyHostToDevice, st));
+    PM_HIP(ctx, hipMemcpyAsync(ra, r_a, 2 * sizeof(Fr), hipMemcpyHostToDevice, st));
+    {
+        StageTimer t(ctx, T_WITNESS_MAP);
+        CsrDev A{pk->d_rowptr[0], pk->d_col[0], pk->d_val[0]}, B{pk->d_rowptr[1], pk->d_col[1], pk->d_val[1]},
+            Cm{pk->d_rowptr[2], pk->d_col[2], pk->d_val[2]};
+        Fr *ztail = sc_c;  // z_tail is the head of the c-MSM scalar vector
+        uint64_t head = n > m0 + mw ? n : m0 + mw;
+        hipLaunchKernelGGL(k_witness_head<P>, dim3(nblk(head)), dim3(256), 0, st, xw, ue, we, ztail, m0, mw, nr, n);
+        PM_HIP(ctx, hipGetLastError());
+        if (nr) {
+            hipLaunchKernelGGL(k_witness_rows<P>, dim3(nblk(nr)), dim3(256), 0, st, A, B, Cm, xw, ue, we, ztail + m0 + mw,
+                               m0, nr);
+            PM_HIP(ctx, hipGetLastError());
+        }
+        // rem == 0 of prover.rs:108  <=>  (Uz)^2 == Wz on the whole domain
+        hipLaunchKernelGGL(k_check_sap<P>, dim3(nblk(n)), dim3(256), 0, st, ue, we, n, flags);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    // N1, N2, N5 (prover.rs:94,96,160-162): coefficients of u, w and of the witness-only U part
+    PM_HIP(ctx, hipMemcpyAsync(u, ue, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    PM_HIP(ctx, hipMemcpyAsync(wv, we, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_copy_zero_head<P>, dim3(nblk(n)), dim3(256), 0, st, ue, wit_u, n, 2 * m0);
+    PM_HIP(ctx, hipGetLastError());
+    PM_TRY(ntt_run<C>(ctx, u, pk->log_n, true));
+    PM_TRY(ntt_run<C>(ctx, wv, pk->log_n, true));
+    PM_TRY(ntt_run<C>(ctx, wit_u, pk->log_n, true));
+    // square_polynomial (prover.rs:315-328): N3, pointwise square, N4
+    hipLaunchKernelGGL(k_pad_copy<P>, dim3(nblk(2 * n)), dim3(256), 0, st, u, u2, n, 2 * n);
+    PM_HIP(ctx, hipGetLastError());
+    PM_TRY(ntt_run<C>(ctx, u2, pk->log_n + 1, false));
+    hipLaunchKernelGGL(k_square<P>, dim3(nblk(2 * n)), dim3(256), 0, st, u2, 2 * n);
+    PM_HIP(ctx, hipGetLastError());
+    PM_TRY(ntt_run<C>(ctx, u2, pk->log_n + 1, true));
+    {
+        StageTimer t(ctx, T_POLY);
+        hipLaunchKernelGGL(k_phase1_scalars<P>, dim3(nblk(n + 1)), dim3(256), 0, st, u, u2, ra, sc_c + Lz, sc_a, n, flags);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    unsigned hflags = 0;
+    PM_HIP(ctx, hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    if (hflags & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
+    if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
+    PM_TRY(msm_shard<C>(ctx, pk, 0, sc_a, a_xy, a_inf));  // [a]_1 = M1 + M2
+    PM_TRY(msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf));  // [c]_1 = M7 + M6 + M3 + M4 + M5
+    t_phase.stop();
+    timing_flush(ctx);
+    ctx->phase = 1;
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------- phase 2
+template <class C>
+int prove_phase2_impl(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    if (ctx->phase < 1 || !ctx->pk) return PM_ERR_STATE;
+    const uint64_t n = ctx->pk->n;
+    hipStream_t st = ctx->stream;
+    Fr x1 = load_fr<P>(x1_in);
+    const unsigned L = 16;
+    uint64_t lanes = (n + L - 1) / L;
+    unsigned blocks = nblk(lanes);
+    PM_HIP(ctx, ctx->scratch.reserve(((size_t)blocks + 1) * sizeof(Fr)));
+    Fr *part = ctx->scratch.as<Fr>();
+    hipLaunchKernelGGL(k_horner_partial<P>, dim3(blocks), dim3(256), 0, st, ctx->u.as<Fr>(), n, x1, L, part);
+    PM_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_sum_small<P>, dim3(1), dim3(64), 0, st, part, blocks, part + blocks);
+    PM_HIP(ctx, hipGetLastError());
+    PM_HIP(ctx, hipMemcpyAsync(u_at_x1, part + blocks, sizeof(Fr), hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    ctx->phase = 2;
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------- phase 3
+template <class C>
+int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in, const uint64_t *a_in,
+                      const uint64_t *c_in, uint64_t *d_xy, int *d_inf) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    if (ctx->phase < 1 || !ctx->pk) return PM_ERR_STATE;
+    const pm_pk *pk = ctx->pk;
+    hipStream_t st = ctx->stream;
+    timing_reset(ctx);
+    StageTimer t_phase(ctx, T_PHASE);
+    const uint64_t n = pk->n, sigma = pk->sigma;
+    Fr x1 = load_fr<P>(x1_in), x2 = load_fr<P>(x2_in), a_at = load_fr<P>(a_in), c_at = load_fr<P>(c_in);
+    Fr rah[2];
+    PM_HIP(ctx, hipMemcpyAsync(rah, ctx->ra.p, sizeof(rah), hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    NumParams np{n, sigma, 8 * sigma + 2 * n - 1};
+    NumConsts<P> nc;
+    nc.x2 = x2;
+    nc.r0 = rah[0];
+    nc.r1 = rah[1];
+    nc.x2r0 = mul<P>(x2, rah[0]);
+    nc.x2r1 = mul<P>(x2, rah[1]);
+    nc.b2[0] = add<P>(rah[0], mul<P>(x2, sqr<P>(rah[0])));
+    nc.b2[1] = add<P>(rah[1], mul<P>(x2, dbl<P>(mul<P>(rah[0], rah[1]))));
+    nc.b2[2] = mul<P>(x2, sqr<P>(rah[1]));
+    nc.two_x2_r0 = dbl<P>(nc.x2r0);
+    nc.two_x2_r1 = dbl<P>(nc.x2r1);
+    nc.minus_const = neg<P>(add<P>(a_at, mul<P>(x2, c_at)));
+    // levels of the chunked recurrence
+    const unsigned L = 32;
+    uint64_t cnt[6];
+    cnt[0] = np.len;
+    int levels = 0;
+    while (cnt[levels] > 4096 && levels < 4) {
+        cnt[levels + 1] = (cnt[levels] + L - 1) / L;
+        ++levels;
+    }
+    // buffers: V[l] (values of level l, l >= 1) and H[l] (suffix values of level l, l >= 1)
+    Fr *V[6] = {nullptr}, *H[6] = {nullptr};
+    for (int l = 1; l <= levels; ++l) {
+        PM_HIP(ctx, ctx->lvl[l - 1].reserve((2 * cnt[l] + 2) * sizeof(Fr)));
+        V[l] = ctx->lvl[l - 1].as<Fr>();
+        H[l] = V[l] + cnt[l];
+    }
+    PM_HIP(ctx, ctx->quotient.reserve((np.len + 1) * sizeof(Fr)));
+    Fr *q = ctx->quotient.as<Fr>();
+    unsigned *flags = ctx->flags.as<unsigned>();
+    const Fr *u = ctx->u.as<Fr>(), *wit_u = ctx->wit_u.as<Fr>(), *u2 = ctx->u2.as<Fr>();
+    {
+        StageTimer t(ctx, T_POLY);
+        PM_HIP(ctx, hipMemsetAsync(flags, 0, 64, st));
+        Fr xp[6];
+        xp[0] = x1;
+        for (int l = 1; l <= levels; ++l) xp[l] = pow_u64<P>(xp[l - 1], L);
+        if (levels == 0) {
+            // small: one lane does the whole division (q written directly)
+            PM_HIP(ctx, ctx->lvl[0].reserve(2 * sizeof(Fr)));
+            Fr *zero = ctx->lvl[0].as<Fr>();
+            PM_HIP(ctx, hipMemsetAsync(zero, 0, 2 * sizeof(Fr), st));
+            hipLaunchKernelGGL(k_div_expand0<P>, dim3(1), dim3(64), 0, st, np, nc, u, wit_u, u2, x1, (unsigned)np.len, (uint64_t)1,
+                               zero, q, flags);
+            PM_HIP(ctx, hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(k_div_level0<P>, dim3(nblk(cnt[1])), dim3(256), 0, st, np, nc, u, wit_u, u2, x1, L, cnt[1], V[1]);
+            PM_HIP(ctx, hipGetLastError());
+            for (int l = 1; l < levels; ++l) {
+                hipLaunchKernelGGL(k_div_levelN<P>, dim3(nblk(cnt[l + 1])), dim3(256), 0, st, V[l], cnt[l], xp[l], L,
+                                   cnt[l + 1], V[l + 1]);
+                PM_HIP(ctx, hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_div_top<P>, dim3(1), dim3(64), 0, st, V[levels], cnt[levels], xp[levels], H[levels]);
+            PM_HIP(ctx, hipGetLastError());
+            for (int l = levels - 1; l >= 1; --l) {
+                hipLaunchKernelGGL(k_div_expandN<P>, dim3(nblk(cnt[l + 1])), dim3(256), 0, st, V[l], cnt[l], xp[l], L,
+                                   cnt[l + 1], H[l + 1], H[l]);
+                PM_HIP(ctx, hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_div_expand0<P>, dim3(nblk(cnt[1])), dim3(256), 0, st, np, nc, u, wit_u, u2, x1, L, cnt[1],
+                               H[1], q, flags);
+            PM_HIP(ctx, hipGetLastError());
+        }
+    }
+    unsigned hflags = 0;
+    PM_HIP(ctx, hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    if (hflags & 8u) return PM_ERR_REMAINDER_NONZERO;  // prover.rs:221
+    PM_TRY(msm_shard<C>(ctx, pk, 2, q, d_xy, d_inf));   // [d]_1 = M8, prover.rs:229
+    t_phase.stop();
+    timing_flush(ctx);
+    ctx->phase = 3;
+    return PM_OK;
+}
+
+#define PM_INST(C)                                                                                                     \
+    template int prove_phase1_impl<C>(pm_ctx *, const pm_pk *, const uint64_t *, const uint64_t *, const uint64_t *,   \
+                                      uint64_t *, int *, uint64_t *, int *);                                           \
+    template int prove_phase2_impl<C>(pm_ctx *, const uint64_t *, uint64_t *);                                         \
+    template int prove_phase3_impl<C>(pm_ctx *, const uint64_t *, const uint64_t *, const uint64_t *,                  \
+                                      const uint64_t *, uint64_t *, int *);
+PM_INST(BlsCurve)
+PM_INST(BnCurve)
+
+}  // namespace pm

@@ -1,0 +1,179 @@
+// Device side of the circuit-specific setup: the reference builds every
+// ProvingKey vector by a serial `g * f(j)` loop with a fresh x.pow([j]) per element
+// (/root/reference/src/generator.rs:169-177).  Here: scalar vectors scale * x^j by a chunked power
+// kernel, then a batched fixed-base multiplication of the G1 generator with an 8-bit windowed table
+// (32 mixed adds per point) and a per-lane Montgomery batch inversion back to affine -- the layout
+// the MSM kernels gather from.
+#include <cstring>
+
+#include "internal.h"
+
+namespace pm {
+
+template <class P>
+__global__ void k_powers(Fp<P> *out, size_t count, Fp<P> scale, Fp<P> x, unsigned L) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * L, hi = lo + L;
+    if (lo >= count) return;
+    if (hi > count) hi = count;
+    Fp<P> acc = mul<P>(scale, pow_u64<P>(x, lo));
+    for (size_t j = lo; j < hi; ++j) {
+        out[j] = acc;
+        acc = mul<P>(acc, x);
+    }
+}
+
+template <class C>
+int powers_fill(pm_ctx *ctx, Fp<typename C::FrP> *d_out, size_t count, const Fp<typename C::FrP> &scale,
+                const Fp<typename C::FrP> &x) {
+    typedef typename C::FrP P;
+    if (!count) return PM_OK;
+    const unsigned L = 64;
+    size_t lanes = (count + L - 1) / L;
+    hipLaunchKernelGGL(k_powers<P>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, d_out, count, scale, x, L);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+}
+
+// table[w * 255 + (d - 1)] = d * 2^(8w) * G, affine
+constexpr int FB_WINDOWS = 32;
+constexpr int FB_BATCH = 8;
+
+template <class C>
+__global__ __launch_bounds__(128) void k_fixed_base(const Fp<typename C::FrP> *scalars, size_t len,
+                                                    const Affine<C> *table, Affine<C> *out) {
+    typedef typename C::FqP Q;
+    typedef Fp<Q> Fq;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * FB_BATCH;
+    if (lo >= len) return;
+    size_t cnt = len - lo < (size_t)FB_BATCH ? len - lo : (size_t)FB_BATCH;
+    // Montgomery batch inversion of the ZZZ coordinates across this lane's FB_BATCH points:
+    // pass 1 computes the points and prefix products (kept in `out` as scratch: X,Y of the XYZZ
+    // result are parked in the output slot, ZZ/ZZZ and the prefix in registers is too much for
+    // 8 points, so recompute-free two-pass with small local arrays).
+    Fq zz[FB_BATCH], zzz[FB_BATCH], pre[FB_BATCH];
+    Fq run = Fq::one();
+    for (size_t i = 0; i < cnt; ++i) {
+        Fp<typename C::FrP> k = from_mont<typename C::FrP>(scalars[lo + i]);
+        XYZZ<C> acc = XYZZ<C>::identity();
+        for (int w = 0; w < FB_WINDOWS; ++w) {
+            unsigned d = (k.l[w >> 2] >> (8 * (w & 3))) & 0xffu;
+            if (d) xyzz_madd<C>(acc, table[w * 255 + (d - 1)], false);
+        }
+        out[lo + i].x = acc.X;
+        out[lo + i].y = acc.Y;
+        zz[i] = acc.ZZ;
+        zzz[i] = acc.ZZZ;
+        pre[i] = run;
+        if (!acc.ZZZ.is_zero()) run = mul<Q>(run, acc.ZZZ);
+    }
+    Fq inv = inverse<Q>(run);
+    for (size_t ii = cnt; ii-- > 0;) {
+        if (zzz[ii].is_zero()) {
+            out[lo + ii] = Affine<C>::infinity();
+            continue;
+        }
+        Fq i3 = mul<Q>(inv, pre[ii]);      // 1 / ZZZ_i
+        inv = mul<Q>(inv, zzz[ii]);
+        Fq i2 = sqr<Q>(mul<Q>(i3, zz[ii]));  // 1 / ZZ_i
+        Affine<C> a;
+        a.x = mul<Q>(out[lo + ii].x, i2);
+        a.y = mul<Q>(out[lo + ii].y, i3);
+        out[lo + ii] = a;
+    }
+}
+
+template <class C>
+static int fixed_base_table(pm_ctx *ctx, const Affine<C> **d_table) {
+    typedef typename C::FqP Q;
+    typedef Fp<Q> Fq;
+    static DevBuf tables[2][16];  // per curve, per device
+    static bool ready[2][16] = {{false}};
+    int dev = ctx->device & 15;
+    DevBuf &buf = tables[C::ID][dev];
+    if (!ready[C::ID][dev]) {
+        const int NT = FB_WINDOWS * 255;
+        std::vector<XYZZ<C>> pts(NT);
+        Affine<C> g;
+        for (int i = 0; i < Q::N; ++i) { g.x.l[i] = C::GX_MONT[i]; g.y.l[i] = C::GY_MONT[i]; }
+        XYZZ<C> base = XYZZ<C>::from_affine(g);
+        for (int w = 0; w < FB_WINDOWS; ++w) {
+            XYZZ<C> acc = XYZZ<C>::identity();
+            for (int d = 0; d < 255; ++d) {
+                acc = xyzz_add<C>(acc, base);
+                pts[w * 255 + d] = acc;
+            }
+            for (int k = 0; k < 8; ++k) base = xyzz_dbl<C>(base);
+        }
+        // host batch inversion of ZZZ
+        std::vector<Fq> pre(NT);
+        Fq run = Fq::one();
+        for (int i = 0; i < NT; ++i) { pre[i] = run; run = mul<Q>(run, pts[i].ZZZ); }
+        Fq inv = inverse<Q>(run);
+        std::vector<Affine<C>> aff(NT);
+        for (int i = NT; i-- > 0;) {
+            Fq i3 = mul<Q>(inv, pre[i]);
+            inv = mul<Q>(inv, pts[i].ZZZ);
+            Fq i2 = sqr<Q>(mul<Q>(i3, pts[i].ZZ));
+            aff[i].x = mul<Q>(pts[i].X, i2);
+            aff[i].y = mul<Q>(pts[i].Y, i3);
+        }
+        PM_HIP(ctx, buf.reserve(NT * sizeof(Affine<C>)));
+        PM_HIP(ctx, hipMemcpy(buf.p, aff.data(), NT * sizeof(Affine<C>), hipMemcpyHostToDevice));
+        ready[C::ID][dev] = true;
+    }
+    *d_table = buf.as<Affine<C>>();
+    return PM_OK;
+}
+
+template <class C>
+int fixed_base_batch(pm_ctx *ctx, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *d_out) {
+    if (!len) return PM_OK;
+    const Affine<C> *table = nullptr;
+    PM_TRY(fixed_base_table<C>(ctx, &table));
+    size_t lanes = (len + FB_BATCH - 1) / FB_BATCH;
+    hipLaunchKernelGGL(k_fixed_base<C>, dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, ctx->stream, d_scalars, len,
+                       table, d_out);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+}
+
+template <class P>
+__global__ void k_iota_mont(Fp<P> *out, size_t len, uint64_t first) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    uint64_t v = first + i;
+    Fp<P> r = Fp<P>::zero();
+    r.l[0] = (uint32_t)v;
+    r.l[1] = (uint32_t)(v >> 32);
+    out[i] = to_mont<P>(r);
+}
+
+// P_i = (i+1) * G   (SURVEY.md §8d MSM micro-inputs)
+template <class C>
+int bases_generate_multiples(pm_ctx *ctx, size_t len, Affine<C> *d_out) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    const size_t CH = (size_t)1 << 22;
+    PM_HIP(ctx, ctx->scratch.reserve((len < CH ? len : CH) * sizeof(Fr)));
+    for (size_t s = 0; s < len; s += CH) {
+        size_t cnt = len - s < CH ? len - s : CH;
+        hipLaunchKernelGGL(k_iota_mont<P>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->scratch.as<Fr>(), cnt, (uint64_t)(s + 1));
+        PM_HIP(ctx, hipGetLastError());
+        PM_TRY(fixed_base_batch<C>(ctx, ctx->scratch.as<Fr>(), cnt, d_out + s));
+    }
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+#define PM_INST(C)                                                                                              \
+    template int powers_fill<C>(pm_ctx *, Fp<typename C::FrP> *, size_t, const Fp<typename C::FrP> &,           \
+                                const Fp<typename C::FrP> &);                                                   \
+    template int fixed_base_batch<C>(pm_ctx *, const Fp<typename C::FrP> *, size_t, Affine<C> *);               \
+    template int bases_generate_multiples<C>(pm_ctx *, size_t, Affine<C> *);
+PM_INST(BlsCurve)
+PM_INST(BnCurve)
+
+}  // namespace pm

@@ -1,0 +1,260 @@
+"""Host-side mirror of the reference's SNARK facade for the prover path
+(/root/reference/src/lib.rs:44-98):
+
+    Polymath(curve, transcript).setup(circuit, x, z) -> ProvingKey      (generator.rs:24-167)
+    Polymath(...).prove(pk, circuit/assignment, r_a) -> Proof           (prover.rs:27-237)
+
+Circuits are anything with `.generate_constraints(cs)` filling a ConstraintSystem (the
+ark-relations ConstraintSynthesizer shape, tests/dummy.rs:25-35), or a ready (R1CS, instance,
+witness) triple.  Everything O(n) or larger runs on the GPU behind the C ABI; this file only does
+the O(m0) scalar glue of common.rs:21-98 and the two Fiat-Shamir calls.  RNG stays with the
+caller: trapdoors and r_a are arguments (generator.rs:72,77; prover.rs:110).
+"""
+import struct
+
+import numpy as np
+
+from . import api
+from .transcript import TRANSCRIPTS
+
+MINUS_ALPHA, MINUS_GAMMA = 3, 5        # common.rs:11,14
+B_POLYMATH = b"polymath"               # common.rs:8
+
+FIELDS = {
+    "bls12_381": dict(r=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+                      p=0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+                      fq_limbs=6),
+    "bn254": dict(r=21888242871839275222246405745257275088548364400416034343698204186575808495617,
+                  p=21888242871839275222246405745257275088696311157297823662689037894645226208583, fq_limbs=4),
+}
+_M64 = (1 << 64) - 1
+
+
+class PolymathProverError(RuntimeError):
+    """The reference panics on these (assert!/unwrap, prover.rs:107,108,221,222,381); the C ABI
+    returns a status and this mirror raises."""
+
+    def __init__(self, phase, status):
+        super().__init__("prove phase %d: %s" % (phase, api.STATUS.get(status, status)))
+        self.phase, self.status = phase, status
+
+
+# ------------------------------------------------------------------ limb <-> int (Montgomery)
+def _to_limbs(vals, nl):
+    if not len(vals):
+        return np.zeros((0, nl), dtype=np.uint64)
+    nb = 8 * nl
+    return np.frombuffer(b"".join(int(v).to_bytes(nb, "little") for v in vals), dtype=np.uint64).reshape(-1, nl).copy()
+
+
+def _from_limbs(row):
+    return sum(int(row[k]) << (64 * k) for k in range(len(row)))
+
+
+class Field:
+    def __init__(self, curve):
+        f = FIELDS[curve]
+        self.curve, self.r, self.p, self.nq = curve, f["r"], f["p"], f["fq_limbs"]
+        self.Rr, self.Rq = pow(2, 256, self.r), pow(2, 64 * self.nq, self.p)
+        self.Rr_inv, self.Rq_inv = pow(self.Rr, -1, self.r), pow(self.Rq, -1, self.p)
+
+    def fr_limbs(self, vals):
+        return _to_limbs([(v % self.r) * self.Rr % self.r for v in vals], 4)
+
+    def fr_int(self, limbs):
+        return _from_limbs(limbs) * self.Rr_inv % self.r
+
+    def g1_affine(self, xy, inf):
+        """x||y Montgomery limbs -> (x, y) canonical ints or None."""
+        if inf:
+            return None
+        return (_from_limbs(xy[:self.nq]) * self.Rq_inv % self.p, _from_limbs(xy[self.nq:]) * self.Rq_inv % self.p)
+
+
+# ------------------------------------------------------------------------- constraint system
+class ConstraintSystem:
+    """Minimal ark-relations ConstraintSystem: variables, assignments and A/B/C rows of
+    (coefficient, column).  Column 0 = One, then instance variables, then witness variables
+    (ConstraintMatrices layout, generator.rs:46-54)."""
+    ONE = ("one", 0)
+
+    def __init__(self, r):
+        self.r = r
+        self.instance, self.witness = [1], []
+        self.rows = []   # (a_lc, b_lc, c_lc) with lc = [(coeff, var)]
+
+    def new_input_variable(self, value):
+        self.instance.append(value % self.r)
+        return ("inst", len(self.instance) - 1)
+
+    def new_witness_variable(self, value):
+        self.witness.append(value % self.r)
+        return ("wit", len(self.witness) - 1)
+
+    def enforce_constraint(self, a, b, c):
+        self.rows.append((list(a), list(b), list(c)))
+
+    def _col(self, var):
+        kind, idx = var
+        return idx if kind in ("one", "inst") else len(self.instance) + idx
+
+    def to_r1cs(self):
+        conv = lambda lc: [(coef % self.r, self._col(v)) for coef, v in lc]
+        return R1CS(len(self.instance), len(self.witness), [conv(a) for a, _, _ in self.rows],
+                    [conv(b) for _, b, _ in self.rows], [conv(c) for _, _, c in self.rows])
+
+
+class R1CS:
+    def __init__(self, m0, mw, a, b, c):
+        assert len(a) == len(b) == len(c)
+        self.m0, self.mw, self.nr, self.a, self.b, self.c = m0, mw, len(a), a, b, c
+
+
+def _csr(field, rows):
+    rowptr, cols, vals = [0], [], []
+    for row in rows:
+        for v, j in row:
+            cols.append(j)
+            vals.append(v)
+        rowptr.append(len(cols))
+    return api.CsrArrays(rowptr, cols, field.fr_limbs(vals) if vals else [])
+
+
+# ------------------------------------------------------------------------------ wire format
+def ser_fr(field, v):
+    return int(v % field.r).to_bytes(32, "little")
+
+
+def ser_fr_slice(field, vs):
+    return struct.pack("<Q", len(vs)) + b"".join(ser_fr(field, v) for v in vs)
+
+
+def ser_g1(field, P):
+    """ark-serialize compressed G1 (macro.rs:7-12 -> serialize_compressed)."""
+    if field.curve == "bls12_381":      # 48 B big-endian x, flags: 0x80 compressed, 0x40 infinity, 0x20 y > -y
+        if P is None:
+            return bytes([0xC0]) + bytes(47)
+        b = bytearray(P[0].to_bytes(48, "big"))
+        b[0] |= 0x80 | (0x20 if P[1] > (field.p - 1) // 2 else 0)
+        return bytes(b)
+    if P is None:                        # BN254: 32 B little-endian x, top byte 0x80 y > -y, 0x40 infinity
+        return bytes(31) + bytes([0x40])
+    b = bytearray(P[0].to_bytes(32, "little"))
+    if P[1] > field.p - P[1]:
+        b[31] |= 0x80
+    return bytes(b)
+
+
+def ser_g1_slice(field, Ps):
+    return struct.pack("<Q", len(Ps)) + b"".join(ser_g1(field, P) for P in Ps)
+
+
+class Proof:
+    """data_structures.rs:10-19."""
+
+    def __init__(self, field, a_g1, c_g1, a_at_x1, d_g1):
+        self.field, self.a_g1, self.c_g1, self.a_at_x1, self.d_g1 = field, a_g1, c_g1, a_at_x1, d_g1
+
+    def to_bytes(self):
+        f = self.field
+        return ser_g1(f, self.a_g1) + ser_g1(f, self.c_g1) + ser_fr(f, self.a_at_x1) + ser_g1(f, self.d_g1)
+
+    def as_dict(self):
+        return dict(a_g1=self.a_g1, c_g1=self.c_g1, a_at_x1=self.a_at_x1, d_g1=self.d_g1)
+
+
+# ------------------------------------------------------------------------------------ facade
+class Polymath:
+    """Polymath<E, T> (lib.rs:44-50): curve = pairing engine, transcript = Fiat-Shamir choice."""
+
+    def __init__(self, curve="bls12_381", transcript="merlin", device=0, ctx=None):
+        self.curve, self.field = curve, Field(curve)
+        self.transcript_cls = TRANSCRIPTS[transcript] if isinstance(transcript, str) else transcript
+        self.ctx = ctx if ctx is not None else api.Context(device)
+
+    # circuit_specific_setup (lib.rs:63-70) -> generate_proving_key (generator.rs:24-167)
+    def setup(self, circuit, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1):
+        r1cs = self._synthesize(circuit)[0]
+        f = self.field
+        A, B, C = _csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)
+        pk = api.ProvingKey.generate(self.ctx, self.curve, r1cs.m0, r1cs.mw, r1cs.nr, A, B, C,
+                                     f.fr_limbs([x_trapdoor])[0], f.fr_limbs([z_trapdoor])[0], shard_rank, shard_count)
+        pk.omega = f.fr_int(pk.omega_limbs)
+        return pk
+
+    def _synthesize(self, circuit):
+        if isinstance(circuit, tuple):
+            return circuit
+        cs = ConstraintSystem(self.field.r)
+        circuit.generate_constraints(cs)                  # prover.rs:44 / generator.rs:37
+        return cs.to_r1cs(), cs.instance, cs.witness
+
+    # prove (lib.rs:72-78) -> create_proof (prover.rs:27-64) -> create_proof_with_assignment (:66-237)
+    def prove(self, pk, circuit, r_a, combine=None):
+        """`combine(xy, inf) -> (xy, inf)` merges per-shard partial points across ranks (RCCL
+        all-gather + pm_g1_sum, polymath_amd.distributed); None for a whole key."""
+        _, instance, witness = self._synthesize(circuit)
+        f = self.field
+        x = f.fr_limbs(instance)
+        w = f.fr_limbs(witness)
+        return self.prove_limbs(pk, instance, x, w, r_a, combine)
+
+    def prove_limbs(self, pk, instance, x_limbs, w_limbs, r_a, combine=None):
+        f, r = self.field, self.field.r
+        rc, a_xy, a_inf, c_xy, c_inf = pk.phase1(x_limbs, w_limbs, f.fr_limbs(r_a))
+        if rc:
+            raise PolymathProverError(1, rc)
+        if combine:
+            a_xy, a_inf = combine(a_xy, a_inf)
+            c_xy, c_inf = combine(c_xy, c_inf)
+        a_g1, c_g1 = f.g1_affine(a_xy, a_inf), f.g1_affine(c_xy, c_inf)
+        t = self.transcript_cls(B_POLYMATH, r)                                   # prover.rs:125
+        x1 = self.compute_x1(t, instance, [a_g1, c_g1])                          # :126
+        y1 = pow(x1, pk.sigma, r)                                                # :128
+        y1_inv = pow(y1, -1, r)
+        y1_alpha = pow(y1_inv, MINUS_ALPHA, r)                                   # :130
+        rc, u_at = pk.phase2(f.fr_limbs([x1])[0])
+        if rc:
+            raise PolymathProverError(2, rc)
+        a_at_x1 = (f.fr_int(u_at) + (r_a[0] + r_a[1] * x1) * y1_alpha) % r       # :132
+        y1_gamma = pow(y1_inv, MINUS_GAMMA, r)                                   # :134
+        pi_at_x1 = self.compute_pi_at_x1(pk.n, pk.omega, instance, x1, y1_gamma)  # :135
+        c_at_x1 = ((a_at_x1 + y1_gamma) * a_at_x1 - pi_at_x1) % r * pow(y1_alpha, -1, r) % r   # :138, common.rs:73-75
+        x2 = self.compute_x2(t, x1, [a_at_x1, c_at_x1])                          # :189
+        L = lambda v: f.fr_limbs([v])[0]
+        rc, d_xy, d_inf = pk.phase3(L(x1), L(x2), L(a_at_x1), L(c_at_x1))
+        if rc:
+            raise PolymathProverError(3, rc)
+        if combine:
+            d_xy, d_inf = combine(d_xy, d_inf)
+        return Proof(f, a_g1, c_g1, a_at_x1, f.g1_affine(d_xy, d_inf))           # :231-236
+
+    # ---- common.rs:21-71
+    def compute_x1(self, t, public_inputs, commitments):
+        t.append_message(b"public_inputs", ser_fr_slice(self.field, public_inputs))
+        t.append_message(b"commitments", ser_g1_slice(self.field, commitments))
+        return t.challenge(b"x1")
+
+    def compute_x2(self, t, x1, values):
+        t.append_message(b"x1", ser_fr(self.field, x1))
+        t.append_message(b"values", ser_fr_slice(self.field, values))
+        return t.challenge(b"x2")
+
+    def compute_pi_at_x1(self, n, omega, public_inputs, x1, y1_gamma):
+        r = self.field.r
+        m0 = len(public_inputs)
+        num = (pow(x1, n, r) - 1) * pow(n, -1, r) % r
+        w_i, s = 1, 0
+        for i in range(2 * m0):
+            if i == 0:
+                zt = 2
+            elif i < m0:
+                zt = 1 + public_inputs[i]
+            elif i == m0:
+                zt = 0
+            else:
+                zt = 1 - public_inputs[i - m0]
+            s = (s + zt * num * pow((x1 - w_i) % r, -1, r)) % r
+            num = num * omega % r
+            w_i = w_i * omega % r
+        return s * y1_gamma % r

@@ -1,0 +1,311 @@
+"""GPU parity tests proper: every call goes through the C ABI (include/polymath_hip.h, ctypes) and is
+compared bit-for-bit with the committed golden vectors (from oracle/pyref) and with the C++ CPU
+restatement on the same seeded inputs; at full sizes, size-independent properties are checked.
+All arithmetic is integer: the bar is exact equality."""
+import numpy as np
+import pytest
+
+from helpers import BASE_NAMES, I, PT, load_golden, pm_csrs, r1cs_from_json, rand_fr_limbs
+from oracle import driver as DR
+from oracle.pyref import circuits as CI, serialize as SE, transcripts as T
+from oracle.pyref.fields import CURVES
+
+pytestmark = pytest.mark.gpu
+
+CURVE_LIST = ["bls12_381", "bn254"]
+
+
+@pytest.fixture(scope="module")
+def api():
+    from polymath_amd import api as _api
+    return _api
+
+
+# ------------------------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("curve", CURVE_LIST)
+def test_ntt_golden(gpu_ctx, oracle, curve):
+    for t in load_golden("ntt_msm.json")[curve]["ntt"]:
+        inp = oracle.fr_to_mont_limbs(curve, [I(x) for x in t["input"]])
+        assert oracle.fr_from_mont_limbs(curve, gpu_ctx.ntt(curve, inp, t["log_n"], False)) == [I(x) for x in t["fwd"]]
+        assert oracle.fr_from_mont_limbs(curve, gpu_ctx.ntt(curve, inp, t["log_n"], True)) == [I(x) for x in t["inv"]]
+
+
+@pytest.mark.parametrize("curve", CURVE_LIST)
+@pytest.mark.parametrize("log_n", [1, 4, 7, 8, 9, 11, 13, 16, 17])
+def test_ntt_vs_oracle(gpu_ctx, oracle, curve, log_n):
+    a = rand_fr_limbs(curve, 1 << log_n, 100 + log_n)
+    for inverse in (False, True):
+        assert np.array_equal(gpu_ctx.ntt(curve, a, log_n, inverse), oracle.ntt(curve, a, log_n, inverse, 8))
+
+
+def test_ntt_full_size_roundtrip_and_domain_limit(gpu_ctx, api):
+    curve, log_n = "bls12_381", 22          # the 2n transform of the 2^20 config (prover.rs:316-319)
+    a = rand_fr_limbs(curve, 1 << log_n, 7)
+    f = gpu_ctx.ntt(curve, a, log_n, False)
+    assert not np.array_equal(f, a)
+    assert np.array_equal(gpu_ctx.ntt(curve, f, log_n, True), a)
+    with pytest.raises(api.PolymathError) as e:      # BN254 two-adicity 28
+        gpu_ctx.ntt("bn254", np.zeros((2, 4), dtype=np.uint64), 29, False)
+    assert e.value.status == 3
+
+
+# ------------------------------------------------------------------------------------ MSM
+@pytest.mark.parametrize("curve", CURVE_LIST)
+def test_msm_golden_edge_cases(gpu_ctx, oracle, curve):
+    """infinity base, zero scalar, scalar 1, scalar -1, a repeated (base, scalar) pair."""
+    for t in load_golden("ntt_msm.json")[curve]["msm"]:
+        bases = oracle.g1_to_mont_limbs(curve, [PT(p) for p in t["bases"]])
+        sc = oracle.fr_to_mont_limbs(curve, [I(s) for s in t["scalars"]])
+        out, inf = gpu_ctx.msm(curve, bases, sc)
+        assert oracle.g1_from_mont_limbs(curve, out, [inf])[0] == PT(t["result"])
+
+
+def test_msm_empty_and_all_zero(gpu_ctx, oracle):
+    curve = "bls12_381"
+    out, inf = gpu_ctx.msm(curve, np.zeros((0, 12), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64))
+    assert inf == 1 and not out.any()
+    bases = oracle.g1_multiples(curve, 5)
+    out, inf = gpu_ctx.msm(curve, bases, np.zeros((5, 4), dtype=np.uint64))
+    assert inf == 1 and not out.any()
+
+
+@pytest.mark.parametrize("curve", CURVE_LIST)
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1 << 14])
+def test_msm_vs_oracle_sizes(gpu_ctx, oracle, api, curve, n):
+    bases = api.Bases.multiples(gpu_ctx, curve, n)
+    host_bases = bases.download()
+    assert np.array_equal(host_bases, oracle.g1_multiples(curve, n))   # device generator == CPU running sum
+    sc = rand_fr_limbs(curve, n, 200 + n)
+    out, inf = bases.msm(sc)
+    ref, rinf = oracle.msm(curve, host_bases, sc, 8)
+    assert inf == rinf == 0 and np.array_equal(out, ref)
+    assert oracle.g1_is_on_curve(curve, out)
+
+
+def test_msm_arkworks_stride_with_infinity_byte(gpu_ctx, oracle):
+    """G1Affine as arkworks lays it out: x || y || infinity: bool, stride 104."""
+    curve, n = "bls12_381", 50
+    packed = oracle.g1_multiples(curve, n)
+    wide = np.zeros((n, 13), dtype=np.uint64)
+    wide[:, :12] = packed
+    wide[7, 12] = 1                      # infinity flag set while coordinates are garbage
+    wide[7, :12] = packed[3]
+    sc = rand_fr_limbs(curve, n, 5)
+    ref_b = packed.copy()
+    ref_b[7] = 0
+    out, inf = gpu_ctx.msm(curve, wide, sc)
+    ref, _ = oracle.msm(curve, ref_b, sc, 2)
+    assert np.array_equal(out, ref)
+
+
+def test_msm_skewed_scalars_hot_buckets(gpu_ctx, oracle, api):
+    """The reference's bench circuit makes every padding witness the same value (benches/bench.rs:49-51):
+    one bucket per window receives almost every point -> exercises the task splitting."""
+    curve, n = "bls12_381", 1 << 14
+    bases = api.Bases.multiples(gpu_ctx, curve, n)
+    hb = bases.download()
+    one_val = rand_fr_limbs(curve, 1, 9)
+    sc = np.repeat(one_val, n, axis=0)
+    sc[::97] = rand_fr_limbs(curve, len(sc[::97]), 10)
+    out, _ = bases.msm(sc)
+    ref, _ = oracle.msm(curve, hb, sc, 8)
+    assert np.array_equal(out, ref)
+    small = oracle.fr_to_mont_limbs(curve, [i % 3 for i in range(n)])       # booleans / tiny values
+    out, _ = bases.msm(small)
+    ref, _ = oracle.msm(curve, hb, small, 8)
+    assert np.array_equal(out, ref)
+
+
+def test_msm_full_size_linearity(gpu_ctx, oracle, api):
+    """2^20 pairs (too slow for the CPU restatement in a unit test): MSM(s) + MSM(t) == MSM(s + t),
+    and a sub-range agrees with the CPU on its own."""
+    curve, n = "bls12_381", 1 << 20
+    r = CURVES[curve].r
+    bases = api.Bases.multiples(gpu_ctx, curve, n)
+    s, t = rand_fr_limbs(curve, n, 11), rand_fr_limbs(curve, n, 12)
+    # s + t in Montgomery form == Montgomery of the sum: add as integers mod r on the host
+    to_int = lambda a: [sum(int(a[i, k]) << (64 * k) for k in range(4)) for i in range(a.shape[0])]
+    si, ti = to_int(s), to_int(t)
+    st = oracle.ints_to_limbs([(x + y) % r for x, y in zip(si, ti)], 4)
+    ps, _ = bases.msm(s)
+    pt, _ = bases.msm(t)
+    pst, _ = bases.msm(st)
+    both, _ = gpu_ctx.g1_sum(curve, np.stack([ps, pt]))
+    assert np.array_equal(both, pst)
+    ref_sum, _ = oracle.g1_sum(curve, np.stack([ps, pt]))          # pm_g1_sum (host glue) vs oracle
+    assert np.array_equal(both, ref_sum)
+    sub, _ = bases.msm(s[1000:1000 + 4096], offset=1000)
+    ref, _ = oracle.msm(curve, bases.download(1000, 4096), s[1000:1000 + 4096], 8)
+    assert np.array_equal(sub, ref)
+
+
+# ---------------------------------------------------------------------------- setup + prove
+def _gpu_pk(api, ctx, curve, q, x, z, oracle, **kw):
+    A, B, C = pm_csrs(curve, q)
+    return api.ProvingKey.generate(ctx, curve, q.m0, q.mw, q.nr, A, B, C, oracle.fr_to_mont_limbs(curve, [x])[0],
+                                   oracle.fr_to_mont_limbs(curve, [z])[0], **kw)
+
+
+def test_golden_setup_prove_bytes(gpu_ctx, oracle, api):
+    """Every committed fixture: GPU setup bases, every intermediate vector, and the 176-byte proofs for
+    the three transcripts (tests/dummy.rs:75-80 shape) equal the big-integer restatement's."""
+    for fx in load_golden("proofs.json"):
+        curve = fx["curve"]
+        c = CURVES[curve]
+        TR = T.make_transcripts(c)
+        q = r1cs_from_json(fx["r1cs"])
+        pk = _gpu_pk(api, gpu_ctx, curve, q, I(fx["x_trapdoor"]), I(fx["z_trapdoor"]), oracle)
+        assert (pk.n, pk.sigma) == (fx["n"], fx["sigma"])
+        assert oracle.fr_from_mont_limbs(curve, pk.omega_limbs)[0] == I(fx["omega"])
+        for i, nm in enumerate(BASE_NAMES):
+            assert oracle.g1_from_mont_limbs(curve, pk.export_bases(i)) == [PT(p) for p in fx["bases"][nm]], (fx["name"], nm)
+        inst, wit, r_a = [I(v) for v in fx["instance"]], [I(v) for v in fx["witness"]], [I(v) for v in fx["r_a"]]
+        for tname, ref in fx["proofs"].items():
+            tr = {}
+            proof = DR.prove(pk, pk.n, pk.sigma, I(fx["omega"]), inst, wit, r_a, TR[tname], tr)
+            assert SE.ser_proof(c, proof).hex() == ref["bytes"], (fx["name"], tname)
+            if tname != "keccak256":
+                continue
+            for which, key in [(0, "u_evals"), (1, "w_evals"), (2, "u"), (3, "w"), (4, "h"), (5, "wit_u"), (6, "z_tail"), (7, "quotient")]:
+                got = oracle.fr_from_mont_limbs(curve, pk.tap(which, 1 << 16))
+                want = [I(v) for v in fx["trace"][key]]
+                assert got[:len(want)] == want and not any(got[len(want):]), (fx["name"], key)
+        pk.free()
+
+
+def _prove_both(api, gpu_ctx, oracle, curve, q, inst, wit, seed, compare_bases=True, **gpu_kw):
+    c = CURVES[curve]
+    TR = T.make_transcripts(c)
+    g = CI.SplitMix64(seed)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    opk = oracle.OraclePk(curve, q, x, z, 8)
+    gpk = _gpu_pk(api, gpu_ctx, curve, q, x, z, oracle, **gpu_kw)
+    if compare_bases:
+        for i in range(6):
+            assert np.array_equal(gpk.export_bases(i), opk.export_bases(i)), BASE_NAMES[i]
+    omega = oracle.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+    tr_o, tr_g = {}, {}
+    po = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_o)
+    pg = DR.prove(gpk, gpk.n, gpk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_g)
+    assert pg == po and tr_g == tr_o
+    for which in range(8):
+        assert np.array_equal(gpk.tap(which, 1 << 22), opk.tap(which, 1 << 22)), which
+    return opk, gpk, pg
+
+
+@pytest.mark.parametrize("curve", CURVE_LIST)
+def test_prove_synthetic_mid_size_vs_oracle(gpu_ctx, oracle, api, curve):
+    """SURVEY.md §8d synthetic R1CS, 3000 gates -> n = 8192, both curves."""
+    q, inst, wit = CI.synthetic_r1cs(CURVES[curve], 3000)
+    _prove_both(api, gpu_ctx, oracle, curve, q, inst, wit, 77)
+
+
+def test_prove_mimc_322_vs_oracle_and_pairing(gpu_ctx, oracle, api):
+    """BASELINE configs[0] shape (tests/mimc.rs): MiMC-322, n = 2048, 27 948 MSM pairs; the GPU proof
+    equals the CPU restatement's and the pairing verifier accepts it."""
+    from oracle.pyref import pairing as PA, protocol as PR
+    from oracle.pyref.fields import BLS12_381 as c
+    g = CI.SplitMix64(322)
+    consts = [g.fr(c.r) for _ in range(322)]
+    q, inst, wit = CI.mimc_circuit(c, g.fr(c.r), g.fr(c.r), consts)
+    opk, gpk, proof = _prove_both(api, gpu_ctx, oracle, "bls12_381", q, inst, wit, 323)
+    gg = CI.SplitMix64(323)
+    x, z = gg.fr(c.r), gg.fr(c.r)
+    omega = oracle.fr_from_mont_limbs("bls12_381", opk.omega_limbs)[0]
+    from oracle.pyref.fields import BLS12_381_G2
+    vk = dict(n=opk.n, m0=2, sigma=opk.sigma, omega=omega, one_g1=c.g1, one_g2=BLS12_381_G2,
+              x_g2=PA.g2_mul(BLS12_381_G2, x), z_g2=PA.g2_mul(BLS12_381_G2, z))
+    TR = T.make_transcripts(c)
+    assert PR.verify_proof(c, vk, proof, inst[1:], TR["merlin"], PA.pairing_check)
+    bad = dict(proof, a_at_x1=(proof["a_at_x1"] + 1) % c.r)
+    assert not PR.verify_proof(c, vk, bad, inst[1:], TR["merlin"], PA.pairing_check)
+
+
+def test_prove_reference_bench_shape(gpu_ctx, oracle, api):
+    """benches/bench.rs:38-61 shape at 2^11 - 100: unused witnesses (infinity bases in uj_wj_lcs),
+    one repeated witness value, an empty last row."""
+    from oracle.pyref.fields import BLS12_381 as c
+    q, inst, wit = CI.bench_circuit(c, 1234567, 7654321, (1 << 11) - 100, (1 << 11) - 100)
+    opk, gpk, _ = _prove_both(api, gpu_ctx, oracle, "bls12_381", q, inst, wit, 99)
+    lcs = gpk.export_bases(5)
+    assert (~lcs.any(axis=1)).sum() > 1000      # the unused-witness columns are points at infinity
+
+
+def test_pk_load_path_equals_generate(gpu_ctx, oracle, api):
+    """pm_pk_load of an existing key (arkworks 104-byte G1Affine stride) gives the same proof."""
+    curve = "bls12_381"
+    c = CURVES[curve]
+    q, inst, wit = CI.synthetic_r1cs(c, 200)
+    opk = oracle.OraclePk(curve, q, 1111, 2222, 4)
+    arrays = []
+    for i in range(6):
+        b = opk.export_bases(i)
+        wide = np.zeros((b.shape[0], 13), dtype=np.uint64)
+        wide[:, :12] = b
+        wide[:, 12] = (~b.any(axis=1)).astype(np.uint64)
+        arrays.append(wide)
+    A, B, C = pm_csrs(curve, q)
+    gpk = api.ProvingKey.load(gpu_ctx, curve, opk.n, q.m0, q.mw, q.nr, opk.sigma, A, B, C, arrays)
+    TR = T.make_transcripts(c)
+    omega = oracle.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+    po = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, [5, 6], TR["blake3"])
+    pg = DR.prove(gpk, gpk.n, gpk.sigma, omega, inst, wit, [5, 6], TR["blake3"])
+    assert po == pg
+
+
+def test_sharded_pk_partials_sum_to_whole(gpu_ctx, oracle, api):
+    """MSM pairs sharded over ranks; partial points summed with pm_g1_sum equal the
+    unsharded commitments (two shards emulated on one GPU)."""
+    curve = "bls12_381"
+    c = CURVES[curve]
+    q, inst, wit = CI.synthetic_r1cs(c, 700)
+    x = oracle.fr_to_mont_limbs(curve, inst)
+    w = oracle.fr_to_mont_limbs(curve, wit)
+    ra = oracle.fr_to_mont_limbs(curve, [31337, 271828])
+    whole = _gpu_pk(api, gpu_ctx, curve, q, 4242, 2424, oracle)
+    rc, a, ai, cc, ci = whole.phase1(x, w, ra)
+    assert rc == 0
+    x1, x2, av, cv = (oracle.fr_to_mont_limbs(curve, [v])[0] for v in (123456789, 987654321, 55, 66))
+    parts_a, parts_c, parts_d = [], [], []
+    ctx2 = api.Context(0)
+    for rank in range(3):
+        shard = _gpu_pk(api, ctx2, curve, q, 4242, 2424, oracle, shard_rank=rank, shard_count=3)
+        rc, pa, pai, pc, pci = shard.phase1(x, w, ra)
+        assert rc == 0
+        parts_a.append(pa)
+        parts_c.append(pc)
+        # phase 3 with arbitrary challenges: the remainder check fails (not a real transcript),
+        # so only compare when it passes -- use the real flow instead:
+        shard.free()
+    sa, _ = gpu_ctx.g1_sum(curve, np.stack(parts_a))
+    sc_, _ = gpu_ctx.g1_sum(curve, np.stack(parts_c))
+    assert np.array_equal(sa, a) and np.array_equal(sc_, cc)
+    ctx2.close()
+
+
+def test_error_codes(gpu_ctx, oracle, api):
+    curve = "bls12_381"
+    c = CURVES[curve]
+    q, inst, wit = CI.synthetic_r1cs(c, 50)
+    pk = _gpu_pk(api, gpu_ctx, curve, q, 77, 88, oracle)
+    x, w = oracle.fr_to_mont_limbs(curve, inst), oracle.fr_to_mont_limbs(curve, wit)
+    ra = oracle.fr_to_mont_limbs(curve, [1, 2])
+    ctx3 = api.Context(0)
+    pk3 = _gpu_pk(api, ctx3, curve, q, 77, 88, oracle)
+    rc, _ = pk3.phase2(ra[0])
+    assert rc == 8                                     # PM_ERR_STATE: phase 2 before phase 1
+    bad = w.copy()
+    bad[3] = oracle.fr_to_mont_limbs(curve, [12345])[0]
+    rc = pk.phase1(x, bad, ra)[0]
+    assert rc == 4                                     # PM_ERR_REMAINDER_NONZERO == prover.rs:108
+    rc = pk.phase1(x, w, ra)[0]
+    assert rc == 0
+    one = oracle.fr_to_mont_limbs(curve, [1])[0]
+    rc = pk.phase3(one, one, one, one)[0]
+    assert rc == 4                                     # bogus challenge values: rem != 0, prover.rs:221
+    bases = api.Bases.multiples(gpu_ctx, curve, 8)
+    with pytest.raises(api.PolymathError) as e:
+        bases.msm(rand_fr_limbs(curve, 9, 1))
+    assert e.value.status == 2                         # scalars.len() > bases.len(), prover.rs:381
+    pk3.free()
+    ctx3.close()

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json from the big-integer restatement oracle/pyref ALONE (no C++ oracle,
+no GPU code): the vectors every other implementation is pinned against.
+
+PARITY UNPINNED w.r.t. the reference binary (no Rust toolchain, no reference golden vectors); the
+proof fixtures are additionally checked here by the pairing verifier before being written.
+
+Run: python tools/gen_golden.py        (about one minute)
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.pyref import circuits as CI, pairing as PA, protocol as PR, serialize as SE, transcripts as T  # noqa: E402
+from oracle.pyref.fields import CURVES, g1_msm_naive, g1_mul  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+H = lambda v: hex(v)
+PT = lambda P: None if P is None else [hex(P[0]), hex(P[1])]
+
+
+def field_and_curve_kats():
+    out = {}
+    for name, c in CURVES.items():
+        g = CI.SplitMix64(0xF1E1D)
+        fr = [[H(a), H(b), H(a * b % c.r), H((a + b) % c.r), H((a - b) % c.r), H(pow(a, -1, c.r))]
+              for a, b in [(g.fr(c.r), g.fr(c.r)) for _ in range(8)] + [(c.r - 1, c.r - 1), (1, c.r - 1), (2, (c.r + 1) // 2)]]
+        fq = []
+        for _ in range(8):
+            a = (g.fr(c.r) * g.fr(c.r)) % c.p
+            b = (g.fr(c.r) * g.fr(c.r) + 12345) % c.p
+            fq.append([H(a), H(b), H(a * b % c.p), H((a + b) % c.p), H((a - b) % c.p)])
+        fq.append([H(c.p - 1), H(c.p - 1), H(1), H(c.p - 2), H(0)])
+        muls = []
+        for k in [1, 2, 3, c.r - 1, g.fr(c.r), g.fr(c.r)]:
+            muls.append([H(k), PT(g1_mul(c, c.g1, k))])
+        out[name] = dict(p=H(c.p), r=H(c.r), fr_R=H(c.fr_R), fq_R=H(c.fq_R), two_adic_root=H(c.two_adic_root),
+                         fr=fr, fq=fq, g1=PT(c.g1), g1_muls=muls)
+    return out
+
+
+def ntt_msm_vectors():
+    out = {}
+    for name, c in CURVES.items():
+        g = CI.SplitMix64(0xA77)
+        ntts = []
+        for log_n in [0, 1, 2, 3, 5]:
+            n = 1 << log_n
+            vals = [g.fr(c.r) for _ in range(n)]
+            ntts.append(dict(log_n=log_n, input=[H(v) for v in vals],
+                             fwd=[H(v) for v in PR.ntt_naive(c, vals, n)],
+                             inv=[H(v) for v in PR.ntt_naive(c, vals, n, True)]))
+        msms = []
+        for ln in [1, 2, 7, 33]:
+            pts = [g1_mul(c, c.g1, g.fr(c.r)) for _ in range(ln)]
+            sc = [g.fr(c.r) for _ in range(ln)]
+            if ln >= 7:
+                pts[2] = None          # base at infinity
+                sc[3] = 0              # zero scalar
+                sc[4] = 1
+                sc[5] = c.r - 1        # == -1
+                pts[6] = pts[1]        # repeated base
+                sc[6] = sc[1]          # ... with the same scalar (forces a doubling inside a bucket)
+            msms.append(dict(bases=[PT(p) for p in pts], scalars=[H(s) for s in sc], result=PT(g1_msm_naive(c, pts, sc))))
+        out[name] = dict(ntt=ntts, msm=msms)
+    return out
+
+
+def r1cs_json(q):
+    row = lambda rw: [[H(v), j] for v, j in rw]
+    return dict(m0=q.m0, mw=q.mw, a=[row(r) for r in q.a], b=[row(r) for r in q.b], c=[row(r) for r in q.c])
+
+
+def proof_fixtures():
+    c = CURVES["bls12_381"]
+    TR = T.make_transcripts(c)
+    g = CI.SplitMix64(0xD00D)
+    cases = [("dummy", ) + CI.dummy_circuit(c, g.fr(c.r), g.fr(c.r)),
+             ("mimc2", ) + CI.mimc_circuit(c, g.fr(c.r), g.fr(c.r), [g.fr(c.r) for _ in range(2)]),
+             ("synthetic6", ) + CI.synthetic_r1cs(c, 6),
+             ("bench_shape", ) + CI.bench_circuit(c, g.fr(c.r), g.fr(c.r), 7, 6)]
+    # a row with a duplicated column: m_at (common.rs:100-105) only sees the first entry
+    q, inst, wit = CI.dummy_circuit(c, 3, 5)
+    q.a[0] = [(1, 2), (7, 2)]
+    cases.append(("dup_column", q, inst, wit))
+    out = []
+    for name, q, inst, wit in cases:
+        x, z = g.fr(c.r), g.fr(c.r)
+        pk = PR.generate_proving_key(c, q, x, z)
+        vk = PA.make_vk(pk)
+        r_a = [g.fr(c.r), g.fr(c.r)]
+        entry = dict(name=name, curve="bls12_381", r1cs=r1cs_json(q), instance=[H(v) for v in inst], witness=[H(v) for v in wit],
+                     x_trapdoor=H(x), z_trapdoor=H(z), r_a=[H(v) for v in r_a], n=pk.n, sigma=pk.sigma, omega=H(pk.omega),
+                     bases={nm: [PT(p) for p in getattr(pk, nm)] for nm in
+                            ["x_powers_g1", "x_powers_y_alpha_g1", "x_powers_y_gamma_g1", "x_powers_y_gamma_z_g1",
+                             "x_powers_zh_by_y_alpha_g1", "uj_wj_lcs_by_y_alpha_g1"]}, proofs={})
+        for tname in ["merlin", "keccak256", "blake3"]:
+            tr = {}
+            proof = PR.create_proof_with_assignment(c, pk, inst, wit, r_a, TR[tname], tr)
+            assert PR.verify_proof(c, vk, proof, inst[1:], TR[tname], PA.pairing_check), (name, tname)
+            entry["proofs"][tname] = dict(a_g1=PT(proof["a_g1"]), c_g1=PT(proof["c_g1"]), a_at_x1=H(proof["a_at_x1"]),
+                                          d_g1=PT(proof["d_g1"]), x1=H(tr["x1"]), x2=H(tr["x2"]),
+                                          bytes=SE.ser_proof(c, proof).hex())
+            if tname == "keccak256":
+                entry["trace"] = {k: [H(v) for v in tr[k]] for k in ["u_evals", "w_evals", "u", "w", "h", "wit_u", "z_tail", "quotient"]}
+        print("fixture", name, "n =", pk.n, "verified x3")
+        out.append(entry)
+    return out
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for fname, fn in [("field_curve_kats.json", field_and_curve_kats), ("ntt_msm.json", ntt_msm_vectors),
+                      ("proofs.json", proof_fixtures)]:
+        with open(os.path.join(OUT, fname), "w") as f:
+            json.dump(fn(), f, separators=(",", ":"))
+        print("wrote", fname)
+
+
+if __name__ == "__main__":
+    main()
