@@ -152,7 +152,7 @@ class Context:
         bases, scalars = _c(bases), _c(scalars)
         out = np.zeros(2 * FQ_LIMBS64[cid], dtype=np.uint64)
         inf = ct.c_int(0)
-        self.check(self.L.pm_msm_g1(self.h, cid, bases.ctypes.data_as(ct.c_void_p), bases.strides[0] if bases.ndim > 1 else 16 * FQ_LIMBS64[cid],
+        self.check(self.L.pm_msm_g1(self.h, cid, bases.ctypes.data_as(ct.c_void_p), max(bases.strides[0], 16 * FQ_LIMBS64[cid]) if bases.ndim > 1 else 16 * FQ_LIMBS64[cid],
                                     _p(scalars), scalars.shape[0], _p(out), ct.byref(inf)))
         return out, inf.value
 
@@ -177,7 +177,7 @@ class Bases:
     def upload(cls, ctx, curve, bases):
         bases = _c(bases)
         h = ct.c_void_p()
-        ctx.check(ctx.L.pm_bases_upload(ctx.h, CURVE_IDS[curve], bases.ctypes.data_as(ct.c_void_p), bases.strides[0],
+        ctx.check(ctx.L.pm_bases_upload(ctx.h, CURVE_IDS[curve], bases.ctypes.data_as(ct.c_void_p), max(bases.strides[0], 16 * FQ_LIMBS64[CURVE_IDS[curve]]),
                                         bases.shape[0], ct.byref(h)))
         return cls(ctx, curve, h)
 

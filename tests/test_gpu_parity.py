@@ -188,8 +188,10 @@ def _prove_both(api, gpu_ctx, oracle, curve, q, inst, wit, seed, compare_bases=T
     po = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_o)
     pg = DR.prove(gpk, gpk.n, gpk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_g)
     assert pg == po and tr_g == tr_o
-    for which in range(8):
-        assert np.array_equal(gpk.tap(which, 1 << 22), opk.tap(which, 1 << 22)), which
+    for which in range(8):   # same vectors; the two sides may differ in trailing zero padding only
+        a, b = gpk.tap(which, 1 << 22), opk.tap(which, 1 << 22)
+        k = min(len(a), len(b))
+        assert k > 0 and np.array_equal(a[:k], b[:k]) and not a[k:].any() and not b[k:].any(), which
     return opk, gpk, pg
 
 
