@@ -128,6 +128,8 @@ static int bases_upload_impl(pm_ctx *ctx, const void *bases, size_t stride, size
         repack_bases<C>(bases, stride, len, packed.data());
         PM_HIP(ctx, hipMalloc(&b->d_points, len * sizeof(Affine<C>)));
         PM_HIP(ctx, hipMemcpy(b->d_points, packed.data(), len * sizeof(Affine<C>), hipMemcpyHostToDevice));
+        PM_TRY(bases_convert<C>(ctx, (Affine<C> *)b->d_points, len, true));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     *out = b.release();
     return PM_OK;
@@ -161,12 +163,24 @@ extern "C" int pm_bases_generate_multiples(pm_ctx *ctx, int curve, size_t len, p
     return PM_DISPATCH(curve, bases_multiples_impl<BlsCurve>(ctx, len, out), bases_multiples_impl<BnCurve>(ctx, len, out));
 }
 
+// device -> host copy of resident (internal-form) points, converted back to standard Montgomery form
+template <class C>
+static int download_points(pm_ctx *ctx, const void *d_src, size_t len, uint64_t *out_xy) {
+    if (!len) return PM_OK;
+    PM_HIP(ctx, ctx->scratch.reserve(len * sizeof(Affine<C>)));
+    PM_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, d_src, len * sizeof(Affine<C>), hipMemcpyDeviceToDevice, ctx->stream));
+    PM_TRY(bases_convert<C>(ctx, ctx->scratch.as<Affine<C>>(), len, false));
+    PM_HIP(ctx, hipMemcpyAsync(out_xy, ctx->scratch.p, len * sizeof(Affine<C>), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
 extern "C" int pm_bases_download(pm_ctx *ctx, const pm_bases *b, size_t offset, size_t len, uint64_t *out_xy) {
     if (!ctx || !b || !out_xy || offset + len > b->len) return PM_ERR_INVALID_ARG;
     PM_TRY(set_device(ctx));
     size_t pt = b->curve == PM_BLS12_381 ? sizeof(Affine<BlsCurve>) : sizeof(Affine<BnCurve>);
-    PM_HIP(ctx, hipMemcpy(out_xy, (const uint8_t *)b->d_points + offset * pt, len * pt, hipMemcpyDeviceToHost));
-    return PM_OK;
+    const void *src = (const uint8_t *)b->d_points + offset * pt;
+    return PM_DISPATCH(b->curve, download_points<BlsCurve>(ctx, src, len, out_xy), download_points<BnCurve>(ctx, src, len, out_xy));
 }
 
 extern "C" size_t pm_bases_len(const pm_bases *b) { return b ? b->len : 0; }
@@ -404,6 +418,8 @@ static int pk_load_impl(pm_ctx *ctx, uint64_t n, uint64_t m0, uint64_t mw, uint6
         tmp.resize(count);
         repack_bases<C>((const uint8_t *)bases[v].points + start * bases[v].stride, bases[v].stride, count, tmp.data());
         PM_HIP(ctx, hipMemcpy(dst, tmp.data(), count * sizeof(Affine<C>), hipMemcpyHostToDevice));
+        PM_TRY(bases_convert<C>(ctx, dst, count, true));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return PM_OK;
     });
     if (st) return guard(st);
@@ -514,6 +530,7 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
                 PM_TRY(powers_fill<C>(ctx, d_sc, cnt, first, x));
             }
             PM_TRY(fixed_base_batch<C>(ctx, d_sc, cnt, dst + s));
+            PM_TRY(bases_convert<C>(ctx, dst + s, cnt, true));
             PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
         return PM_OK;
@@ -561,8 +578,8 @@ extern "C" int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_
         }
     }
     if (!found) return PM_ERR_INVALID_ARG;  // not resident on this shard
-    PM_HIP(ctx, hipMemcpy(out_xy, (const uint8_t *)pk->d_bases + dev_off * pt, len * pt, hipMemcpyDeviceToHost));
-    return PM_OK;
+    const void *src = (const uint8_t *)pk->d_bases + dev_off * pt;
+    return PM_DISPATCH(pk->curve, download_points<BlsCurve>(ctx, src, len, out_xy), download_points<BnCurve>(ctx, src, len, out_xy));
 }
 
 // -------------------------------------------------------------------------------- prove

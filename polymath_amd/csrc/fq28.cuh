@@ -1,0 +1,334 @@
+// Reduced-radix base-field arithmetic for the MSM inner loop on gfx950.
+//
+// Measured on MI355X (profiles/r01_microbench_valu.txt): v_mad_u64_u32, v_add_co_u32 / v_addc_co_u32
+// and v_lshl_add_u64 all issue at the same (half) rate, so on dense 32-bit limbs every carry costs as
+// much as a multiply and the compiler's Montgomery multiplier spends 1328 instructions per Fq product
+// (288 mads + 299 64-bit adds + 640 register moves).  Here an element is N limbs of W = 28 bits held in
+// u32 registers; the 64-bit accumulator of v_mad_u64_u32 then absorbs 2N products without overflow, so a
+// product is N*N mads for a*b plus N*N for the interleaved Montgomery reduction and NO carry chain:
+// ~490 instructions for BLS12-381 (N = 14).  Additions and subtractions are limb-wise v_add_u32 with
+// lazy carries (14 instructions instead of ~200).
+//
+// Bounds discipline (R = 2^(W N) is >= 2^8 larger than p, so magnitudes up to ~45p are harmless):
+//   T ("tight")  limbs < 2^28,            value < 2p      -- every mul/sqr output
+//   W ("weak")   limbs < 2^28,            value < 16p     -- output of weak_norm (carry propagation only)
+//   L ("loose")  limbs < 2^(28+e), e <= 3 (fits u32)      -- outputs of add / sub
+//   mul(a, b) requires e_a + e_b <= 4  (14 * 2^(56+4) + 14 * 2^56 + carry < 2^64)
+//   and value(a) * value(b) < 2^(W N) * p  (then the result is < 2p); the callers in this file
+//   (the XYZZ mixed add) document their bounds inline.
+// Values are in Montgomery form with radix 2^(W N) ("internal" form); bases are converted once when
+// they are uploaded / generated (api.hip), results are converted back before they leave the kernel.
+#pragma once
+#include "ec.cuh"
+
+namespace pm {
+
+template <class RR>
+struct F28 {
+    static constexpr int N = RR::N;
+    uint32_t l[N];
+};
+
+template <class RR>
+PM_HD F28<RR> f28_zero() {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = 0;
+    return r;
+}
+template <class RR>
+PM_HD F28<RR> f28_one() {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = RR::ONE[i];
+    return r;
+}
+template <class RR>
+PM_HD bool f28_all_zero(const F28<RR> &a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) o |= a.l[i];
+    return o == 0;
+}
+// a is T (tight limbs, value < 2p): a == 0 (mod p)  <=>  a in {0, p}
+template <class RR>
+PM_HD bool f28_is_zero_mod_p(const F28<RR> &a) {
+    uint32_t o = 0, q = 0;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) {
+        o |= a.l[i];
+        q |= a.l[i] ^ RR::MOD[i];
+    }
+    return o == 0 || q == 0;
+}
+
+// Montgomery product, interleaved (CIOS) over 28-bit digits.  Output T.
+template <class RR>
+PM_HD F28<RR> f28_mul(const F28<RR> &a, const F28<RR> &b) {
+    constexpr int N = RR::N;
+    uint64_t acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t bi = b.l[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)a.l[j] * bi;
+        const uint32_t m = ((uint32_t)acc[0] * RR::INV) & RR::MASK;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
+        const uint64_t carry = acc[0] >> RR::W;
+#pragma unroll
+        for (int j = 0; j < N - 1; ++j) acc[j] = acc[j + 1];
+        acc[N - 1] = 0;
+        acc[0] += carry;
+    }
+    F28<RR> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        c += acc[j];
+        r.l[j] = (uint32_t)c & RR::MASK;
+        c >>= RR::W;
+    }
+    // value < 2p < 2^(W N): the final carry is zero
+    return r;
+}
+
+// Montgomery square: the N(N-1)/2 cross products are taken once against the doubled operand
+// (limbs < 2^(29+e)), so a square costs N(N+1)/2 + N*N mads instead of 2 N*N.  Requires e_a <= 1.6
+// (2 e_a + 1 <= 4.2 under the same 64-bit column bound as f28_mul).  Output T.
+template <class RR>
+PM_HD F28<RR> f28_sqr(const F28<RR> &a) {
+    constexpr int N = RR::N;
+    uint32_t a2[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) a2[j] = a.l[j] << 1;
+    uint64_t acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        // After i shifts acc[j] holds ORIGINAL column i + j.  Row i adds the diagonal a_i^2 (original
+        // column 2i -> local i) and the doubled cross terms 2 a_i a_j, j > i (original i + j -> local j).
+        // A term (k, l), k <= l, enters at iteration k <= (k + l) / 2, so original column i is complete
+        // when iteration i reads acc[0] for the Montgomery digit.
+        acc[i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) acc[j] += (uint64_t)a2[i] * a.l[j];
+        const uint32_t m = ((uint32_t)acc[0] * RR::INV) & RR::MASK;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
+        const uint64_t carry = acc[0] >> RR::W;
+#pragma unroll
+        for (int j = 0; j < N - 1; ++j) acc[j] = acc[j + 1];
+        acc[N - 1] = 0;
+        acc[0] += carry;
+    }
+    F28<RR> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        c += acc[j];
+        r.l[j] = (uint32_t)c & RR::MASK;
+        c >>= RR::W;
+    }
+    return r;
+}
+
+template <class RR>
+PM_HD F28<RR> f28_add(const F28<RR> &a, const F28<RR> &b) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// a + K - b with K = 4p (K4: b tight-limbed, value <= 2p), 8p (K8: b limbs < 2^29, value <= 4p)
+// or 16p (K16: b tight-limbed, value < 14p); every limb of K dominates the matching limb of b.
+template <class RR>
+PM_HD F28<RR> f28_sub_k4(const F28<RR> &a, const F28<RR> &b) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = a.l[i] + (RR::K4[i] - b.l[i]);
+    return r;
+}
+template <class RR>
+PM_HD F28<RR> f28_sub_k8(const F28<RR> &a, const F28<RR> &b) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = a.l[i] + (RR::K8[i] - b.l[i]);
+    return r;
+}
+template <class RR>
+PM_HD F28<RR> f28_sub_k16(const F28<RR> &a, const F28<RR> &b) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = a.l[i] + (RR::K16[i] - b.l[i]);
+    return r;
+}
+// carry propagation only: limbs back below 2^28, value unchanged (top limb keeps the excess)
+template <class RR>
+PM_HD F28<RR> f28_weak_norm(const F28<RR> &a) {
+    F28<RR> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < RR::N - 1; ++i) {
+        uint32_t v = a.l[i] + c;
+        r.l[i] = v & RR::MASK;
+        c = v >> RR::W;
+    }
+    r.l[RR::N - 1] = a.l[RR::N - 1] + c;
+    return r;
+}
+
+// dense 32-bit limbs (value < p, already in internal Montgomery form) -> 28-bit limbs
+template <class RR>
+PM_HD F28<RR> f28_unpack(const uint32_t *d) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) {
+        const int bit = RR::W * i, w = bit >> 5, s = bit & 31;
+        uint64_t two = w < RR::N32 ? d[w] : 0u;
+        if (w + 1 < RR::N32) two |= (uint64_t)d[w + 1] << 32;
+        r.l[i] = (uint32_t)(two >> s) & RR::MASK;
+    }
+    return r;
+}
+
+// T value -> canonical (< p) -> dense 32-bit limbs
+template <class RR>
+PM_HD void f28_pack_reduced(const F28<RR> &a, uint32_t *d) {
+    constexpr int N = RR::N;
+    uint32_t t[N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {  // t = a - p
+        uint32_t v = a.l[i] - RR::MOD[i] - borrow;
+        borrow = v >> 31;            // limbs < 2^28, so a negative difference sets bit 31
+        t[i] = v & RR::MASK;
+    }
+    uint32_t c[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) c[i] = borrow ? a.l[i] : t[i];
+#pragma unroll
+    for (int w = 0; w < RR::N32; ++w) {
+        const int bit = 32 * w, i = bit / RR::W, s = bit % RR::W;
+        uint64_t v = (uint64_t)c[i] >> s;
+        if (i + 1 < N) v |= (uint64_t)c[i + 1] << (RR::W - s);
+        if (i + 2 < N && 2 * RR::W - s < 32) v |= (uint64_t)c[i + 2] << (2 * RR::W - s);
+        d[w] = (uint32_t)v;
+    }
+}
+
+// internal T value -> standard Montgomery form (radix 2^(32 N32)), canonical, dense
+template <class RR>
+PM_HD Fp<typename RR::Dense> f28_to_std(const F28<RR> &a) {
+    F28<RR> k;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) k.l[i] = RR::TO_STD[i];
+    Fp<typename RR::Dense> out;
+    f28_pack_reduced<RR>(f28_mul<RR>(a, k), out.l);
+    return out;
+}
+
+// ---------------------------------------------------------------------------- XYZZ on F28
+template <class C>
+struct XYZZ28 {
+    typedef typename C::FqRR RR;
+    F28<RR> X, Y, ZZ, ZZZ;  // X: W (< 14p), Y: W (< 6p), ZZ, ZZZ: T; identity <=> ZZ all-zero
+};
+
+// dense-side conversions between the standard and the internal Montgomery radix (one dense mul)
+template <class C>
+PM_HD Fp<typename C::FqP> fq_std_to_int(const Fp<typename C::FqP> &x) {
+    Fp<typename C::FqP> c;
+    for (int i = 0; i < C::FqP::N; ++i) c.l[i] = C::FqRR::STD2INT[i];
+    return mul<typename C::FqP>(x, c);
+}
+template <class C>
+PM_HD Fp<typename C::FqP> fq_int_to_std(const Fp<typename C::FqP> &x) {
+    Fp<typename C::FqP> c;
+    for (int i = 0; i < C::FqP::N; ++i) c.l[i] = C::FqRR::INT2STD[i];
+    return mul<typename C::FqP>(x, c);
+}
+
+// acc += (x2, +-y2): madd-2008-s (8M + 2S) with lazy reductions.  `q` holds INTERNAL-form dense
+// coordinates (pre-converted bases).  Returns false when the pair hits the exceptional case
+// P == 0 (same x: doubling or cancellation), which the caller resolves on the dense path.
+template <class C>
+PM_HD bool xyzz28_madd(XYZZ28<C> &acc, const Affine<C> &q, bool negate) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    const F x2 = f28_unpack<RR>(q.x.l);
+    F y2 = f28_unpack<RR>(q.y.l);
+    if (negate) y2 = f28_weak_norm<RR>(f28_sub_k4<RR>(f28_zero<RR>(), y2));  // 4p - y: W, < 4p
+    if (f28_all_zero<RR>(acc.ZZ)) {
+        acc.X = x2;
+        acc.Y = y2;
+        acc.ZZ = f28_one<RR>();
+        acc.ZZZ = f28_one<RR>();
+        return true;
+    }
+    const F U2 = f28_mul<RR>(x2, acc.ZZ);                  // T
+    const F S2 = f28_mul<RR>(y2, acc.ZZZ);                 // y2 W(<4p) x T -> T
+    const F P = f28_sub_k16<RR>(U2, acc.X);                // L e<=2, < 18p
+    const F R = f28_sub_k16<RR>(S2, acc.Y);                // L e<=2, < 18p
+    const F PP = f28_sqr<RR>(P);                           // e 2+2, 18p*18p < 2^8.4 p^2 -> T
+    if (f28_is_zero_mod_p<RR>(PP)) return false;           // P == 0 (mod p): exceptional
+    const F PPP = f28_mul<RR>(P, PP);                      // T
+    const F Q = f28_mul<RR>(acc.X, PP);                    // W(<14p) x T -> T
+    const F RR2 = f28_sqr<RR>(R);                          // T
+    // X3 = R^2 - PPP - 2Q
+    F X3 = f28_sub_k4<RR>(RR2, PPP);                       // < 6p,  limbs < 2^28 + 2^29
+    X3 = f28_sub_k8<RR>(X3, f28_add<RR>(Q, Q));            // < 14p, limbs < 2^31
+    X3 = f28_weak_norm<RR>(X3);                            // W, < 14p
+    // Y3 = R (Q - X3) - Y1 PPP
+    const F QX = f28_sub_k16<RR>(Q, X3);                   // L e<=2, < 18p
+    const F RQX = f28_mul<RR>(R, QX);                      // e 2+2 -> T
+    const F YP = f28_mul<RR>(acc.Y, PPP);                  // W(<6p) x T -> T
+    acc.Y = f28_weak_norm<RR>(f28_sub_k4<RR>(RQX, YP));    // W, < 6p
+    acc.X = X3;
+    acc.ZZ = f28_mul<RR>(acc.ZZ, PP);                      // T
+    acc.ZZZ = f28_mul<RR>(acc.ZZZ, PPP);                   // T
+    return true;
+}
+
+// XYZZ28 (internal) -> dense XYZZ in STANDARD Montgomery form (what the reduce kernels consume)
+template <class C>
+PM_HD_COLD XYZZ<C> xyzz28_to_std(XYZZ28<C> a) {
+    typedef typename C::FqRR RR;
+    XYZZ<C> r;
+    if (f28_all_zero<RR>(a.ZZ)) return XYZZ<C>::identity();
+    r.X = f28_to_std<RR>(a.X);
+    r.Y = f28_to_std<RR>(a.Y);
+    r.ZZ = f28_to_std<RR>(a.ZZ);
+    r.ZZZ = f28_to_std<RR>(a.ZZZ);
+    return r;
+}
+// dense STANDARD XYZZ -> internal XYZZ28 (after resolving an exceptional case on the dense path)
+template <class C>
+PM_HD_COLD XYZZ28<C> xyzz28_from_std(const XYZZ<C> &a) {
+    typedef typename C::FqRR RR;
+    XYZZ28<C> r;
+    if (a.is_identity()) {
+        r.X = r.Y = r.ZZ = r.ZZZ = f28_zero<RR>();
+        return r;
+    }
+    r.X = f28_unpack<RR>(fq_std_to_int<C>(a.X).l);
+    r.Y = f28_unpack<RR>(fq_std_to_int<C>(a.Y).l);
+    r.ZZ = f28_unpack<RR>(fq_std_to_int<C>(a.ZZ).l);
+    r.ZZZ = f28_unpack<RR>(fq_std_to_int<C>(a.ZZZ).l);
+    return r;
+}
+
+// The exceptional case of xyzz28_madd (acc == +-point), resolved with the complete dense formulas.
+template <class C>
+PM_HD_COLD XYZZ28<C> xyzz28_madd_exceptional(XYZZ28<C> acc, Affine<C> q_internal, bool negate) {
+    // by value on purpose: a by-reference accumulator would have to live in scratch memory in the hot loop
+    XYZZ<C> d = xyzz28_to_std<C>(acc);
+    Affine<C> ps{fq_int_to_std<C>(q_internal.x), fq_int_to_std<C>(q_internal.y)};
+    xyzz_madd<C>(d, ps, negate);
+    return xyzz28_from_std<C>(d);
+}
+
+}  // namespace pm

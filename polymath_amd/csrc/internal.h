@@ -154,6 +154,11 @@ int bases_generate_multiples(pm_ctx *ctx, size_t len, Affine<C> *d_out);
 template <class C>
 int fixed_base_batch(pm_ctx *ctx, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *d_out);
 
+// Device base vectors are kept in the INTERNAL Montgomery radix of the reduced-radix accumulate kernel
+// (fq28.cuh); this converts a device array in place at the API boundary (upload / generate / export).
+template <class C>
+int bases_convert(pm_ctx *ctx, Affine<C> *d_points, size_t len, bool to_internal);
+
 template <class C>
 int powers_fill(pm_ctx *ctx, Fp<typename C::FrP> *d_out, size_t count, const Fp<typename C::FrP> &scale,
                 const Fp<typename C::FrP> &x);

@@ -18,10 +18,12 @@
 //                 bases are gathered from HBM by index (96 B affine points).
 //   k_bucket_reduce  per window sum_b (b+1) * B_b by per-lane running sums over K buckets, a
 //                 small scalar multiple, and an LDS tree reduction per workgroup.
-//   k_finish      Horner over the windows (c doublings each) and one inversion to affine.
+//   host_finish   Horner over the W window sums (c doublings each) and one inversion to affine, on the
+//                 host: an O(W) dependent chain (see host_finish).
 #include <cstring>
 
 #include "internal.h"
+#include "fq28.cuh"
 
 namespace pm {
 
@@ -197,10 +199,14 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t *digits, const 
 }
 
 // ---------------------------------------------------------------------------- accumulate
+// One lane per task.  The accumulator lives in reduced-radix registers (fq28.cuh): 10 carry-free
+// Montgomery products and 7 lazy add/sub per mixed add.  `bases` are in INTERNAL Montgomery form.
+// The exceptional case acc == +-point (doubling / cancellation) is resolved on the dense path.
 template <class C>
 __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, const uint32_t *counts,
                                                     const uint32_t *bucket_off, const uint32_t *task_off,
                                                     const Affine<C> *bases, XYZZ<C> *partials, size_t G, unsigned seg) {
+    typedef typename C::FqRR RR;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = task_off[G];
     if (t >= total) return;
@@ -215,13 +221,14 @@ __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, cons
     const uint32_t start = bucket_off[g] + k * seg;
     uint32_t end = bucket_off[g] + counts[g];
     if (start + seg < end) end = start + seg;
-    XYZZ<C> acc = XYZZ<C>::identity();
+    XYZZ28<C> acc;
+    acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
     for (uint32_t e = start; e < end; ++e) {
-        uint32_t v = sorted[e];
-        Affine<C> p = bases[v >> 1];
-        xyzz_madd<C>(acc, p, (v & 1u) != 0);
+        const uint32_t v = sorted[e];
+        const Affine<C> p = bases[v >> 1];
+        if (!xyzz28_madd<C>(acc, p, (v & 1u) != 0)) acc = xyzz28_madd_exceptional<C>(acc, p, (v & 1u) != 0);
     }
-    partials[t] = acc;
+    partials[t] = xyzz28_to_std<C>(acc);
 }
 
 // ------------------------------------------------------------------------- bucket reduce
@@ -263,34 +270,18 @@ __global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, 
     if (threadIdx.x == 0) wsum[blockIdx.x] = sh[0];
 }
 
+// Final combine S = sum_w 2^(c w) S_w (Horner, c doublings per window) and the inversion to affine:
+// O(W) point operations on W * blocks_per_window partial sums.  A single GPU lane needs ~9 ms for this
+// dependent chain (profiles/r01_a_*), the host 0.3 ms with the same templates, so it runs on the host.
 template <class C>
-struct MsmResult {
-    Affine<C> p;
-    int inf;
-    int pad[3];
-};
-
-// Final combine: S = sum_w 2^(c w) S_w by Horner, then one inversion to affine.
-template <class C>
-__global__ void k_finish(const XYZZ<C> *wsum, unsigned nwin, unsigned blocks_per_window, unsigned c, MsmResult<C> *out) {
-    __shared__ XYZZ<C> sw[64];
-    const unsigned w = threadIdx.x;
-    if (w < nwin) {
-        XYZZ<C> s = XYZZ<C>::identity();
-        for (unsigned b = 0; b < blocks_per_window; ++b) s = xyzz_add<C>(s, wsum[w * blocks_per_window + b]);
-        sw[w] = s;
+static void host_finish(const XYZZ<C> *wsum, unsigned nwin, unsigned bpw, unsigned c, Affine<C> *out, int *inf) {
+    XYZZ<C> acc = XYZZ<C>::identity();
+    for (int w = (int)nwin - 1; w >= 0; --w) {
+        for (unsigned k = 0; k < c; ++k) acc = xyzz_dbl<C>(acc);
+        for (unsigned b = 0; b < bpw; ++b) acc = xyzz_add<C>(acc, wsum[w * bpw + b]);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        XYZZ<C> acc = sw[nwin - 1];
-        for (int ww = (int)nwin - 2; ww >= 0; --ww) {
-            for (unsigned k = 0; k < c; ++k) acc = xyzz_dbl<C>(acc);
-            acc = xyzz_add<C>(acc, sw[ww]);
-        }
-        Affine<C> a = xyzz_to_affine<C>(acc);
-        out->p = a;
-        out->inf = acc.is_identity() ? 1 : 0;
-    }
+    *inf = acc.is_identity() ? 1 : 0;
+    *out = xyzz_to_affine<C>(acc);
 }
 
 // ------------------------------------------------------------------------------- driver
@@ -318,7 +309,6 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
     unsigned red_block = p.red_threads < 256 ? p.red_threads : 256;
     if (red_block < 64) red_block = 64;
     PM_HIP(ctx, ws.wsum.reserve((size_t)p.nwin * bpw * sizeof(XYZZ<C>)));
-    PM_HIP(ctx, ws.result.reserve(sizeof(MsmResult<C>)));
     uint32_t *counts = ws.counts.as<uint32_t>(), *cursor = counts + G;
     {
         StageTimer t(ctx, T_MSM_SORT);
@@ -355,15 +345,11 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
                            ctx->stream, ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.wsum.as<XYZZ<C>>(),
                            p.nbuckets, p.red_k, p.red_threads, bpw);
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_finish<C>, dim3(1), dim3(64), 0, ctx->stream, ws.wsum.as<XYZZ<C>>(), p.nwin, bpw, p.c,
-                           ws.result.as<MsmResult<C>>());
-        PM_HIP(ctx, hipGetLastError());
     }
-    MsmResult<C> res;
-    PM_HIP(ctx, hipMemcpyAsync(&res, ws.result.p, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<XYZZ<C>> hw((size_t)p.nwin * bpw);
+    PM_HIP(ctx, hipMemcpyAsync(hw.data(), ws.wsum.p, hw.size() * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *h_out = res.p;
-    *h_inf = res.inf;
+    host_finish<C>(hw.data(), p.nwin, bpw, p.c, h_out, h_inf);
     return PM_OK;
 }
 

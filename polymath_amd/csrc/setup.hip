@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "internal.h"
+#include "fq28.cuh"
 
 namespace pm {
 
@@ -163,8 +164,33 @@ int bases_generate_multiples(pm_ctx *ctx, size_t len, Affine<C> *d_out) {
                            ctx->scratch.as<Fr>(), cnt, (uint64_t)(s + 1));
         PM_HIP(ctx, hipGetLastError());
         PM_TRY(fixed_base_batch<C>(ctx, ctx->scratch.as<Fr>(), cnt, d_out + s));
+        PM_TRY(bases_convert<C>(ctx, d_out + s, cnt, true));
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+template <class C>
+__global__ void k_bases_convert(Affine<C> *pts, size_t len, int to_internal) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    Affine<C> a = pts[i];
+    if (to_internal) {
+        a.x = fq_std_to_int<C>(a.x);
+        a.y = fq_std_to_int<C>(a.y);
+    } else {
+        a.x = fq_int_to_std<C>(a.x);
+        a.y = fq_int_to_std<C>(a.y);
+    }
+    pts[i] = a;
+}
+
+template <class C>
+int bases_convert(pm_ctx *ctx, Affine<C> *d_points, size_t len, bool to_internal) {
+    if (!len) return PM_OK;
+    hipLaunchKernelGGL(k_bases_convert<C>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, d_points, len,
+                       to_internal ? 1 : 0);
+    PM_HIP(ctx, hipGetLastError());
     return PM_OK;
 }
 
@@ -172,7 +198,8 @@ int bases_generate_multiples(pm_ctx *ctx, size_t len, Affine<C> *d_out) {
     template int powers_fill<C>(pm_ctx *, Fp<typename C::FrP> *, size_t, const Fp<typename C::FrP> &,           \
                                 const Fp<typename C::FrP> &);                                                   \
     template int fixed_base_batch<C>(pm_ctx *, const Fp<typename C::FrP> *, size_t, Affine<C> *);               \
-    template int bases_generate_multiples<C>(pm_ctx *, size_t, Affine<C> *);
+    template int bases_generate_multiples<C>(pm_ctx *, size_t, Affine<C> *);                                    \
+    template int bases_convert<C>(pm_ctx *, Affine<C> *, size_t, bool);
 PM_INST(BlsCurve)
 PM_INST(BnCurve)
 

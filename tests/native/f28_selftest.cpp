@@ -1,0 +1,108 @@
+// Host build of the device field/EC templates (plain C++): checks the reduced-radix (28-bit limb)
+// path of csrc/fq28.cuh against the dense 32-bit-limb path of csrc/field.cuh / ec.cuh, which the GPU
+// parity tests pin against the oracle.  Built and run by tests/test_native_f28.py (CPU, no GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../polymath_amd/csrc/fq28.cuh"
+
+using namespace pm;
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t next_u64() {
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <class P>
+static Fp<P> rand_fp() {
+    Fp<P> r;
+    for (int i = 0; i < P::N; ++i) r.l[i] = (uint32_t)next_u64();
+    // squash below the modulus: clear top bits then one conditional subtraction via mul by one
+    int top_bits = P::BITS - 32 * (P::N - 1);
+    r.l[P::N - 1] &= (1u << (top_bits - 1)) - 1;
+    return r;
+}
+
+template <class C>
+static int run(const char *name, int iters) {
+    typedef typename C::FqP Q;
+    typedef typename C::FqRR RR;
+    typedef Fp<Q> Fq;
+    int fails = 0;
+    // 1. products, including the extremes 0, 1, p-1
+    std::vector<Fq> pool;
+    pool.push_back(Fq::zero());
+    pool.push_back(Fq::one());
+    Fq pm1;
+    for (int i = 0; i < Q::N; ++i) pm1.l[i] = Q::MOD[i];
+    pm1.l[0] -= 1;
+    pool.push_back(pm1);
+    for (int i = 0; i < iters; ++i) pool.push_back(rand_fp<Q>());
+    for (size_t i = 0; i + 1 < pool.size(); ++i) {
+        Fq a = pool[i], b = pool[i + 1];
+        Fq want = mul<Q>(a, b);
+        F28<RR> fa = f28_unpack<RR>(fq_std_to_int<C>(a).l), fb = f28_unpack<RR>(fq_std_to_int<C>(b).l);
+        Fq got = f28_to_std<RR>(f28_mul<RR>(fa, fb));
+        if (!got.eq(want)) { if (fails++ < 5) printf("%s mul mismatch at %zu\n", name, i); }
+        Fq gsq = f28_to_std<RR>(f28_sqr<RR>(f28_sub_k16<RR>(fa, fb)));      // loose input (e ~ 1.6), as in the mixed add
+        Fq dsq = sqr<Q>(sub<Q>(a, b));
+        if (!gsq.eq(dsq)) { if (fails++ < 5) printf("%s sqr mismatch at %zu\n", name, i); }
+        // round trip of the radix conversions
+        if (!fq_int_to_std<C>(fq_std_to_int<C>(a)).eq(a)) { if (fails++ < 5) printf("%s conv mismatch\n", name); }
+        // lazy add/sub chain: (a + b) * (a - b) == a^2 - b^2
+        F28<RR> s = f28_add<RR>(fa, fb), d = f28_sub_k4<RR>(fa, fb);
+        Fq lhs = f28_to_std<RR>(f28_mul<RR>(s, d));
+        Fq rhs = sub<Q>(sqr<Q>(a), sqr<Q>(b));
+        if (!lhs.eq(rhs)) { if (fails++ < 5) printf("%s lazy mismatch at %zu\n", name, i); }
+    }
+    // 2. accumulate a chain of points both ways: P_k = (k+1) G built with the dense path
+    Affine<C> g;
+    for (int i = 0; i < Q::N; ++i) { g.x.l[i] = C::GX_MONT[i]; g.y.l[i] = C::GY_MONT[i]; }
+    const int NP = 300;
+    std::vector<Affine<C>> pts(NP);
+    XYZZ<C> run_pt = XYZZ<C>::identity();
+    for (int k = 0; k < NP; ++k) {
+        xyzz_madd<C>(run_pt, g, false);
+        pts[k] = xyzz_to_affine<C>(run_pt);
+        if (!affine_on_curve<C>(pts[k])) { if (fails++ < 5) printf("%s off curve\n", name); }
+    }
+    XYZZ<C> dense = XYZZ<C>::identity();
+    XYZZ28<C> rr;
+    rr.X = rr.Y = rr.ZZ = rr.ZZZ = f28_zero<RR>();
+    int exceptional = 0;
+    for (int rep = 0; rep < 3; ++rep)
+        for (int k = 0; k < NP; ++k) {
+            bool negate = (next_u64() & 1) != 0;
+            int idx = (rep == 2 && k == 5) ? 4 : k;       // force a repeated point (doubling) once
+            const Affine<C> &p = pts[idx];
+            xyzz_madd<C>(dense, p, negate);
+            Affine<C> pi{fq_std_to_int<C>(p.x), fq_std_to_int<C>(p.y)};
+            if (!xyzz28_madd<C>(rr, pi, negate)) {
+                ++exceptional;
+                XYZZ<C> tmp = xyzz28_to_std<C>(rr);
+                xyzz_madd<C>(tmp, p, negate);
+                rr = xyzz28_from_std<C>(tmp);
+            }
+        }
+    Affine<C> a1 = xyzz_to_affine<C>(dense), a2 = xyzz_to_affine<C>(xyzz28_to_std<C>(rr));
+    if (!(a1.x.eq(a2.x) && a1.y.eq(a2.y))) { fails++; printf("%s madd chain mismatch\n", name); }
+    // 3. P + (-P) and P + P through the exceptional path
+    XYZZ28<C> e;
+    e.X = e.Y = e.ZZ = e.ZZZ = f28_zero<RR>();
+    Affine<C> pi{fq_std_to_int<C>(pts[7].x), fq_std_to_int<C>(pts[7].y)};
+    bool ok1 = xyzz28_madd<C>(e, pi, false), ok2 = xyzz28_madd<C>(e, pi, true), ok3 = xyzz28_madd<C>(e, pi, false);
+    if (!ok1 || ok2 || ok3) { fails++; printf("%s exceptional-case detection wrong %d %d %d\n", name, ok1, ok2, ok3); }
+    printf("%s: %d failures (%d exceptional cases resolved)\n", name, fails, exceptional);
+    return fails;
+}
+
+int main(int argc, char **argv) {
+    int iters = argc > 1 ? atoi(argv[1]) : 2000;
+    int f = run<BlsCurve>("bls12_381", iters) + run<BnCurve>("bn254", iters);
+    return f ? 1 : 0;
+}
