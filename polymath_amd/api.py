@@ -106,6 +106,20 @@ def _c(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
 
 
+def g1_sum(curve, pts, infs=None):
+    """pm_g1_sum: host-side sum of G1 points (combining per-GPU partial MSM results); needs no GPU."""
+    L = load_library()
+    cid = CURVE_IDS[curve]
+    pts = _c(pts).reshape(-1, 2 * FQ_LIMBS64[cid])
+    out = np.zeros(2 * FQ_LIMBS64[cid], dtype=np.uint64)
+    inf = ct.c_int(0)
+    ia = np.ascontiguousarray(infs, dtype=np.int32) if infs is not None else None
+    st = L.pm_g1_sum(cid, _p(pts), ia.ctypes.data_as(intp) if ia is not None else None, len(pts), _p(out), ct.byref(inf))
+    if st:
+        raise PolymathError(st, "pm_g1_sum")
+    return out, inf.value
+
+
 class Context:
     """pm_ctx: one HIP stream + workspaces on one GPU; one proof in flight."""
 
@@ -157,14 +171,7 @@ class Context:
         return out, inf.value
 
     def g1_sum(self, curve, pts, infs=None):
-        cid = CURVE_IDS[curve]
-        pts = _c(pts).reshape(-1, 2 * FQ_LIMBS64[cid])
-        out = np.zeros(2 * FQ_LIMBS64[cid], dtype=np.uint64)
-        inf = ct.c_int(0)
-        ia = np.ascontiguousarray(infs, dtype=np.int32) if infs is not None else None
-        st = self.L.pm_g1_sum(cid, _p(pts), ia.ctypes.data_as(intp) if ia is not None else None, len(pts), _p(out), ct.byref(inf))
-        self.check(st)
-        return out, inf.value
+        return g1_sum(curve, pts, infs)
 
 
 class Bases:
