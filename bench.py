@@ -76,9 +76,16 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     import torch
     import torch.distributed as dist
+    # test hooks: several ranks sharing one GPU over gloo (tests/test_gpu_parity.py::test_bench_two_ranks_one_gpu)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from polymath_amd import circuits as PC
     from polymath_amd.distributed import PointCombiner
@@ -97,7 +104,7 @@ def main():
     pk = pm.setup((r1cs, inst, wit), x_trap, z_trap, shard_rank=rank, shard_count=world)
     log(rank, "setup on device: n=%d, %d resident points (%.1f s)" % (pk.n, sum(pk.base_lens), time.time() - t0))
     x_l, w_l = pm.field.fr_limbs(inst), pm.field.fr_limbs(wit)
-    combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local) if world > 1 else None
+    combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local, backend_gloo=(backend != "nccl")) if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -118,7 +125,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3

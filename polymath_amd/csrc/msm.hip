@@ -20,6 +20,7 @@
 //                 small scalar multiple, and an LDS tree reduction per workgroup.
 //   host_finish   Horner over the W window sums (c doublings each) and one inversion to affine, on the
 //                 host: an O(W) dependent chain (see host_finish).
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.h"
@@ -56,11 +57,18 @@ static MsmPlan make_plan(size_t len, unsigned scalar_bits) {
     size_t seg = 2 * avg;
     if (seg < 64) seg = 64;
     p.seg = (unsigned)seg;
-    p.chunk = 1u << 16;
+    p.chunk = 1u << 15;   // scalars per (chunk, window) histogram / scatter workgroup (tools/msm_bench.py sweep)
     if (len < p.chunk) p.chunk = (unsigned)(len ? len : 1);
     p.nchunks = (unsigned)((len + p.chunk - 1) / p.chunk);
     p.red_threads = p.nbuckets < 2048 ? p.nbuckets : 2048;
     p.red_k = p.nbuckets / p.red_threads;
+    // developer knobs for tuning sweeps (tools/msm_bench.py); unset in production
+    if (const char *e = getenv("PM_MSM_CHUNK_LOG")) {
+        p.chunk = 1u << atoi(e);
+        if (len < p.chunk) p.chunk = (unsigned)(len ? len : 1);
+        p.nchunks = (unsigned)((len + p.chunk - 1) / p.chunk);
+    }
+    if (const char *e = getenv("PM_MSM_SEG")) p.seg = (unsigned)atoi(e);
     p.max_tasks = (size_t)p.nwin * p.nbuckets + ((size_t)p.nwin * len) / p.seg + 1;
     return p;
 }
@@ -127,26 +135,29 @@ __global__ __launch_bounds__(1024) void k_hist(const uint32_t *digits, uint32_t 
     }
 }
 
-// Single-workgroup exclusive scans over all nwin*nbuckets buckets:
+// Exclusive scans over all G = nwin*nbuckets buckets, three small launches (tile scan, scan of the
+// tile totals, offset add):
 //   bucket_off[g] = sum_{g' < g} counts[g'],   task_off[g] = sum_{g' < g} ceil(counts[g'] / seg)
-// (+ totals at index G).  G <= 2^20, so one 1024-thread workgroup with a sequential tile per lane.
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t *counts, uint32_t *bucket_off, uint32_t *task_off,
-                                               size_t G, unsigned seg) {
-    __shared__ uint32_t s_a[1024], s_b[1024];
-    const unsigned tid = threadIdx.x, T = blockDim.x;
-    size_t per = (G + T - 1) / T, lo = (size_t)tid * per, hi = lo + per;
-    if (lo > G) lo = G;
-    if (hi > G) hi = G;
+// (+ totals at index G).  A lane owns SCAN_PER contiguous counters (64 B), a workgroup SCAN_TILE.
+constexpr unsigned SCAN_PER = 16, SCAN_TILE = 256 * SCAN_PER;
+
+__global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *counts, uint32_t *bucket_off, uint32_t *task_off,
+                                                    uint32_t *tile_tot, size_t G, unsigned seg) {
+    __shared__ uint32_t s_a[256], s_b[256];
+    const unsigned tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)tid * SCAN_PER;
+    uint32_t c[SCAN_PER];
     uint32_t sa = 0, sb = 0;
-    for (size_t g = lo; g < hi; ++g) {
-        uint32_t cnt = counts[g];
-        sa += cnt;
-        sb += (cnt + seg - 1) / seg;
+#pragma unroll
+    for (unsigned k = 0; k < SCAN_PER; ++k) {
+        c[k] = base + k < G ? counts[base + k] : 0u;
+        sa += c[k];
+        sb += (c[k] + seg - 1) / seg;
     }
     s_a[tid] = sa;
     s_b[tid] = sb;
     __syncthreads();
-    for (unsigned off = 1; off < T; off <<= 1) {  // Hillis-Steele inclusive scan
+    for (unsigned off = 1; off < 256; off <<= 1) {
         uint32_t va = 0, vb = 0;
         if (tid >= off) { va = s_a[tid - off]; vb = s_b[tid - off]; }
         __syncthreads();
@@ -154,18 +165,49 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t *counts, uint32_t 
         s_b[tid] += vb;
         __syncthreads();
     }
-    uint32_t ra = s_a[tid] - sa, rb = s_b[tid] - sb;  // exclusive prefix of this lane's tile
-    for (size_t g = lo; g < hi; ++g) {
-        uint32_t cnt = counts[g];
-        bucket_off[g] = ra;
-        task_off[g] = rb;
-        ra += cnt;
-        rb += (cnt + seg - 1) / seg;
+    uint32_t ra = s_a[tid] - sa, rb = s_b[tid] - sb;
+#pragma unroll
+    for (unsigned k = 0; k < SCAN_PER; ++k) {
+        if (base + k < G) { bucket_off[base + k] = ra; task_off[base + k] = rb; }
+        ra += c[k];
+        rb += (c[k] + seg - 1) / seg;
     }
-    if (tid == T - 1) {
-        bucket_off[G] = s_a[T - 1];
-        task_off[G] = s_b[T - 1];
+    if (tid == 255) { tile_tot[2 * blockIdx.x] = s_a[255]; tile_tot[2 * blockIdx.x + 1] = s_b[255]; }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_totals(uint32_t *tile_tot, unsigned ntiles, uint32_t *bucket_off,
+                                                      uint32_t *task_off, size_t G) {
+    __shared__ uint32_t s_a[1024], s_b[1024];
+    const unsigned tid = threadIdx.x;
+    uint32_t carry_a = 0, carry_b = 0;
+    for (unsigned base = 0; base < ntiles; base += 1024) {
+        unsigned i = base + tid;
+        uint32_t a = i < ntiles ? tile_tot[2 * i] : 0u, b = i < ntiles ? tile_tot[2 * i + 1] : 0u;
+        s_a[tid] = a;
+        s_b[tid] = b;
+        __syncthreads();
+        for (unsigned off = 1; off < 1024; off <<= 1) {
+            uint32_t va = 0, vb = 0;
+            if (tid >= off) { va = s_a[tid - off]; vb = s_b[tid - off]; }
+            __syncthreads();
+            s_a[tid] += va;
+            s_b[tid] += vb;
+            __syncthreads();
+        }
+        if (i < ntiles) { tile_tot[2 * i] = carry_a + s_a[tid] - a; tile_tot[2 * i + 1] = carry_b + s_b[tid] - b; }
+        carry_a += s_a[1023];
+        carry_b += s_b[1023];
+        __syncthreads();
     }
+    if (tid == 0) { bucket_off[G] = carry_a; task_off[G] = carry_b; }
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t *bucket_off, uint32_t *task_off, const uint32_t *tile_tot, size_t G) {
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_PER;
+    const uint32_t oa = tile_tot[2 * blockIdx.x], ob = tile_tot[2 * blockIdx.x + 1];
+#pragma unroll
+    for (unsigned k = 0; k < SCAN_PER; ++k)
+        if (base + k < G) { bucket_off[base + k] += oa; task_off[base + k] += ob; }
 }
 
 __global__ __launch_bounds__(1024) void k_scatter(const uint32_t *digits, const uint32_t *bucket_off, uint32_t *cursor,
@@ -270,6 +312,20 @@ __global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, 
     if (threadIdx.x == 0) wsum[blockIdx.x] = sh[0];
 }
 
+// wsum[w * bpw + b] (b < bpw <= 64) -> one point per window, LDS tree in a 64-lane workgroup per window
+template <class C>
+__global__ __launch_bounds__(64) void k_window_sum(const XYZZ<C> *wsum, unsigned bpw, XYZZ<C> *out) {
+    __shared__ XYZZ<C> sh[64];
+    const unsigned w = blockIdx.x, t = threadIdx.x;
+    sh[t] = t < bpw ? wsum[w * bpw + t] : XYZZ<C>::identity();
+    __syncthreads();
+    for (unsigned off = 32; off > 0; off >>= 1) {
+        if (t < off && t + off < 64) sh[t] = xyzz_add<C>(sh[t], sh[t + off]);
+        __syncthreads();
+    }
+    if (t == 0) out[w] = sh[0];
+}
+
 // Final combine S = sum_w 2^(c w) S_w (Horner, c doublings per window) and the inversion to affine:
 // O(W) point operations on W * blocks_per_window partial sums.  A single GPU lane needs ~9 ms for this
 // dependent chain (profiles/r01_a_*), the host 0.3 ms with the same templates, so it runs on the host.
@@ -304,11 +360,12 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
     PM_HIP(ctx, ws.counts.reserve(2 * G * 4));  // counts | cursor, one memset
     PM_HIP(ctx, ws.bucket_off.reserve((G + 1) * 4));
     PM_HIP(ctx, ws.task_off.reserve((G + 1) * 4));
+    PM_HIP(ctx, ws.cursor.reserve(((G + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));  // scan tile totals
     PM_HIP(ctx, ws.partials.reserve(p.max_tasks * sizeof(XYZZ<C>)));
     unsigned bpw = (p.red_threads + 255) / 256;
     unsigned red_block = p.red_threads < 256 ? p.red_threads : 256;
     if (red_block < 64) red_block = 64;
-    PM_HIP(ctx, ws.wsum.reserve((size_t)p.nwin * bpw * sizeof(XYZZ<C>)));
+    PM_HIP(ctx, ws.wsum.reserve(((size_t)p.nwin * bpw + p.nwin) * sizeof(XYZZ<C>)));
     uint32_t *counts = ws.counts.as<uint32_t>(), *cursor = counts + G;
     {
         StageTimer t(ctx, T_MSM_SORT);
@@ -324,8 +381,15 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
         hipLaunchKernelGGL(k_hist, dim3(p.nchunks, p.nwin), dim3(1024), lds, ctx->stream, ws.digits.as<uint32_t>(), counts,
                            len, p.chunk, p.nbuckets);
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, counts, ws.bucket_off.as<uint32_t>(),
-                           ws.task_off.as<uint32_t>(), G, p.seg);
+        const unsigned ntiles = (unsigned)((G + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, counts, ws.bucket_off.as<uint32_t>(),
+                           ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), G, p.seg);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, ws.cursor.as<uint32_t>(), ntiles,
+                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), G);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, ctx->stream, ws.bucket_off.as<uint32_t>(),
+                           ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), G);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_scatter, dim3(p.nchunks, p.nwin), dim3(1024), lds, ctx->stream, ws.digits.as<uint32_t>(),
                            ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>(), len, p.chunk, p.nbuckets);
@@ -346,10 +410,13 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
                            p.nbuckets, p.red_k, p.red_threads, bpw);
         PM_HIP(ctx, hipGetLastError());
     }
-    std::vector<XYZZ<C>> hw((size_t)p.nwin * bpw);
-    PM_HIP(ctx, hipMemcpyAsync(hw.data(), ws.wsum.p, hw.size() * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
+    XYZZ<C> *d_wfinal = ws.wsum.as<XYZZ<C>>() + (size_t)p.nwin * bpw;
+    hipLaunchKernelGGL(k_window_sum<C>, dim3(p.nwin), dim3(64), 0, ctx->stream, ws.wsum.as<XYZZ<C>>(), bpw, d_wfinal);
+    PM_HIP(ctx, hipGetLastError());
+    std::vector<XYZZ<C>> hw(p.nwin);
+    PM_HIP(ctx, hipMemcpyAsync(hw.data(), d_wfinal, hw.size() * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    host_finish<C>(hw.data(), p.nwin, bpw, p.c, h_out, h_inf);
+    host_finish<C>(hw.data(), p.nwin, 1, p.c, h_out, h_inf);
     return PM_OK;
 }
 

@@ -311,3 +311,22 @@ def test_error_codes(gpu_ctx, oracle, api):
     assert e.value.status == 2                         # scalars.len() > bases.len(), prover.rs:381
     pk3.free()
     ctx3.close()
+
+
+def test_bench_two_ranks_one_gpu_same_proof():
+    """bench.py's N > 1 flow end to end: 2 ranks (sharing the one GPU here, gloo instead of RCCL) each
+    generate and hold half of every MSM pair range, all-gather partial points, and must print the same
+    proof bytes as the single-rank run."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "0", "--log-constraints", "12", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29544", os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["proof_bytes"] == j2["proof_bytes"] and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
