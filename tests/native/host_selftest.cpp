@@ -1,0 +1,23 @@
+// CPU-only known-answer tests of the C++ host mirror's hashes and field glue (no GPU, no library link).
+#include <cstdio>
+#include "../../polymath_amd/host/hashes.hpp"
+#include "../../polymath_amd/csrc/field.cuh"
+using namespace pmhost;
+int main() {
+    int fails = 0;
+    auto hex = [](const Bytes &b) { static const char *d = "0123456789abcdef"; std::string s; for (uint8_t v : b) { s.push_back(d[v >> 4]); s.push_back(d[v & 15]); } return s; };
+    if (hex(keccak256(Bytes())) != "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470") { fails++; printf("keccak256 KAT\n"); }
+    if (hex(blake3(Bytes())) != "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262") { fails++; printf("blake3 KAT\n"); }
+    Bytes pat(2049);
+    for (size_t i = 0; i < pat.size(); ++i) pat[i] = (uint8_t)(i % 251);
+    if (hex(blake3(pat)).substr(0, 32) != "5f4d72f40d7a5f82b15ca2b2e44b1de3") { fails++; printf("blake3 2049 KAT\n"); }
+    pat.resize(1025);
+    if (hex(blake3(pat)).substr(0, 32) != "d00278ae47eb27b34faecf67b4fe263f") { fails++; printf("blake3 1025 KAT\n"); }
+    MerlinTranscript m("test protocol");   // merlin 3.0.0 transcript.rs equivalence_simple
+    m.append_message("some label", (const uint8_t *)"some data", 9);
+    Bytes ch(32);
+    m.challenge_bytes("challenge", ch.data(), 32);
+    if (hex(ch) != "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615") { fails++; printf("merlin KAT %s\n", hex(ch).c_str()); }
+    printf("host selftest: %d failures\n", fails);
+    return fails ? 1 : 0;
+}
