@@ -35,7 +35,7 @@ for curve, nq in (("bls12_381", 6), ("bn254", 4)):
     assert np.array_equal(got, first), (curve, rank, "infinity part")
 dist.barrier()
 dist.destroy_process_group()
-sys.stdout.write("rank%d-ok\n" % rank); sys.stdout.flush()
+sys.stdout.write("rank" + str(rank) + "-ok\n"); sys.stdout.flush()
 '''
 
 
