@@ -341,16 +341,13 @@ static void host_finish(const XYZZ<C> *wsum, unsigned nwin, unsigned bpw, unsign
 }
 
 // ------------------------------------------------------------------------------- driver
+// One bucket pipeline over at most MSM_MAX_PIECE pairs (sorted-entry positions are u32: W * len < 2^32).
+constexpr size_t MSM_MAX_PIECE = (size_t)1 << 27;
+
 template <class C>
-int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *h_out,
-            int *h_inf) {
+static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *h_out,
+                     int *h_inf) {
     typedef typename C::FrP FrP;
-    if (len == 0) {
-        *h_out = Affine<C>::infinity();
-        *h_inf = 1;
-        return PM_OK;
-    }
-    if (len >= ((size_t)1 << 31)) return PM_ERR_INVALID_ARG;
     StageTimer t_total(ctx, T_MSM_TOTAL);
     MsmPlan p = make_plan(len, (unsigned)FrP::BITS);
     MsmWorkspace &ws = ctx->msm;
@@ -417,6 +414,29 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
     PM_HIP(ctx, hipMemcpyAsync(hw.data(), d_wfinal, hw.size() * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     host_finish<C>(hw.data(), p.nwin, 1, p.c, h_out, h_inf);
+    return PM_OK;
+}
+
+template <class C>
+int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *h_out,
+            int *h_inf) {
+    if (len == 0) {
+        *h_out = Affine<C>::infinity();
+        *h_inf = 1;
+        return PM_OK;
+    }
+    if (len <= MSM_MAX_PIECE) return msm_piece<C>(ctx, d_bases, d_scalars, len, h_out, h_inf);
+    // very long MSMs (the 10n-pair quotient commitment at n >= 2^24 on one GPU): pieces, summed on the host
+    XYZZ<C> acc = XYZZ<C>::identity();
+    for (size_t off = 0; off < len; off += MSM_MAX_PIECE) {
+        size_t cnt = len - off < MSM_MAX_PIECE ? len - off : MSM_MAX_PIECE;
+        Affine<C> part;
+        int inf = 1;
+        PM_TRY(msm_piece<C>(ctx, d_bases + off, d_scalars + off, cnt, &part, &inf));
+        if (!inf) xyzz_madd<C>(acc, part, false);
+    }
+    *h_inf = acc.is_identity() ? 1 : 0;
+    *h_out = xyzz_to_affine<C>(acc);
     return PM_OK;
 }
 

@@ -330,3 +330,37 @@ def test_bench_two_ranks_one_gpu_same_proof():
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["proof_bytes"] == j2["proof_bytes"] and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+
+
+def test_full_size_2p20_proof_passes_pairing_verifier(oracle):
+    """BASELINE configs[1] at full size: 2^20-100 synthetic gates (n = 2^21, 29.4 M MSM pairs).  The CPU
+    restatement needs minutes here, so the check is the reference's own acceptance criterion
+    (tests/mimc.rs:214): the pairing verifier (verifier.rs:19-62, oracle/pyref) accepts the GPU proof
+    and rejects a tampered one; plus phase-1 outputs are on the curve."""
+    from oracle.pyref import pairing as PA, protocol as PR
+    from oracle.pyref.fields import BLS12_381 as c, BLS12_381_G2, g1_is_on_curve
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    nr = (1 << 20) - 100
+    r1cs, inst, wit = PC.synthetic_r1cs(c.r, nr)
+    g = PC.SplitMix64(0xF00D)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    pm = Polymath("bls12_381", "merlin", device=0)
+    pk = pm.setup((r1cs, inst, wit), x, z)
+    assert pk.n == 1 << 21
+    proof = pm.prove(pk, (r1cs, inst, wit), r_a).as_dict()
+    assert all(g1_is_on_curve(c, proof[k]) for k in ("a_g1", "c_g1", "d_g1"))
+    vk = dict(n=pk.n, m0=2, sigma=pk.sigma, omega=pk.omega, one_g1=c.g1, one_g2=BLS12_381_G2,
+              x_g2=PA.g2_mul(BLS12_381_G2, x), z_g2=PA.g2_mul(BLS12_381_G2, z))
+    TR = T.make_transcripts(c)
+    assert PR.verify_proof(c, vk, proof, inst[1:], TR["merlin"], PA.pairing_check)
+    bad = dict(proof, a_at_x1=(proof["a_at_x1"] + 1) % c.r)
+    assert not PR.verify_proof(c, vk, bad, inst[1:], TR["merlin"], PA.pairing_check)
+    # unsatisfied witness at full size -> PM_ERR_REMAINDER_NONZERO (prover.rs:108)
+    from polymath_amd.polymath import PolymathProverError
+    wit2 = list(wit)
+    wit2[12345] = (wit2[12345] + 1) % c.r
+    with pytest.raises(PolymathProverError) as e:
+        pm.prove(pk, (r1cs, inst, wit2), r_a)
+    assert (e.value.phase, e.value.status) == (1, 4)
+    pk.free()
