@@ -95,6 +95,41 @@ PM_HD F28<RR> f28_mul(const F28<RR> &a, const F28<RR> &b) {
     return r;
 }
 
+// a*b + c*d with ONE interleaved Montgomery reduction (3 N^2 mads instead of 4 N^2).  Column bound:
+// N 2^(56+ea+eb) + N 2^(56+ec+ed) + N 2^56 < 2^64; value bound (ab + cd) < 2^(W N) p.  Output T.
+template <class RR>
+PM_HD F28<RR> f28_mul2_add(const F28<RR> &a, const F28<RR> &b, const F28<RR> &c, const F28<RR> &d) {
+    constexpr int N = RR::N;
+    uint64_t acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint32_t bi = b.l[i], di = d.l[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)a.l[j] * bi;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)c.l[j] * di;
+        const uint32_t m = ((uint32_t)acc[0] * RR::INV) & RR::MASK;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
+        const uint64_t carry = acc[0] >> RR::W;
+#pragma unroll
+        for (int j = 0; j < N - 1; ++j) acc[j] = acc[j + 1];
+        acc[N - 1] = 0;
+        acc[0] += carry;
+    }
+    F28<RR> r;
+    uint64_t cc = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        cc += acc[j];
+        r.l[j] = (uint32_t)cc & RR::MASK;
+        cc >>= RR::W;
+    }
+    return r;
+}
+
 // Montgomery square: the N(N-1)/2 cross products are taken once against the doubled operand
 // (limbs < 2^(29+e)), so a square costs N(N+1)/2 + N*N mads instead of 2 N*N.  Requires e_a <= 1.6
 // (2 e_a + 1 <= 4.2 under the same 64-bit column bound as f28_mul).  Output T.
@@ -284,9 +319,10 @@ PM_HD bool xyzz28_madd(XYZZ28<C> &acc, const Affine<C> &q, bool negate) {
     X3 = f28_weak_norm<RR>(X3);                            // W, < 14p
     // Y3 = R (Q - X3) - Y1 PPP
     const F QX = f28_sub_k16<RR>(Q, X3);                   // L e<=2, < 18p
-    const F RQX = f28_mul<RR>(R, QX);                      // e 2+2 -> T
-    const F YP = f28_mul<RR>(acc.Y, PPP);                  // W(<6p) x T -> T
-    acc.Y = f28_weak_norm<RR>(f28_sub_k4<RR>(RQX, YP));    // W, < 6p
+    // Y3 = R QX - Y1 PPP = R QX + Y1 (4p - PPP): both products under one reduction
+    // (columns 14 (2^59.2 + 2^57.6 + 2^56) < 2^63.5; (18p)^2 + 6p 6p < 2^(392) p 0.15 -> result < 2p)
+    const F nPPP = f28_sub_k4<RR>(f28_zero<RR>(), PPP);    // 4p - PPP, limbs < 2^29
+    acc.Y = f28_mul2_add<RR>(R, QX, acc.Y, nPPP);          // T (so also W < 6p)
     acc.X = X3;
     acc.ZZ = f28_mul<RR>(acc.ZZ, PP);                      // T
     acc.ZZZ = f28_mul<RR>(acc.ZZZ, PPP);                   // T
@@ -319,6 +355,101 @@ PM_HD_COLD XYZZ28<C> xyzz28_from_std(const XYZZ<C> &a) {
     r.ZZ = f28_unpack<RR>(fq_std_to_int<C>(a.ZZ).l);
     r.ZZZ = f28_unpack<RR>(fq_std_to_int<C>(a.ZZZ).l);
     return r;
+}
+
+// ---- internal-form points in memory ---------------------------------------------------------------
+// Task partials and every intermediate of the bucket reduction stay in the INTERNAL Montgomery radix:
+// an XYZZ<C> record whose four coordinates are canonical (< p) dense words of the internal form.
+template <class C>
+PM_HD XYZZ28<C> xyzz28_load(const XYZZ<C> &m) {
+    typedef typename C::FqRR RR;
+    XYZZ28<C> r;
+    r.X = f28_unpack<RR>(m.X.l);
+    r.Y = f28_unpack<RR>(m.Y.l);
+    r.ZZ = f28_unpack<RR>(m.ZZ.l);
+    r.ZZZ = f28_unpack<RR>(m.ZZZ.l);
+    return r;
+}
+template <class C>
+PM_HD XYZZ<C> xyzz28_store(const XYZZ28<C> &a) {
+    typedef typename C::FqRR RR;
+    XYZZ<C> r;
+    if (f28_all_zero<RR>(a.ZZ)) return XYZZ<C>::identity();
+    const F28<RR> one = f28_one<RR>();
+    f28_pack_reduced<RR>(f28_mul<RR>(a.X, one), r.X.l);   // X is W (< 14p): one Montgomery product by R brings it below 2p
+    f28_pack_reduced<RR>(f28_mul<RR>(a.Y, one), r.Y.l);
+    f28_pack_reduced<RR>(a.ZZ, r.ZZ.l);                   // T already
+    f28_pack_reduced<RR>(a.ZZZ, r.ZZZ.l);
+    return r;
+}
+// internal-form record <-> standard-form record (dense conversions; cold / host)
+template <class C>
+PM_HD_COLD XYZZ<C> xyzz_internal_to_std(XYZZ<C> a) {
+    if (a.is_identity()) return a;
+    a.X = fq_int_to_std<C>(a.X); a.Y = fq_int_to_std<C>(a.Y); a.ZZ = fq_int_to_std<C>(a.ZZ); a.ZZZ = fq_int_to_std<C>(a.ZZZ);
+    return a;
+}
+template <class C>
+PM_HD_COLD XYZZ<C> xyzz_std_to_internal(XYZZ<C> a) {
+    if (a.is_identity()) return a;
+    a.X = fq_std_to_int<C>(a.X); a.Y = fq_std_to_int<C>(a.Y); a.ZZ = fq_std_to_int<C>(a.ZZ); a.ZZZ = fq_std_to_int<C>(a.ZZZ);
+    return a;
+}
+
+// a + b on reduced-radix registers: add-2008-s (12M + 2S), same invariants as xyzz28_madd
+// (X: W < 14p, Y: W < 6p, ZZ, ZZZ: T).  Returns false on the exceptional case (same x).
+template <class C>
+PM_HD bool xyzz28_add(XYZZ28<C> &a, const XYZZ28<C> &b) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(b.ZZ)) return true;
+    if (f28_all_zero<RR>(a.ZZ)) { a = b; return true; }
+    const F U1 = f28_mul<RR>(a.X, b.ZZ), U2 = f28_mul<RR>(b.X, a.ZZ);      // W x T -> T
+    const F S1 = f28_mul<RR>(a.Y, b.ZZZ), S2 = f28_mul<RR>(b.Y, a.ZZZ);    // T
+    const F P = f28_sub_k4<RR>(U2, U1), R = f28_sub_k4<RR>(S2, S1);        // L e<=1.6, < 6p
+    const F PP = f28_sqr<RR>(P);
+    if (f28_is_zero_mod_p<RR>(PP)) return false;
+    const F PPP = f28_mul<RR>(P, PP), Q = f28_mul<RR>(U1, PP), RR2 = f28_sqr<RR>(R);
+    F X3 = f28_sub_k4<RR>(RR2, PPP);
+    X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(X3, f28_add<RR>(Q, Q)));         // W, < 14p
+    const F QX = f28_sub_k16<RR>(Q, X3);                                   // L e<=1.6, < 18p
+    const F Y3 = f28_mul2_add<RR>(R, QX, S1, f28_sub_k4<RR>(f28_zero<RR>(), PPP));             // R QX + S1 (4p - PPP): T
+    a.X = X3;
+    a.Y = Y3;
+    a.ZZ = f28_mul<RR>(f28_mul<RR>(a.ZZ, b.ZZ), PP);
+    a.ZZZ = f28_mul<RR>(f28_mul<RR>(a.ZZZ, b.ZZZ), PPP);
+    return true;
+}
+// 2a on reduced-radix registers: dbl-2008-s-1 (6M + 3S... here 5M + 4S incl. the fused last product).
+// No point of order 2 exists on either curve (odd group order), so Y != 0 for every finite curve point.
+template <class C>
+PM_HD void xyzz28_dbl(XYZZ28<C> &a) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(a.ZZ)) return;
+    const F U = f28_add<RR>(a.Y, a.Y);                         // limbs < 2^29, < 12p
+    const F V = f28_sqr<RR>(U), Wv = f28_mul<RR>(U, V), S = f28_mul<RR>(a.X, V);   // T
+    const F X2 = f28_sqr<RR>(a.X);                             // T
+    const F M = f28_add<RR>(f28_add<RR>(X2, X2), X2);          // limbs < 3 2^28, < 6p
+    F X3 = f28_sub_k8<RR>(f28_sqr<RR>(M), f28_add<RR>(S, S));  // < 10p
+    X3 = f28_weak_norm<RR>(X3);                                // W
+    const F SX = f28_sub_k16<RR>(S, X3);                       // L e<=1.6, < 18p
+    const F Y3 = f28_mul2_add<RR>(M, SX, a.Y, f28_sub_k4<RR>(f28_zero<RR>(), Wv));   // M (S - X3) + Y1 (4p - W): T
+    a.ZZ = f28_mul<RR>(V, a.ZZ);
+    a.ZZZ = f28_mul<RR>(Wv, a.ZZZ);
+    a.X = X3;
+    a.Y = Y3;
+}
+
+// exceptional case of xyzz28_add, complete dense formulas (cold)
+template <class C>
+PM_HD_COLD XYZZ28<C> xyzz28_add_exceptional(XYZZ28<C> a, XYZZ28<C> b) {
+    XYZZ<C> da = xyzz_internal_to_std<C>(xyzz28_store<C>(a)), db = xyzz_internal_to_std<C>(xyzz28_store<C>(b));
+    return xyzz28_load<C>(xyzz_std_to_internal<C>(xyzz_add<C>(da, db)));
+}
+template <class C>
+PM_HD void xyzz28_add_full(XYZZ28<C> &a, const XYZZ28<C> &b) {
+    if (!xyzz28_add<C>(a, b)) a = xyzz28_add_exceptional<C>(a, b);
 }
 
 // The exceptional case of xyzz28_madd (acc == +-point), resolved with the complete dense formulas.

@@ -35,7 +35,6 @@ struct MsmPlan {
     unsigned seg;                // max entries per accumulate task
     size_t len;
     unsigned chunk, nchunks;     // scalars per histogram workgroup
-    unsigned red_threads, red_k; // bucket-reduce geometry per window
     size_t max_tasks;
 };
 
@@ -60,8 +59,6 @@ static MsmPlan make_plan(size_t len, unsigned scalar_bits) {
     p.chunk = 1u << 15;   // scalars per (chunk, window) histogram / scatter workgroup (tools/msm_bench.py sweep)
     if (len < p.chunk) p.chunk = (unsigned)(len ? len : 1);
     p.nchunks = (unsigned)((len + p.chunk - 1) / p.chunk);
-    p.red_threads = p.nbuckets < 2048 ? p.nbuckets : 2048;
-    p.red_k = p.nbuckets / p.red_threads;
     // developer knobs for tuning sweeps (tools/msm_bench.py); unset in production
     if (const char *e = getenv("PM_MSM_CHUNK_LOG")) {
         p.chunk = 1u << atoi(e);
@@ -270,71 +267,84 @@ __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, cons
         const Affine<C> p = bases[v >> 1];
         if (!xyzz28_madd<C>(acc, p, (v & 1u) != 0)) acc = xyzz28_madd_exceptional<C>(acc, p, (v & 1u) != 0);
     }
-    partials[t] = xyzz28_to_std<C>(acc);
+    partials[t] = xyzz28_store<C>(acc);   // INTERNAL form: the bucket reduction stays on reduced-radix arithmetic
 }
 
 // ------------------------------------------------------------------------- bucket reduce
-// Window sum S_w = sum_b (b+1) * B_b, B_b = sum of the bucket's task partials.
-// Lane j of the window owns buckets [jK, jK+K):  sum (b+1) B_b = jK * A + sum_i (i+1) B_{jK+i},
-// the second term by the descending running-sum trick, A = run.  Workgroup tree-reduces in LDS.
+// Window sum S_w = sum_b (b+1) * B_b, B_b = sum of the bucket's task partials.  Lane j of the window
+// owns RED_K consecutive buckets [jK, jK+K):  sum (b+1) B_b = jK * A + sum_i (i+1) B_{jK+i}  with
+// A = running sum (descending), second term = sum of the running sums; jK * A by double-and-add
+// (jK < 2^c).  Everything on F28 registers; workgroup LDS tree, then k_sum_parts per window.
+// RED_K = 4 keeps the dependent chain short (8 adds + <= 15 doublings) and puts 8192 lanes on a window.
+constexpr unsigned RED_K = 4;
+
 template <class C>
-__global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off,
-                                                       XYZZ<C> *wsum, unsigned nbuckets, unsigned K,
-                                                       unsigned threads_per_window, unsigned blocks_per_window) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    XYZZ<C> *sh = (XYZZ<C> *)smem_raw;
-    const unsigned w = blockIdx.x / blocks_per_window, bw = blockIdx.x % blocks_per_window;
-    const unsigned j = bw * blockDim.x + threadIdx.x;
-    XYZZ<C> res = XYZZ<C>::identity();
-    if (j < threads_per_window) {
-        XYZZ<C> run = XYZZ<C>::identity(), acc = XYZZ<C>::identity();
-        const size_t gbase = (size_t)w * nbuckets + (size_t)j * K;
-        for (int i = (int)K - 1; i >= 0; --i) {
-            uint32_t t0 = task_off[gbase + i], t1 = task_off[gbase + i + 1];
-            for (uint32_t t = t0; t < t1; ++t) run = xyzz_add<C>(run, partials[t]);
-            acc = xyzz_add<C>(acc, run);
-        }
-        // acc += (j*K) * run   (double-and-add, j*K < 2^15)
-        uint32_t s = j * K;
-        XYZZ<C> m = XYZZ<C>::identity();
-        for (int b = 31 - __clz((int)(s | 1)); b >= 0; --b) {
-            m = xyzz_dbl<C>(m);
-            if ((s >> b) & 1) m = xyzz_add<C>(m, run);
-        }
-        res = s ? xyzz_add<C>(acc, m) : acc;
-    }
-    sh[threadIdx.x] = res;
+__device__ __forceinline__ XYZZ28<C> lds_tree_sum(XYZZ28<C> *sh, const XYZZ28<C> &mine) {
+    sh[threadIdx.x] = mine;
     __syncthreads();
     for (unsigned off = blockDim.x >> 1; off > 0; off >>= 1) {
-        if (threadIdx.x < off) sh[threadIdx.x] = xyzz_add<C>(sh[threadIdx.x], sh[threadIdx.x + off]);
+        if (threadIdx.x < off) {
+            XYZZ28<C> a = sh[threadIdx.x];
+            xyzz28_add_full<C>(a, sh[threadIdx.x + off]);
+            sh[threadIdx.x] = a;
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) wsum[blockIdx.x] = sh[0];
+    return sh[0];
 }
 
-// wsum[w * bpw + b] (b < bpw <= 64) -> one point per window, LDS tree in a 64-lane workgroup per window
 template <class C>
-__global__ __launch_bounds__(64) void k_window_sum(const XYZZ<C> *wsum, unsigned bpw, XYZZ<C> *out) {
-    __shared__ XYZZ<C> sh[64];
-    const unsigned w = blockIdx.x, t = threadIdx.x;
-    sh[t] = t < bpw ? wsum[w * bpw + t] : XYZZ<C>::identity();
-    __syncthreads();
-    for (unsigned off = 32; off > 0; off >>= 1) {
-        if (t < off && t + off < 64) sh[t] = xyzz_add<C>(sh[t], sh[t + off]);
-        __syncthreads();
+__global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, unsigned nbuckets,
+                                                       unsigned lanes_per_window, unsigned bpw, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    const unsigned w = blockIdx.x / bpw, bw = blockIdx.x % bpw;
+    const unsigned j = bw * blockDim.x + threadIdx.x;
+    XYZZ28<C> run, acc;
+    run.X = run.Y = run.ZZ = run.ZZZ = f28_zero<RR>();
+    acc = run;
+    if (j < lanes_per_window) {
+        const size_t gbase = (size_t)w * nbuckets + (size_t)j * RED_K;
+        for (int i = (int)RED_K - 1; i >= 0; --i) {
+            if ((size_t)j * RED_K + i >= nbuckets) continue;
+            for (uint32_t q = task_off[gbase + i]; q < task_off[gbase + i + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
+            xyzz28_add_full<C>(acc, run);
+        }
+        const uint32_t s = j * RED_K;          // acc += s * run
+        if (s) {
+            XYZZ28<C> m = run;
+            for (int b = 30 - __clz((int)s); b >= 0; --b) {
+                xyzz28_dbl<C>(m);
+                if ((s >> b) & 1) xyzz28_add_full<C>(m, run);
+            }
+            xyzz28_add_full<C>(acc, m);
+        }
     }
-    if (t == 0) out[w] = sh[0];
+    XYZZ28<C> tot = lds_tree_sum<C>(sh, acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(tot);
 }
 
-// Final combine S = sum_w 2^(c w) S_w (Horner, c doublings per window) and the inversion to affine:
-// O(W) point operations on W * blocks_per_window partial sums.  A single GPU lane needs ~9 ms for this
-// dependent chain (profiles/r01_a_*), the host 0.3 ms with the same templates, so it runs on the host.
+// out[w] = sum of parts[w * count .. + count)
 template <class C>
-static void host_finish(const XYZZ<C> *wsum, unsigned nwin, unsigned bpw, unsigned c, Affine<C> *out, int *inf) {
+__global__ __launch_bounds__(64) void k_sum_parts(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
+    __shared__ XYZZ28<C> sh[64];
+    typedef typename C::FqRR RR;
+    XYZZ28<C> acc;
+    acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
+    for (unsigned i = threadIdx.x; i < count; i += 64) xyzz28_add_full<C>(acc, xyzz28_load<C>(parts[(size_t)blockIdx.x * count + i]));
+    XYZZ28<C> tot = lds_tree_sum<C>(sh, acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(tot);
+}
+
+// Final combine on the host: S = sum_w 2^(c w) S_w by Horner (c doublings per window) and one inversion
+// to affine -- an O(W c) dependent chain on W points (9 ms on one GPU lane, ~0.3 ms here).
+template <class C>
+static void host_finish(const XYZZ<C> *S /*[nwin], internal form*/, unsigned nwin, unsigned c, Affine<C> *out, int *inf) {
     XYZZ<C> acc = XYZZ<C>::identity();
     for (int w = (int)nwin - 1; w >= 0; --w) {
         for (unsigned k = 0; k < c; ++k) acc = xyzz_dbl<C>(acc);
-        for (unsigned b = 0; b < bpw; ++b) acc = xyzz_add<C>(acc, wsum[w * bpw + b]);
+        acc = xyzz_add<C>(acc, xyzz_internal_to_std<C>(S[w]));
     }
     *inf = acc.is_identity() ? 1 : 0;
     *out = xyzz_to_affine<C>(acc);
@@ -359,9 +369,10 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
     PM_HIP(ctx, ws.task_off.reserve((G + 1) * 4));
     PM_HIP(ctx, ws.cursor.reserve(((G + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));  // scan tile totals
     PM_HIP(ctx, ws.partials.reserve(p.max_tasks * sizeof(XYZZ<C>)));
-    unsigned bpw = (p.red_threads + 255) / 256;
-    unsigned red_block = p.red_threads < 256 ? p.red_threads : 256;
-    if (red_block < 64) red_block = 64;
+    const unsigned red_lanes = (p.nbuckets + RED_K - 1) / RED_K;      // lanes per window
+    unsigned red_block = 64;
+    while (red_block < red_lanes && red_block < 256) red_block <<= 1;
+    const unsigned bpw = (red_lanes + red_block - 1) / red_block;
     PM_HIP(ctx, ws.wsum.reserve(((size_t)p.nwin * bpw + p.nwin) * sizeof(XYZZ<C>)));
     uint32_t *counts = ws.counts.as<uint32_t>(), *cursor = counts + G;
     {
@@ -400,20 +411,19 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
                            ws.partials.as<XYZZ<C>>(), G, p.seg);
         PM_HIP(ctx, hipGetLastError());
     }
+    std::vector<XYZZ<C>> hS(p.nwin);
     {
         StageTimer t(ctx, T_MSM_REDUCE);
-        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ<C>),
-                           ctx->stream, ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.wsum.as<XYZZ<C>>(),
-                           p.nbuckets, p.red_k, p.red_threads, bpw);
+        XYZZ<C> *parts = ws.wsum.as<XYZZ<C>>(), *dS = parts + (size_t)p.nwin * bpw;
+        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
+                           ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), p.nbuckets, red_lanes, bpw, parts);
         PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_sum_parts<C>, dim3(p.nwin), dim3(64), 0, ctx->stream, parts, bpw, dS);
+        PM_HIP(ctx, hipGetLastError());
+        PM_HIP(ctx, hipMemcpyAsync(hS.data(), dS, hS.size() * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
     }
-    XYZZ<C> *d_wfinal = ws.wsum.as<XYZZ<C>>() + (size_t)p.nwin * bpw;
-    hipLaunchKernelGGL(k_window_sum<C>, dim3(p.nwin), dim3(64), 0, ctx->stream, ws.wsum.as<XYZZ<C>>(), bpw, d_wfinal);
-    PM_HIP(ctx, hipGetLastError());
-    std::vector<XYZZ<C>> hw(p.nwin);
-    PM_HIP(ctx, hipMemcpyAsync(hw.data(), d_wfinal, hw.size() * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    host_finish<C>(hw.data(), p.nwin, 1, p.c, h_out, h_inf);
+    host_finish<C>(hS.data(), p.nwin, p.c, h_out, h_inf);
     return PM_OK;
 }
 

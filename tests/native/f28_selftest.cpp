@@ -91,6 +91,31 @@ static int run(const char *name, int iters) {
         }
     Affine<C> a1 = xyzz_to_affine<C>(dense), a2 = xyzz_to_affine<C>(xyzz28_to_std<C>(rr));
     if (!(a1.x.eq(a2.x) && a1.y.eq(a2.y))) { fails++; printf("%s madd chain mismatch\n", name); }
+    // 2b. full additions on F28 registers vs the dense add, through the internal-form memory records
+    {
+        XYZZ<C> dsum = XYZZ<C>::identity();
+        XYZZ28<C> rsum;
+        rsum.X = rsum.Y = rsum.ZZ = rsum.ZZZ = f28_zero<RR>();
+        for (int k = 0; k + 1 < NP; k += 2) {
+            XYZZ<C> pair = XYZZ<C>::from_affine(pts[k]);
+            xyzz_madd<C>(pair, pts[k + 1], (k & 2) != 0);
+            dsum = xyzz_add<C>(dsum, pair);
+            XYZZ<C> rec = xyzz_std_to_internal<C>(pair);                    // what a task partial looks like in memory
+            xyzz28_add_full<C>(rsum, xyzz28_load<C>(rec));
+            if (k == 10) { xyzz28_add_full<C>(rsum, xyzz28_load<C>(xyzz28_store<C>(rsum))); dsum = xyzz_add<C>(dsum, dsum); }   // a + a: exceptional
+        }
+        Affine<C> b1 = xyzz_to_affine<C>(dsum), b2 = xyzz_to_affine<C>(xyzz_internal_to_std<C>(xyzz28_store<C>(rsum)));
+        if (!(b1.x.eq(b2.x) && b1.y.eq(b2.y))) { fails++; printf("%s full-add chain mismatch\n", name); }
+    }
+    // 2c. doubling on F28 registers vs dense
+    {
+        XYZZ<C> d = XYZZ<C>::from_affine(pts[9]);
+        xyzz_madd<C>(d, pts[3], false);
+        XYZZ28<C> q = xyzz28_load<C>(xyzz_std_to_internal<C>(d));
+        for (int k = 0; k < 20; ++k) { d = xyzz_dbl<C>(d); xyzz28_dbl<C>(q); }
+        Affine<C> c1 = xyzz_to_affine<C>(d), c2 = xyzz_to_affine<C>(xyzz_internal_to_std<C>(xyzz28_store<C>(q)));
+        if (!(c1.x.eq(c2.x) && c1.y.eq(c2.y))) { fails++; printf("%s doubling chain mismatch\n", name); }
+    }
     // 3. P + (-P) and P + P through the exceptional path
     XYZZ28<C> e;
     e.X = e.Y = e.ZZ = e.ZZZ = f28_zero<RR>();
