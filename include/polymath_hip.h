@@ -103,6 +103,10 @@ int pm_msm_g1(pm_ctx *ctx, int curve, const void *bases, size_t base_stride, con
 int pm_bases_upload(pm_ctx *ctx, int curve, const void *bases, size_t base_stride, size_t len, pm_bases **out);
 /* Synthetic base vector P_i = (i+1)*G built on the device (SURVEY.md §8d MSM micro-inputs). */
 int pm_bases_generate_multiples(pm_ctx *ctx, int curve, size_t len, pm_bases **out);
+/* Build the window tables 2^(c w) * P_i of a resident base vector (W x its memory): later resident MSMs
+ * against it then need ceil(256/c) instead of 16 mixed additions per pair.  Proving keys do this
+ * themselves when the tables fit in HBM (PM_TABLES=0 in the environment disables it). */
+int pm_bases_precompute(pm_ctx *ctx, pm_bases *b);
 int pm_bases_download(pm_ctx *ctx, const pm_bases *b, size_t offset, size_t len, uint64_t *out_xy);
 size_t pm_bases_len(const pm_bases *b);
 void pm_bases_free(pm_bases *b);

@@ -45,7 +45,7 @@ class PolymathError(RuntimeError):
 EXPORTS = [
     "pm_device_count", "pm_ctx_create", "pm_ctx_destroy", "pm_last_error", "pm_last_timings", "pm_ntt",
     "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
-    "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
+    "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
     "pm_pk_info", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase2", "pm_prove_phase3",
     "pm_prove_tap",
 ]
@@ -76,6 +76,7 @@ def load_library():
     L.pm_bases_upload.argtypes = [vp, i, vp, sz, sz, ct.POINTER(vp)]
     L.pm_bases_generate_multiples.argtypes = [vp, i, sz, ct.POINTER(vp)]
     L.pm_bases_download.argtypes = [vp, vp, sz, sz, u64p]
+    L.pm_bases_precompute.argtypes = [vp, vp]
     L.pm_bases_len.argtypes = [vp]
     L.pm_bases_len.restype = sz
     L.pm_bases_free.argtypes = [vp]
@@ -193,6 +194,11 @@ class Bases:
         h = ct.c_void_p()
         ctx.check(ctx.L.pm_bases_generate_multiples(ctx.h, CURVE_IDS[curve], length, ct.byref(h)))
         return cls(ctx, curve, h)
+
+    def precompute(self):
+        """pm_bases_precompute: build the window tables (W x memory) for faster resident MSMs."""
+        self.ctx.check(self.ctx.L.pm_bases_precompute(self.ctx.h, self.h))
+        return self
 
     def __len__(self):
         return int(self.ctx.L.pm_bases_len(self.h))

@@ -3,6 +3,7 @@
 // removes row-duplicate R1CS entries the reference cannot see (m_at, common.rs:100-105), and
 // prepares the O(nnz) setup scalars.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -183,6 +184,31 @@ extern "C" int pm_bases_download(pm_ctx *ctx, const pm_bases *b, size_t offset, 
     return PM_DISPATCH(b->curve, download_points<BlsCurve>(ctx, src, len, out_xy), download_points<BnCurve>(ctx, src, len, out_xy));
 }
 
+template <class C>
+static int bases_precompute_impl(pm_ctx *ctx, pm_bases *b) {
+    if (b->tables.c || !b->len) return PM_OK;
+    MsmTables tb = tables_plan(b->len, 1, b->len, (unsigned)C::FrP::BITS);
+    if (!tb.c) return PM_OK;
+    void *d_new = nullptr;
+    PM_HIP(ctx, hipMalloc(&d_new, b->len * tb.nwin * sizeof(Affine<C>)));
+    PM_HIP(ctx, hipMemcpyAsync(d_new, b->d_points, b->len * sizeof(Affine<C>), hipMemcpyDeviceToDevice, ctx->stream));
+    int st = tables_build<C>(ctx, (Affine<C> *)d_new, b->len, tb);
+    if (st != PM_OK) {
+        (void)hipFree(d_new);
+        return st;
+    }
+    PM_HIP(ctx, hipFree(b->d_points));
+    b->d_points = d_new;
+    b->tables = tb;
+    return PM_OK;
+}
+
+extern "C" int pm_bases_precompute(pm_ctx *ctx, pm_bases *b) {
+    if (!ctx || !b) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(b->curve, bases_precompute_impl<BlsCurve>(ctx, b), bases_precompute_impl<BnCurve>(ctx, b));
+}
+
 extern "C" size_t pm_bases_len(const pm_bases *b) { return b ? b->len : 0; }
 
 extern "C" void pm_bases_free(pm_bases *b) {
@@ -205,7 +231,13 @@ static int msm_resident_impl(pm_ctx *ctx, const pm_bases *bases, size_t off, con
     Affine<C> r;
     int inf = 1;
     timing_reset(ctx);
-    PM_TRY(msm_run<C>(ctx, (const Affine<C> *)bases->d_points + off, d_sc, len, &r, &inf));
+    if (bases->tables.c) {
+        MsmTables tb = bases->tables;
+        tb.base_index = off;
+        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)bases->d_points, d_sc, len, &r, &inf, &tb));
+    } else {
+        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)bases->d_points + off, d_sc, len, &r, &inf));
+    }
     timing_flush(ctx);
     if (inf) memset(out_xy, 0, sizeof(Affine<C>));
     else memcpy(out_xy, &r, sizeof(Affine<C>));
@@ -386,15 +418,37 @@ static int for_cat_range(const pm_pk *pk, uint64_t lo, uint64_t hi, Affine<C> *d
     return PM_OK;
 }
 
+static bool tables_disabled_by_env() {
+    const char *e = getenv("PM_TABLES");
+    return e && e[0] == '0';
+}
+
+// Allocates the resident base array (plus its window tables when they fit: sized for 288 GB of HBM),
+// fills window 0 through `fill`, then builds windows 1..W-1 on the device.
 template <class C, class F>
 static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
-    uint64_t resident = pk_resident_points(pk);
-    PM_HIP(ctx, hipMalloc(&pk->d_bases, resident * sizeof(Affine<C>)));
+    const uint64_t resident = pk_resident_points(pk);
+    uint64_t total_pairs = 0;
+    for (int k = 0; k < 3; ++k) total_pairs += pk->res_hi[k] - pk->res_lo[k];
+    MsmTables tb = tables_plan((size_t)total_pairs, 3, (size_t)resident, (unsigned)C::FrP::BITS);
+    size_t free_b = 0, total_b = 0;
+    PM_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    // leave room for the per-proof vectors and the MSM workspace (~ 40 B per table entry of the longest MSM)
+    const double need = (double)resident * tb.nwin * sizeof(Affine<C>) + 48.0 * tb.nwin * (double)(pk->res_hi[2] - pk->res_lo[2]) +
+                        64.0 * 40.0 * (double)pk->n;
+    if (tables_disabled_by_env() || !tb.c || need > 0.9 * (double)free_b) tb = MsmTables();
+    const uint64_t windows = tb.c ? tb.nwin : 1;
+    PM_HIP(ctx, hipMalloc(&pk->d_bases, resident * windows * sizeof(Affine<C>)));
     Affine<C> *d = (Affine<C> *)pk->d_bases;
-    if (pk->shard_count == 1) return for_cat_range<C>(pk, 0, pk->total_points, d, fill);
-    for (int k = 0; k < 3; ++k)
-        PM_TRY(for_cat_range<C>(pk, pk->msm_lo[k] + pk->res_lo[k], pk->msm_lo[k] + pk->res_hi[k], d + pk->res_dev_off[k], fill));
-    return PM_OK;
+    if (pk->shard_count == 1) {
+        PM_TRY(for_cat_range<C>(pk, 0, pk->total_points, d, fill));
+    } else {
+        for (int k = 0; k < 3; ++k)
+            PM_TRY(for_cat_range<C>(pk, pk->msm_lo[k] + pk->res_lo[k], pk->msm_lo[k] + pk->res_hi[k], d + pk->res_dev_off[k], fill));
+    }
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pk->tables = tb;
+    return tables_build<C>(ctx, d, (size_t)resident, tb);
 }
 
 template <class C>

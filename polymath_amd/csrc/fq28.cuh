@@ -357,6 +357,30 @@ PM_HD_COLD XYZZ28<C> xyzz28_from_std(const XYZZ<C> &a) {
     return r;
 }
 
+// a^(p-2) for a T input (Fermat); cold: table construction only
+template <class RR>
+PM_HD_COLD F28<RR> f28_inverse(F28<RR> a) {
+    constexpr int N = RR::N;
+    uint32_t e[N];
+    uint32_t borrow = 2;
+    for (int i = 0; i < N; ++i) {
+        uint32_t v = RR::MOD[i] - borrow;
+        borrow = v >> 31;
+        e[i] = v & RR::MASK;
+    }
+    F28<RR> acc = f28_one<RR>();
+    bool started = false;
+    for (int i = N - 1; i >= 0; --i)
+        for (int b = RR::W - 1; b >= 0; --b) {
+            if (started) acc = f28_sqr<RR>(acc);
+            if ((e[i] >> b) & 1) {
+                acc = started ? f28_mul<RR>(acc, a) : a;
+                started = true;
+            }
+        }
+    return acc;
+}
+
 // ---- internal-form points in memory ---------------------------------------------------------------
 // Task partials and every intermediate of the bucket reduction stay in the INTERNAL Montgomery radix:
 // an XYZZ<C> record whose four coordinates are canonical (< p) dense words of the internal form.

@@ -75,7 +75,15 @@ enum TimingSlot {
 };
 
 struct MsmWorkspace {
-    DevBuf digits, sorted, counts, bucket_off, task_off, cursor, partials, wsum, result, canon;
+    DevBuf digits, sorted, counts, bucket_off, task_off, cursor, partials, wsum, result, canon, region;
+};
+
+// Window tables of a resident base vector (setup.hip: tables_build): point (w, i) = 2^(c w) P_i lives at
+// index w * stride + i of the table array.  c == 0: no tables (per-window Pippenger).
+struct MsmTables {
+    unsigned c = 0, nwin = 0;
+    size_t stride = 0;      // points per window
+    size_t base_index = 0;  // first point of this MSM inside window 0
 };
 
 struct TwiddleCache {
@@ -90,7 +98,8 @@ struct pm_bases {
     int curve;
     int device;
     size_t len;
-    void *d_points;  // Affine<C>[len]
+    void *d_points;  // Affine<C>[len], or the window tables [nwin][len] after pm_bases_precompute
+    pm::MsmTables tables;
 };
 
 struct pm_pk {
@@ -115,6 +124,7 @@ struct pm_pk {
     // stored at d_bases + res_dev_off[k]
     uint64_t res_lo[3], res_hi[3], res_dev_off[3];
     uint64_t msm_lo[3], msm_len[3];  // logical pair range of each merged MSM inside the concatenation
+    pm::MsmTables tables;            // window tables over ALL resident points (stride = resident point count)
 };
 
 struct PendingTimer {
@@ -144,9 +154,17 @@ namespace pm {
 template <class C>
 int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d_data, unsigned log_n, bool inverse);
 
+// tables == nullptr (or c == 0): d_bases points at the MSM's first base.  Otherwise d_bases is the start of
+// the table array and tables->base_index locates the MSM's first base inside window 0.
 template <class C>
 int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len,
-            Affine<C> *h_out, int *h_inf);
+            Affine<C> *h_out, int *h_inf, const MsmTables *tables = nullptr);
+
+// choose c and the number of windows for a key whose longest MSM has `max_len` pairs
+MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits);
+// fill windows 1..nwin-1 of a table array whose window 0 holds `count` internal-form affine points
+template <class C>
+int tables_build(pm_ctx *ctx, Affine<C> *d_table, size_t count, const MsmTables &t);
 
 template <class C>
 int bases_generate_multiples(pm_ctx *ctx, size_t len, Affine<C> *d_out);

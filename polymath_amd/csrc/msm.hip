@@ -293,7 +293,9 @@ __device__ __forceinline__ XYZZ28<C> lds_tree_sum(XYZZ28<C> *sh, const XYZZ28<C>
     return sh[0];
 }
 
-template <class C>
+// DIRECT = false: input bucket b = sum of its task partials, weight b + 1 (a Pippenger window).
+// DIRECT = true : input i = partials[w * nbuckets + i] itself, weight i (level-1 input of the table mode).
+template <class C, bool DIRECT>
 __global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, unsigned nbuckets,
                                                        unsigned lanes_per_window, unsigned bpw, XYZZ<C> *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -308,8 +310,13 @@ __global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, 
         const size_t gbase = (size_t)w * nbuckets + (size_t)j * RED_K;
         for (int i = (int)RED_K - 1; i >= 0; --i) {
             if ((size_t)j * RED_K + i >= nbuckets) continue;
-            for (uint32_t q = task_off[gbase + i]; q < task_off[gbase + i + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
-            xyzz28_add_full<C>(acc, run);
+            if (DIRECT) {
+                xyzz28_add_full<C>(run, xyzz28_load<C>(partials[gbase + i]));
+                if (i > 0) xyzz28_add_full<C>(acc, run);      // weight i (zero-based)
+            } else {
+                for (uint32_t q = task_off[gbase + i]; q < task_off[gbase + i + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
+                xyzz28_add_full<C>(acc, run);                 // weight i + 1
+            }
         }
         const uint32_t s = j * RED_K;          // acc += s * run
         if (s) {
@@ -335,6 +342,209 @@ __global__ __launch_bounds__(64) void k_sum_parts(const XYZZ<C> *parts, unsigned
     for (unsigned i = threadIdx.x; i < count; i += 64) xyzz28_add_full<C>(acc, xyzz28_load<C>(parts[(size_t)blockIdx.x * count + i]));
     XYZZ28<C> tot = lds_tree_sum<C>(sh, acc);
     if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(tot);
+}
+
+// =====================================================================================================
+// Table mode: the base vector is resident together with its window tables T_w[i] = 2^(c w) P_i
+// (setup.hip: tables_build), so every window's digits share ONE set of 2^(c-1) buckets: c = 22 gives
+// 12 mixed adds per pair instead of 16, no per-window reduction and no doublings.  2^21 buckets do not
+// fit the LDS histogram, so the counting sort has two levels: entries are first partitioned by the high
+// bucket bits into regions of 2^15 buckets (k_tbl_*), then each region is sorted by the LDS-staged
+// kernels (k_hist2 / k_scatter2) exactly like a Pippenger window.
+// =====================================================================================================
+constexpr unsigned LO_BITS = 15;
+constexpr unsigned TBL_PER_BLOCK = 1024;   // scalars per partition workgroup (4 per lane)
+constexpr unsigned RED_K0 = 16;            // level-0 fan-in of the table-mode bucket reduction
+
+// canonical scalars (zeroed when the base is the point at infinity): digits are then pure bit extraction
+template <class C>
+__global__ void k_canon(const Fp<typename C::FrP> *scalars, const Affine<C> *bases0, Fp<typename C::FrP> *canon, size_t len) {
+    typedef typename C::FrP P;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    Fp<P> k = from_mont<P>(scalars[i]);
+    const uint32_t *bx = (const uint32_t *)&bases0[i];
+    uint32_t any = 0;
+#pragma unroll
+    for (int t = 0; t < 2 * C::FqP::N; ++t) any |= bx[t];
+    canon[i] = any ? k : Fp<P>::zero();
+}
+
+// signed digit w of canonical scalar k: returns false for a zero digit; bucket = |d| - 1
+template <class P>
+__device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned w, unsigned c, uint32_t &carry, uint32_t &bucket, uint32_t &neg) {
+    const uint32_t half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+    unsigned lo = w * c, limb = lo >> 5, off = lo & 31;
+    uint32_t v = 0;
+    if (limb < (unsigned)P::N) {
+        uint64_t two = k.l[limb];
+        if (limb + 1 < (unsigned)P::N) two |= (uint64_t)k.l[limb + 1] << 32;
+        v = (uint32_t)(two >> off) & mask;
+    }
+    uint32_t d = v + carry;
+    if (d > half) {
+        uint32_t m = full - d;
+        carry = 1;
+        if (!m) return false;
+        bucket = m - 1;
+        neg = 1;
+        return true;
+    }
+    carry = 0;
+    if (!d) return false;
+    bucket = d - 1;
+    neg = 0;
+    return true;
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void k_tbl_count(const Fp<P> *canon, size_t len, unsigned c, unsigned nwin, unsigned regions,
+                                                   uint32_t *region_count) {
+    __shared__ uint32_t cnt[1024];
+    for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
+    __syncthreads();
+    for (unsigned q = 0; q < TBL_PER_BLOCK / 256; ++q) {
+        size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
+        if (i >= len) break;
+        Fp<P> k = canon[i];
+        uint32_t carry = 0, b, neg;
+        for (unsigned w = 0; w < nwin; ++w)
+            if (digit_at<P>(k, w, c, carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
+    }
+    __syncthreads();
+    for (unsigned r = threadIdx.x; r < regions; r += blockDim.x)
+        if (cnt[r]) atomicAdd(&region_count[r], cnt[r]);
+}
+
+// region_off = exclusive scan of region_count (regions <= 1024); also clears the claim cursors
+__global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *region_count, uint32_t *region_off, uint32_t *region_cursor,
+                                                         unsigned regions) {
+    __shared__ uint32_t s[1024];
+    const unsigned t = threadIdx.x;
+    uint32_t v = t < regions ? region_count[t] : 0u;
+    s[t] = v;
+    __syncthreads();
+    for (unsigned off = 1; off < 1024; off <<= 1) {
+        uint32_t a = t >= off ? s[t - off] : 0u;
+        __syncthreads();
+        s[t] += a;
+        __syncthreads();
+    }
+    if (t < regions) { region_off[t] = s[t] - v; region_cursor[t] = 0; }
+    if (t == 1023) region_off[regions] = s[1023];
+}
+
+// entry (i, w) -> region of its bucket: key = low LO_BITS of the bucket, val = table index << 1 | negate
+template <class P>
+__global__ __launch_bounds__(256) void k_tbl_partition(const Fp<P> *canon, size_t len, unsigned c, unsigned nwin, unsigned regions,
+                                                       const uint32_t *region_off, uint32_t *region_cursor, size_t tbl_stride,
+                                                       size_t base_index, uint16_t *keys, uint32_t *vals) {
+    __shared__ uint32_t cnt[1024], base[1024];
+    for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
+    __syncthreads();
+    for (unsigned q = 0; q < TBL_PER_BLOCK / 256; ++q) {
+        size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
+        if (i >= len) break;
+        Fp<P> k = canon[i];
+        uint32_t carry = 0, b, neg;
+        for (unsigned w = 0; w < nwin; ++w)
+            if (digit_at<P>(k, w, c, carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
+    }
+    __syncthreads();
+    for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) {
+        uint32_t v = cnt[r];
+        base[r] = v ? region_off[r] + atomicAdd(&region_cursor[r], v) : 0u;
+        cnt[r] = 0;
+    }
+    __syncthreads();
+    for (unsigned q = 0; q < TBL_PER_BLOCK / 256; ++q) {
+        size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
+        if (i >= len) break;
+        Fp<P> k = canon[i];
+        uint32_t carry = 0, b, neg;
+        for (unsigned w = 0; w < nwin; ++w)
+            if (digit_at<P>(k, w, c, carry, b, neg)) {
+                const unsigned r = b >> LO_BITS;
+                const uint32_t pos = base[r] + atomicAdd(&cnt[r], 1u);
+                keys[pos] = (uint16_t)(b & ((1u << LO_BITS) - 1));
+                vals[pos] = (uint32_t)(((size_t)w * tbl_stride + base_index + i) << 1) | neg;
+            }
+    }
+}
+
+// Level 2: workgroup `blockIdx.x` owns entries [x CH, (x+1) CH) of the region-partitioned array and
+// handles each region segment inside it with the LDS table (usually exactly one segment).
+template <bool SCATTER>
+__global__ __launch_bounds__(1024) void k_region_sort(const uint16_t *keys, const uint32_t *vals, const uint32_t *region_off,
+                                                      unsigned regions, unsigned lo_buckets, unsigned chunk, uint32_t *counts,
+                                                      const uint32_t *bucket_off, uint32_t *cursor, uint32_t *sorted) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *h = (uint32_t *)smem_raw;
+    const uint32_t total = region_off[regions];
+    const uint32_t lo = blockIdx.x * chunk;
+    if (lo >= total) return;
+    uint32_t hi = lo + chunk;
+    if (hi > total) hi = total;
+    // region containing `lo`: largest r with region_off[r] <= lo
+    unsigned ra = 0, rb = regions;
+    while (rb - ra > 1) {
+        unsigned mid = (ra + rb) >> 1;
+        if (region_off[mid] <= lo) ra = mid; else rb = mid;
+    }
+    for (unsigned r = ra; r < regions; ++r) {
+        const uint32_t s0 = region_off[r] > lo ? region_off[r] : lo;
+        const uint32_t s1 = region_off[r + 1] < hi ? region_off[r + 1] : hi;
+        if (s0 >= hi) break;
+        if (s0 >= s1) continue;
+        for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) h[b] = 0;
+        __syncthreads();
+        for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) atomicAdd(&h[keys[e]], 1u);
+        __syncthreads();
+        const size_t gbase = (size_t)r * lo_buckets;
+        if (!SCATTER) {
+            for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) {
+                uint32_t v = h[b];
+                if (v) atomicAdd(&counts[gbase + b], v);
+            }
+        } else {
+            for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) {
+                uint32_t v = h[b];
+                if (v) h[b] = bucket_off[gbase + b] + atomicAdd(&cursor[gbase + b], v);
+            }
+            __syncthreads();
+            for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) {
+                uint32_t pos = atomicAdd(&h[keys[e]], 1u);
+                sorted[pos] = vals[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Level 0 of the table-mode reduction: lane t owns buckets [t K0, t K0 + K0) (weights b + 1):
+//   A_t = sum B_b  -> outA[t];   acc_t = sum (b - t K0 + 1) B_b  -> LDS tree -> one partial per workgroup.
+// S = sum_t acc_t + K0 * sum_t t A_t; the second sum is k_bucket_reduce<DIRECT> on outA.
+template <class C>
+__global__ __launch_bounds__(256) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, size_t nbuckets, size_t lanes,
+                                                       XYZZ<C> *outA, XYZZ<C> *outAcc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    XYZZ28<C> run, acc;
+    run.X = run.Y = run.ZZ = run.ZZZ = f28_zero<RR>();
+    acc = run;
+    if (t < lanes) {
+        for (int j = (int)RED_K0 - 1; j >= 0; --j) {
+            const size_t g = t * RED_K0 + (size_t)j;
+            if (g >= nbuckets) continue;
+            for (uint32_t q = task_off[g]; q < task_off[g + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
+            xyzz28_add_full<C>(acc, run);
+        }
+        outA[t] = xyzz28_store<C>(run);
+    }
+    XYZZ28<C> tot = lds_tree_sum<C>(sh, acc);
+    if (threadIdx.x == 0) outAcc[blockIdx.x] = xyzz28_store<C>(tot);
 }
 
 // Final combine on the host: S = sum_w 2^(c w) S_w by Horner (c doublings per window) and one inversion
@@ -415,7 +625,7 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
     {
         StageTimer t(ctx, T_MSM_REDUCE);
         XYZZ<C> *parts = ws.wsum.as<XYZZ<C>>(), *dS = parts + (size_t)p.nwin * bpw;
-        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
+        hipLaunchKernelGGL((k_bucket_reduce<C, false>), dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
                            ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), p.nbuckets, red_lanes, bpw, parts);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_sum_parts<C>, dim3(p.nwin), dim3(64), 0, ctx->stream, parts, bpw, dS);
@@ -427,22 +637,152 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
     return PM_OK;
 }
 
+// ------------------------------------------------------------------------- table-mode driver
+template <class C>
+static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTables &tb, const Fp<typename C::FrP> *d_scalars,
+                            size_t len, Affine<C> *h_out, int *h_inf) {
+    typedef typename C::FrP FrP;
+    typedef Fp<FrP> Fr;
+    StageTimer t_total(ctx, T_MSM_TOTAL);
+    MsmWorkspace &ws = ctx->msm;
+    const unsigned c = tb.c, nwin = tb.nwin;
+    const size_t NB = (size_t)1 << (c - 1);
+    const unsigned lo_buckets = (unsigned)(NB < ((size_t)1 << LO_BITS) ? NB : ((size_t)1 << LO_BITS));
+    const unsigned regions = (unsigned)(NB / lo_buckets);
+    if (regions > 1024) return PM_ERR_INVALID_ARG;
+    const size_t Emax = (size_t)nwin * len;
+    size_t seg = 2 * (Emax / NB + 1);
+    if (seg < 64) seg = 64;
+    if (const char *e = getenv("PM_MSM_SEG")) seg = (size_t)atoi(e);
+    const size_t max_tasks = NB + Emax / seg + 1;
+    const unsigned chunk = 1u << 15;
+    const size_t keys_bytes = (Emax * 2 + 15) & ~(size_t)15;
+    PM_HIP(ctx, ws.canon.reserve(len * sizeof(Fr)));
+    PM_HIP(ctx, ws.digits.reserve(keys_bytes + Emax * 4));
+    PM_HIP(ctx, ws.sorted.reserve(Emax * 4));
+    PM_HIP(ctx, ws.counts.reserve(2 * NB * 4));
+    PM_HIP(ctx, ws.region.reserve((3 * (size_t)regions + 4) * 4));
+    PM_HIP(ctx, ws.bucket_off.reserve((NB + 1) * 4));
+    PM_HIP(ctx, ws.task_off.reserve((NB + 1) * 4));
+    PM_HIP(ctx, ws.cursor.reserve(((NB + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
+    PM_HIP(ctx, ws.partials.reserve(max_tasks * sizeof(XYZZ<C>)));
+    const bool two_level = NB >= 4096;
+    const size_t lanes0 = (NB + RED_K0 - 1) / RED_K0, blocks0 = (lanes0 + 255) / 256;
+    const size_t nb1 = two_level ? lanes0 : NB;                                   // inputs of k_bucket_reduce
+    const unsigned red_lanes = (unsigned)((nb1 + RED_K - 1) / RED_K);
+    unsigned red_block = 64;
+    while (red_block < red_lanes && red_block < 256) red_block <<= 1;
+    const unsigned bpw = (red_lanes + red_block - 1) / red_block;
+    PM_HIP(ctx, ws.wsum.reserve((lanes0 + blocks0 + bpw + 4) * sizeof(XYZZ<C>)));
+    Fr *canon = ws.canon.as<Fr>();
+    uint16_t *keys = (uint16_t *)ws.digits.p;
+    uint32_t *vals = (uint32_t *)((uint8_t *)ws.digits.p + keys_bytes);
+    uint32_t *counts = ws.counts.as<uint32_t>(), *cursor = counts + NB;
+    uint32_t *region_count = ws.region.as<uint32_t>(), *region_off = region_count + regions, *region_cursor = region_off + regions + 1;
+    {
+        StageTimer t(ctx, T_MSM_SORT);
+        PM_HIP(ctx, hipMemsetAsync(counts, 0, 2 * NB * 4, ctx->stream));
+        PM_HIP(ctx, hipMemsetAsync(region_count, 0, (size_t)regions * 4, ctx->stream));
+        hipLaunchKernelGGL(k_canon<C>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, d_scalars,
+                           d_table + tb.base_index, canon, len);
+        PM_HIP(ctx, hipGetLastError());
+        const unsigned pblocks = (unsigned)((len + TBL_PER_BLOCK - 1) / TBL_PER_BLOCK);
+        hipLaunchKernelGGL(k_tbl_count<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, c, nwin, regions, region_count);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, region_count, region_off, region_cursor, regions);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_tbl_partition<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, c, nwin, regions, region_off,
+                           region_cursor, tb.stride, tb.base_index, keys, vals);
+        PM_HIP(ctx, hipGetLastError());
+        const size_t lds = (size_t)lo_buckets * 4;
+        if (lds > 48 * 1024) {
+            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_region_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_region_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        const unsigned sblocks = (unsigned)((Emax + chunk - 1) / chunk);
+        hipLaunchKernelGGL(k_region_sort<false>, dim3(sblocks), dim3(1024), lds, ctx->stream, keys, vals, region_off, regions, lo_buckets,
+                           chunk, counts, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        PM_HIP(ctx, hipGetLastError());
+        const unsigned ntiles = (unsigned)((NB + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, counts, ws.bucket_off.as<uint32_t>(),
+                           ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB, (unsigned)seg);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, ws.cursor.as<uint32_t>(), ntiles,
+                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), NB);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, ctx->stream, ws.bucket_off.as<uint32_t>(),
+                           ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_region_sort<true>, dim3(sblocks), dim3(1024), lds, ctx->stream, keys, vals, region_off, regions, lo_buckets,
+                           chunk, counts, ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>());
+        PM_HIP(ctx, hipGetLastError());
+    }
+    {
+        StageTimer t(ctx, T_MSM_ACCUMULATE);
+        size_t blocks = (max_tasks + 127) / 128;
+        hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
+                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), d_table, ws.partials.as<XYZZ<C>>(), NB,
+                           (unsigned)seg);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    XYZZ<C> hres[2];
+    {
+        StageTimer t(ctx, T_MSM_REDUCE);
+        XYZZ<C> *A = ws.wsum.as<XYZZ<C>>(), *parts0 = A + lanes0, *parts1 = parts0 + blocks0, *dres = parts1 + bpw;
+        if (two_level) {
+            hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
+                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), NB, lanes0, A, parts0);
+            PM_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_sum_parts<C>, dim3(1), dim3(64), 0, ctx->stream, parts0, (unsigned)blocks0, dres);
+            PM_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL((k_bucket_reduce<C, true>), dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream, A,
+                               (const uint32_t *)nullptr, (unsigned)nb1, red_lanes, bpw, parts1);
+        } else {
+            hipLaunchKernelGGL((k_bucket_reduce<C, false>), dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
+                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), (unsigned)nb1, red_lanes, bpw, parts1);
+        }
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_sum_parts<C>, dim3(1), dim3(64), 0, ctx->stream, parts1, bpw, dres + 1);
+        PM_HIP(ctx, hipGetLastError());
+        PM_HIP(ctx, hipMemcpyAsync(hres, dres, sizeof(hres), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // S = P0 + K0 * S1  (two-level)  or  S = S1
+    XYZZ<C> acc = xyzz_internal_to_std<C>(hres[1]);
+    if (two_level) {
+        for (unsigned k = 1; k < RED_K0; k <<= 1) acc = xyzz_dbl<C>(acc);
+        acc = xyzz_add<C>(acc, xyzz_internal_to_std<C>(hres[0]));
+    }
+    *h_inf = acc.is_identity() ? 1 : 0;
+    *h_out = xyzz_to_affine<C>(acc);
+    return PM_OK;
+}
+
 template <class C>
 int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *h_out,
-            int *h_inf) {
+            int *h_inf, const MsmTables *tables) {
     if (len == 0) {
         *h_out = Affine<C>::infinity();
         *h_inf = 1;
         return PM_OK;
     }
-    if (len <= MSM_MAX_PIECE) return msm_piece<C>(ctx, d_bases, d_scalars, len, h_out, h_inf);
+    const bool tbl = tables && tables->c;
+    if (len <= MSM_MAX_PIECE)
+        return tbl ? msm_piece_tables<C>(ctx, d_bases, *tables, d_scalars, len, h_out, h_inf)
+                   : msm_piece<C>(ctx, d_bases, d_scalars, len, h_out, h_inf);
     // very long MSMs (the 10n-pair quotient commitment at n >= 2^24 on one GPU): pieces, summed on the host
     XYZZ<C> acc = XYZZ<C>::identity();
     for (size_t off = 0; off < len; off += MSM_MAX_PIECE) {
         size_t cnt = len - off < MSM_MAX_PIECE ? len - off : MSM_MAX_PIECE;
         Affine<C> part;
         int inf = 1;
-        PM_TRY(msm_piece<C>(ctx, d_bases + off, d_scalars + off, cnt, &part, &inf));
+        if (tbl) {
+            MsmTables tb = *tables;
+            tb.base_index += off;
+            PM_TRY(msm_piece_tables<C>(ctx, d_bases, tb, d_scalars + off, cnt, &part, &inf));
+        } else {
+            PM_TRY(msm_piece<C>(ctx, d_bases + off, d_scalars + off, cnt, &part, &inf));
+        }
         if (!inf) xyzz_madd<C>(acc, part, false);
     }
     *h_inf = acc.is_identity() ? 1 : 0;
@@ -450,7 +790,7 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
     return PM_OK;
 }
 
-template int msm_run<BlsCurve>(pm_ctx *, const Affine<BlsCurve> *, const Fp<BlsFrP> *, size_t, Affine<BlsCurve> *, int *);
-template int msm_run<BnCurve>(pm_ctx *, const Affine<BnCurve> *, const Fp<BnFrP> *, size_t, Affine<BnCurve> *, int *);
+template int msm_run<BlsCurve>(pm_ctx *, const Affine<BlsCurve> *, const Fp<BlsFrP> *, size_t, Affine<BlsCurve> *, int *, const MsmTables *);
+template int msm_run<BnCurve>(pm_ctx *, const Affine<BnCurve> *, const Fp<BnFrP> *, size_t, Affine<BnCurve> *, int *, const MsmTables *);
 
 }  // namespace pm

@@ -194,12 +194,88 @@ int bases_convert(pm_ctx *ctx, Affine<C> *d_points, size_t len, bool to_internal
     return PM_OK;
 }
 
+// ------------------------------------------------------------------------------ window tables
+// T_w[i] = 2^c T_{w-1}[i]: c doublings on F28 registers, then back to affine with a per-lane Montgomery
+// batch inversion over TB_BATCH points (all in the internal radix).
+constexpr int TB_BATCH = 8;
+
+template <class C>
+__global__ __launch_bounds__(128) void k_table_next(const Affine<C> *prev, Affine<C> *next, size_t count, unsigned c) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = t * TB_BATCH;
+    if (lo >= count) return;
+    size_t cnt = count - lo < (size_t)TB_BATCH ? count - lo : (size_t)TB_BATCH;
+    F zz[TB_BATCH], zzz[TB_BATCH], pre[TB_BATCH];
+    bool live[TB_BATCH];
+    F run = f28_one<RR>();
+    for (size_t i = 0; i < cnt; ++i) {
+        Affine<C> p = prev[lo + i];
+        live[i] = !p.is_inf();
+        pre[i] = run;
+        if (!live[i]) continue;
+        XYZZ28<C> a;
+        a.X = f28_unpack<RR>(p.x.l);
+        a.Y = f28_unpack<RR>(p.y.l);
+        a.ZZ = f28_one<RR>();
+        a.ZZZ = f28_one<RR>();
+        for (unsigned k = 0; k < c; ++k) xyzz28_dbl<C>(a);
+        XYZZ<C> rec = xyzz28_store<C>(a);          // canonical internal words
+        next[lo + i].x = rec.X;                     // parked until the inverses are known
+        next[lo + i].y = rec.Y;
+        zz[i] = a.ZZ;
+        zzz[i] = a.ZZZ;
+        run = f28_mul<RR>(run, a.ZZZ);
+    }
+    F inv = f28_inverse<RR>(run);
+    for (size_t ii = cnt; ii-- > 0;) {
+        if (!live[ii]) { next[lo + ii] = Affine<C>::infinity(); continue; }
+        F i3 = f28_mul<RR>(inv, pre[ii]);           // 1 / ZZZ
+        inv = f28_mul<RR>(inv, zzz[ii]);
+        F i2 = f28_sqr<RR>(f28_mul<RR>(i3, zz[ii]));  // 1 / ZZ
+        Affine<C> out;
+        f28_pack_reduced<RR>(f28_mul<RR>(f28_unpack<RR>(next[lo + ii].x.l), i2), out.x.l);
+        f28_pack_reduced<RR>(f28_mul<RR>(f28_unpack<RR>(next[lo + ii].y.l), i3), out.y.l);
+        next[lo + ii] = out;
+    }
+}
+
+template <class C>
+int tables_build(pm_ctx *ctx, Affine<C> *d_table, size_t count, const MsmTables &t) {
+    if (!t.c || !count) return PM_OK;
+    size_t lanes = (count + TB_BATCH - 1) / TB_BATCH;
+    for (unsigned w = 1; w < t.nwin; ++w) {
+        hipLaunchKernelGGL(k_table_next<C>, dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, ctx->stream,
+                           d_table + (size_t)(w - 1) * t.stride, d_table + (size_t)w * t.stride, count, t.c);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+// One c for the whole key: minimise  W(c) * (pairs of all MSMs) + n_msm * 3 * 2^(c-1)  (3 ~ mixed-add
+// equivalents the bucket reduction pays per bucket), subject to W * resident < 2^31 (u32 table indices).
+MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits) {
+    MsmTables t;
+    double best = 1e300;
+    for (unsigned c = 4; c <= 22; ++c) {
+        unsigned w = (scalar_bits + 1 + c - 1) / c;
+        if ((double)w * (double)resident_points >= 2147483648.0) continue;
+        double cost = (double)w * (double)total_pairs + (double)n_msm * 3.0 * (double)((size_t)1 << (c - 1));
+        if (cost < best) { best = cost; t.c = c; t.nwin = w; }
+    }
+    t.stride = resident_points;
+    return t;
+}
+
 #define PM_INST(C)                                                                                              \
     template int powers_fill<C>(pm_ctx *, Fp<typename C::FrP> *, size_t, const Fp<typename C::FrP> &,           \
                                 const Fp<typename C::FrP> &);                                                   \
     template int fixed_base_batch<C>(pm_ctx *, const Fp<typename C::FrP> *, size_t, Affine<C> *);               \
     template int bases_generate_multiples<C>(pm_ctx *, size_t, Affine<C> *);                                    \
-    template int bases_convert<C>(pm_ctx *, Affine<C> *, size_t, bool);
+    template int bases_convert<C>(pm_ctx *, Affine<C> *, size_t, bool);                                          \
+    template int tables_build<C>(pm_ctx *, Affine<C> *, size_t, const MsmTables &);
 PM_INST(BlsCurve)
 PM_INST(BnCurve)
 

@@ -82,6 +82,34 @@ def test_msm_vs_oracle_sizes(gpu_ctx, oracle, api, curve, n):
     assert oracle.g1_is_on_curve(curve, out)
 
 
+@pytest.mark.parametrize("curve", CURVE_LIST)
+@pytest.mark.parametrize("n", [1, 40, 5000, 1 << 16])
+def test_msm_window_tables_vs_oracle(gpu_ctx, oracle, api, curve, n):
+    """pm_bases_precompute: window tables 2^(c w) P_i, single bucket set, two-level counting sort --
+    same canonical result as the per-window path and as the CPU oracle (incl. offset sub-ranges)."""
+    bases = api.Bases.multiples(gpu_ctx, curve, n)
+    hb = bases.download()
+    sc = rand_fr_limbs(curve, n, 300 + n)
+    if n >= 40:
+        sc[3] = 0
+        sc[4] = oracle.fr_to_mont_limbs(curve, [1])[0]
+        sc[5] = oracle.fr_to_mont_limbs(curve, [CURVES[curve].r - 1])[0]
+    plain, _ = bases.msm(sc)
+    bases.precompute()
+    assert np.array_equal(bases.download(), hb)            # window 0 is still the base vector
+    tabled, inf = bases.msm(sc)
+    ref, rinf = oracle.msm(curve, hb, sc, 8)
+    assert inf == rinf and np.array_equal(tabled, ref) and np.array_equal(plain, ref)
+    if n >= 5000:
+        sub, _ = bases.msm(sc[100:3100], offset=777)
+        ref, _ = oracle.msm(curve, hb[777:777 + 3000], sc[100:3100], 8)
+        assert np.array_equal(sub, ref)
+        same = np.repeat(sc[7:8], n, axis=0)               # one hot bucket in every window
+        out, _ = bases.msm(same)
+        ref, _ = oracle.msm(curve, hb, same, 8)
+        assert np.array_equal(out, ref)
+
+
 def test_msm_arkworks_stride_with_infinity_byte(gpu_ctx, oracle):
     """G1Affine as arkworks lays it out: x || y || infinity: bool, stride 104."""
     curve, n = "bls12_381", 50
@@ -196,8 +224,11 @@ def _prove_both(api, gpu_ctx, oracle, curve, q, inst, wit, seed, compare_bases=T
 
 
 @pytest.mark.parametrize("curve", CURVE_LIST)
-def test_prove_synthetic_mid_size_vs_oracle(gpu_ctx, oracle, api, curve):
-    """SURVEY.md §8d synthetic R1CS, 3000 gates -> n = 8192, both curves."""
+@pytest.mark.parametrize("tables", ["1", "0"])
+def test_prove_synthetic_mid_size_vs_oracle(gpu_ctx, oracle, api, curve, tables, monkeypatch):
+    """SURVEY.md §8d synthetic R1CS, 3000 gates -> n = 8192, both curves; with the key's window tables
+    (default) and with PM_TABLES=0 (per-window Pippenger)."""
+    monkeypatch.setenv("PM_TABLES", tables)
     q, inst, wit = CI.synthetic_r1cs(CURVES[curve], 3000)
     _prove_both(api, gpu_ctx, oracle, curve, q, inst, wit, 77)
 

@@ -14,12 +14,17 @@ ap.add_argument("--log-len", type=int, default=22)
 ap.add_argument("--len", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--curve", default="bls12_381")
+ap.add_argument("--tables", action="store_true", help="pm_bases_precompute: window tables")
 a = ap.parse_args()
 n = a.len or (1 << a.log_len)
 ctx = api.Context(0)
 t0 = time.time()
 bases = api.Bases.multiples(ctx, a.curve, n)
 gen_s = time.time() - t0
+t0 = time.time()
+if a.tables:
+    bases.precompute()
+tbl_s = time.time() - t0
 g = torch.Generator(device="cuda").manual_seed(1234)
 sc = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device="cuda", generator=g) * 4 + torch.randint(0, 4, (n, 4), dtype=torch.int64, device="cuda", generator=g)
 sc[:, 3] &= (1 << 61) - 1          # < 2^253: a valid residue for both scalar fields
@@ -35,6 +40,6 @@ for rep in range(a.reps + 1):
         res.append((dt, tm))
 best = min(r[0] for r in res)
 tm = res[-1][1]
-print(json.dumps({"curve": a.curve, "len": n, "best_ms": best * 1e3, "pairs_per_sec": n / best, "gen_s": gen_s,
+print(json.dumps({"curve": a.curve, "len": n, "best_ms": best * 1e3, "pairs_per_sec": n / best, "gen_s": gen_s, "tables": a.tables, "tables_s": tbl_s,
                   "env": {k: v for k, v in os.environ.items() if k.startswith("PM_MSM")},
                   "stage_ms": {k: round(v, 3) for k, v in tm.items() if k.startswith("msm")}}))
