@@ -80,10 +80,15 @@ struct MsmWorkspace {
 
 // Window tables of a resident base vector (setup.hip: tables_build): point (w, i) = 2^(c w) P_i lives at
 // index w * stride + i of the table array.  c == 0: no tables (per-window Pippenger).
+// Windows are BALANCED: the 256 scalar bits (255 + signed-digit carry) are split into nwin windows of
+// width c or c - 1 (wider ones first), so no window is narrow -- with one shared bucket set a short top
+// window would pile all of its digits into a few hot buckets.
 struct MsmTables {
-    unsigned c = 0, nwin = 0;
-    size_t stride = 0;      // points per window
-    size_t base_index = 0;  // first point of this MSM inside window 0
+    unsigned c = 0, nwin = 0;        // c = widest window; buckets = 2^(c-1)
+    unsigned off[33] = {0};          // bit offset of window w (off[nwin] = 256)
+    unsigned char width[32] = {0};   // bits of window w
+    size_t stride = 0;               // points per window
+    size_t base_index = 0;           // first point of this MSM inside window 0
 };
 
 struct TwiddleCache {

@@ -296,7 +296,7 @@ __device__ __forceinline__ XYZZ28<C> lds_tree_sum(XYZZ28<C> *sh, const XYZZ28<C>
 // DIRECT = false: input bucket b = sum of its task partials, weight b + 1 (a Pippenger window).
 // DIRECT = true : input i = partials[w * nbuckets + i] itself, weight i (level-1 input of the table mode).
 template <class C, bool DIRECT>
-__global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, unsigned nbuckets,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, unsigned nbuckets,
                                                        unsigned lanes_per_window, unsigned bpw, XYZZ<C> *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_bucket_reduce(const XYZZ<C> *partials, 
 
 // out[w] = sum of parts[w * count .. + count)
 template <class C>
-__global__ __launch_bounds__(64) void k_sum_parts(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_sum_parts(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
     __shared__ XYZZ28<C> sh[64];
     typedef typename C::FqRR RR;
     XYZZ28<C> acc;
@@ -371,10 +371,16 @@ __global__ void k_canon(const Fp<typename C::FrP> *scalars, const Affine<C> *bas
 }
 
 // signed digit w of canonical scalar k: returns false for a zero digit; bucket = |d| - 1
+struct WinLayout {   // by-value kernel argument (MsmTables::off / width)
+    unsigned nwin;
+    unsigned short off[32];
+    unsigned char width[32];
+};
+
 template <class P>
-__device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned w, unsigned c, uint32_t &carry, uint32_t &bucket, uint32_t &neg) {
+__device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned lo, unsigned c, uint32_t &carry, uint32_t &bucket, uint32_t &neg) {
     const uint32_t half = 1u << (c - 1), full = 1u << c, mask = full - 1;
-    unsigned lo = w * c, limb = lo >> 5, off = lo & 31;
+    unsigned limb = lo >> 5, off = lo & 31;
     uint32_t v = 0;
     if (limb < (unsigned)P::N) {
         uint64_t two = k.l[limb];
@@ -398,7 +404,7 @@ __device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned w, unsigned c,
 }
 
 template <class P>
-__global__ __launch_bounds__(256) void k_tbl_count(const Fp<P> *canon, size_t len, unsigned c, unsigned nwin, unsigned regions,
+__global__ __launch_bounds__(256) void k_tbl_count(const Fp<P> *canon, size_t len, WinLayout L, unsigned regions,
                                                    uint32_t *region_count) {
     __shared__ uint32_t cnt[1024];
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
@@ -408,8 +414,8 @@ __global__ __launch_bounds__(256) void k_tbl_count(const Fp<P> *canon, size_t le
         if (i >= len) break;
         Fp<P> k = canon[i];
         uint32_t carry = 0, b, neg;
-        for (unsigned w = 0; w < nwin; ++w)
-            if (digit_at<P>(k, w, c, carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
+        for (unsigned w = 0; w < L.nwin; ++w)
+            if (digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
     }
     __syncthreads();
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x)
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *region_
 
 // entry (i, w) -> region of its bucket: key = low LO_BITS of the bucket, val = table index << 1 | negate
 template <class P>
-__global__ __launch_bounds__(256) void k_tbl_partition(const Fp<P> *canon, size_t len, unsigned c, unsigned nwin, unsigned regions,
+__global__ __launch_bounds__(256) void k_tbl_partition(const Fp<P> *canon, size_t len, WinLayout L, unsigned regions,
                                                        const uint32_t *region_off, uint32_t *region_cursor, size_t tbl_stride,
                                                        size_t base_index, uint16_t *keys, uint32_t *vals) {
     __shared__ uint32_t cnt[1024], base[1024];
@@ -447,8 +453,8 @@ __global__ __launch_bounds__(256) void k_tbl_partition(const Fp<P> *canon, size_
         if (i >= len) break;
         Fp<P> k = canon[i];
         uint32_t carry = 0, b, neg;
-        for (unsigned w = 0; w < nwin; ++w)
-            if (digit_at<P>(k, w, c, carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
+        for (unsigned w = 0; w < L.nwin; ++w)
+            if (digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
     }
     __syncthreads();
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) {
@@ -462,8 +468,8 @@ __global__ __launch_bounds__(256) void k_tbl_partition(const Fp<P> *canon, size_
         if (i >= len) break;
         Fp<P> k = canon[i];
         uint32_t carry = 0, b, neg;
-        for (unsigned w = 0; w < nwin; ++w)
-            if (digit_at<P>(k, w, c, carry, b, neg)) {
+        for (unsigned w = 0; w < L.nwin; ++w)
+            if (digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) {
                 const unsigned r = b >> LO_BITS;
                 const uint32_t pos = base[r] + atomicAdd(&cnt[r], 1u);
                 keys[pos] = (uint16_t)(b & ((1u << LO_BITS) - 1));
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(1024) void k_region_sort(const uint16_t *keys, cons
 //   A_t = sum B_b  -> outA[t];   acc_t = sum (b - t K0 + 1) B_b  -> LDS tree -> one partial per workgroup.
 // S = sum_t acc_t + K0 * sum_t t A_t; the second sum is k_bucket_reduce<DIRECT> on outA.
 template <class C>
-__global__ __launch_bounds__(256) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, size_t nbuckets, size_t lanes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, size_t nbuckets, size_t lanes,
                                                        XYZZ<C> *outA, XYZZ<C> *outAcc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
@@ -687,11 +693,14 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
                            d_table + tb.base_index, canon, len);
         PM_HIP(ctx, hipGetLastError());
         const unsigned pblocks = (unsigned)((len + TBL_PER_BLOCK - 1) / TBL_PER_BLOCK);
-        hipLaunchKernelGGL(k_tbl_count<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, c, nwin, regions, region_count);
+        WinLayout L;
+        L.nwin = nwin;
+        for (unsigned w = 0; w < 32; ++w) { L.off[w] = (unsigned short)(w < nwin ? tb.off[w] : 0); L.width[w] = w < nwin ? tb.width[w] : 0; }
+        hipLaunchKernelGGL(k_tbl_count<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, L, regions, region_count);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, region_count, region_off, region_cursor, regions);
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_tbl_partition<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, c, nwin, regions, region_off,
+        hipLaunchKernelGGL(k_tbl_partition<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, L, regions, region_off,
                            region_cursor, tb.stride, tb.base_index, keys, vals);
         PM_HIP(ctx, hipGetLastError());
         const size_t lds = (size_t)lo_buckets * 4;

@@ -4,6 +4,7 @@
 // kernel, then a batched fixed-base multiplication of the G1 generator with an 8-bit windowed table
 // (32 mixed adds per point) and a per-lane Montgomery batch inversion back to affine -- the layout
 // the MSM kernels gather from.
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.h"
@@ -245,28 +246,48 @@ template <class C>
 int tables_build(pm_ctx *ctx, Affine<C> *d_table, size_t count, const MsmTables &t) {
     if (!t.c || !count) return PM_OK;
     size_t lanes = (count + TB_BATCH - 1) / TB_BATCH;
-    for (unsigned w = 1; w < t.nwin; ++w) {
+    for (unsigned w = 1; w < t.nwin; ++w) {   // T_w = 2^(width of window w-1) * T_{w-1}
         hipLaunchKernelGGL(k_table_next<C>, dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, ctx->stream,
-                           d_table + (size_t)(w - 1) * t.stride, d_table + (size_t)w * t.stride, count, t.c);
+                           d_table + (size_t)(w - 1) * t.stride, d_table + (size_t)w * t.stride, count, (unsigned)t.width[w - 1]);
         PM_HIP(ctx, hipGetLastError());
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PM_OK;
 }
 
-// One c for the whole key: minimise  W(c) * (pairs of all MSMs) + n_msm * 3 * 2^(c-1)  (3 ~ mixed-add
+// One layout for the whole key: minimise  W * (pairs of all MSMs) + n_msm * 3 * 2^(c-1)  (3 ~ mixed-add
 // equivalents the bucket reduction pays per bucket), subject to W * resident < 2^31 (u32 table indices).
-MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits) {
-    MsmTables t;
-    double best = 1e300;
-    for (unsigned c = 4; c <= 22; ++c) {
-        unsigned w = (scalar_bits + 1 + c - 1) / c;
-        if ((double)w * (double)resident_points >= 2147483648.0) continue;
-        double cost = (double)w * (double)total_pairs + (double)n_msm * 3.0 * (double)((size_t)1 << (c - 1));
-        if (cost < best) { best = cost; t.c = c; t.nwin = w; }
+static void tables_layout(MsmTables &t, unsigned nwin) {
+    const unsigned total = 256, base = total / nwin, rem = total % nwin;
+    t.nwin = nwin;
+    unsigned off = 0;
+    for (unsigned w = 0; w < nwin; ++w) {
+        t.off[w] = off;
+        t.width[w] = (unsigned char)(base + (w < rem ? 1 : 0));
+        off += t.width[w];
     }
-    t.stride = resident_points;
-    return t;
+    t.off[nwin] = off;
+    t.c = base + (rem ? 1 : 0);
+}
+
+MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits) {
+    (void)scalar_bits;
+    MsmTables best_t;
+    double best = 1e300;
+    for (unsigned nwin = 10; nwin <= 32; ++nwin) {
+        MsmTables t;
+        tables_layout(t, nwin);
+        if (t.c < 4 || t.c > 23) continue;
+        if ((double)nwin * (double)resident_points >= 2147483648.0) continue;
+        double cost = (double)nwin * (double)total_pairs + (double)n_msm * 3.0 * (double)((size_t)1 << (t.c - 1));
+        if (cost < best) { best = cost; best_t = t; }
+    }
+    if (const char *e = getenv("PM_TABLE_C")) {   // developer knob for tuning sweeps: widest window
+        unsigned c = (unsigned)atoi(e);
+        if (c >= 4 && c <= 23) tables_layout(best_t, (256 + c - 1) / c);
+    }
+    best_t.stride = resident_points;
+    return best_t;
 }
 
 #define PM_INST(C)                                                                                              \
