@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--curve", default="bls12_381")
     ap.add_argument("--transcript", default="merlin")
-    ap.add_argument("--cpu-baseline-log", type=int, default=14)
+    ap.add_argument("--cpu-baseline-log", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
