@@ -12,6 +12,7 @@
 // kernels use (csrc/field.cuh compiles as plain C++).  Header-only; link with -lpolymath_hip.
 #pragma once
 #include <stdexcept>
+#include <type_traits>
 #include <string>
 #include <utility>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "../../include/polymath_hip.h"
 #include "../csrc/ec.cuh"
 #include "hashes.hpp"
+#include "pairing.hpp"
 
 namespace pmhost {
 
@@ -211,6 +213,15 @@ struct ProvingKey {   // device-resident ProvingKey (data_structures.rs:56-73) +
     ~ProvingKey() { if (h) pm_pk_free(h); }
 };
 
+// VerifyingKey (data_structures.rs:38-52) with PairingVK (:25-35).  BLS12-381 only: the reference
+// instantiates no other pairing engine (Cargo.toml:35).
+struct VerifyingKey {
+    G1Point<pm::BlsCurve> one_g1;
+    Bls12Pairing::G2 one_g2, x_g2, z_g2;
+    uint64_t n = 0, m0 = 0, sigma = 0;
+    pm::Fp<pm::BlsFrP> omega;
+};
+
 template <class C, class T>
 class Polymath {
 public:
@@ -271,6 +282,60 @@ public:
         if (st) throw PolymathError(3, st, "prove phase 3 failed: status " + std::to_string(st));   // prover.rs:221,222
         proof.d_g1.inf = di != 0;
         return proof;                                                                       // :231-236
+    }
+
+    // generator.rs:139-157: the verifying key of a proving key made from trapdoors (x, z)
+    template <class CC = C>
+    static typename std::enable_if<CC::ID == 0, VerifyingKey>::type make_vk(const ProvingKey<C> &pk, const Fr &x_trapdoor, const Fr &z_trapdoor) {
+        VerifyingKey vk;
+        for (int i = 0; i < C::FqP::N; ++i) { vk.one_g1.p.x.l[i] = C::GX_MONT[i]; vk.one_g1.p.y.l[i] = C::GY_MONT[i]; }
+        vk.one_g1.inf = false;
+        vk.one_g2 = Bls12Pairing::g2_generator();
+        Fr xc = pm::from_mont<typename C::FrP>(x_trapdoor), zc = pm::from_mont<typename C::FrP>(z_trapdoor);
+        vk.x_g2 = Bls12Pairing::g2_mul(vk.one_g2, xc.l, 8);
+        vk.z_g2 = Bls12Pairing::g2_mul(vk.one_g2, zc.l, 8);
+        vk.n = pk.n; vk.m0 = pk.m0; vk.sigma = pk.sigma; vk.omega = pk.omega;
+        return vk;
+    }
+
+    // verify (lib.rs:80-90) -> verify_proof (verifier.rs:19-62).  `public_inputs` WITHOUT the leading one (:26).
+    template <class CC = C>
+    static typename std::enable_if<CC::ID == 0, bool>::type verify(const VerifyingKey &vk, const std::vector<Fr> &public_inputs, const Proof<C> &proof) {
+        typedef pm::XYZZ<C> J;
+        T t("polymath");                                                                   // :24
+        std::vector<Fr> pub{Fr::one()};
+        pub.insert(pub.end(), public_inputs.begin(), public_inputs.end());                 // :26
+        Fr x1 = compute_x1(t, pub, proof.a_g1, proof.c_g1);                                // :29
+        Fr y1 = F::pow(x1, vk.sigma), y1_inv = F::inv(y1);                                 // :32
+        Fr y1_gamma = F::pow(y1_inv, MINUS_GAMMA);                                         // :34
+        ProvingKey<C> view;                                                                // n / omega carrier for compute_pi_at_x1
+        view.n = vk.n; view.omega = vk.omega;
+        Fr pi_at_x1 = compute_pi_at_x1(view, pub, x1, y1_gamma);                           // :35
+        Fr y1_alpha = F::pow(y1_inv, MINUS_ALPHA);                                         // :37
+        Fr c_at_x1 = F::mul(F::sub(F::mul(F::add(proof.a_at_x1, y1_gamma), proof.a_at_x1), pi_at_x1), F::inv(y1_alpha));   // :40
+        Fr x2 = compute_x2(t, x1, proof.a_at_x1, c_at_x1);                                 // :42
+        // commitments_minus_evals_in_g1 = a + x2 c - (a_at_x1 + x2 c_at_x1) [1]_1         :44-47
+        auto smul = [](const G1Point<C> &g, const Fr &k_mont) {
+            J acc = J::identity();
+            if (g.inf) return acc;
+            Fr k = pm::from_mont<typename C::FrP>(k_mont);
+            for (int i = 7; i >= 0; --i)
+                for (int b = 31; b >= 0; --b) {
+                    acc = pm::xyzz_dbl<C>(acc);
+                    if ((k.l[i] >> b) & 1) pm::xyzz_madd<C>(acc, g.p, false);
+                }
+            return acc;
+        };
+        J lhs = J::identity();
+        if (!proof.a_g1.inf) pm::xyzz_madd<C>(lhs, proof.a_g1.p, false);
+        lhs = pm::xyzz_add<C>(lhs, smul(proof.c_g1, x2));
+        lhs = pm::xyzz_add<C>(lhs, smul(vk.one_g1, F::neg(F::add(proof.a_at_x1, F::mul(x2, c_at_x1)))));
+        Fr x1c = pm::from_mont<typename C::FrP>(x1);
+        Bls12Pairing::G2 x_minus_x1 = Bls12Pairing::g2_add(vk.x_g2, Bls12Pairing::g2_neg(Bls12Pairing::g2_mul(vk.one_g2, x1c.l, 8)));   // :48
+        pm::Affine<C> lhs_aff = pm::xyzz_to_affine<C>(lhs), neg_d = proof.d_g1.p;
+        neg_d.y = pm::neg<typename C::FqP>(neg_d.y);                                        // proof.d_g1 * (-1)  :53
+        std::vector<Bls12Pairing::Pair> pairs{{lhs_aff, lhs.is_identity(), vk.z_g2}, {neg_d, proof.d_g1.inf, x_minus_x1}};
+        return Bls12Pairing::product_is_one(pairs);                                        // :50-61
     }
 
     // common.rs:21-30

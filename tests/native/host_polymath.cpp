@@ -74,6 +74,16 @@ static void run_dummy(Context &ctx, const char *tname, uint64_t seed) {
     ProvingKey<Curve> pk = pm.setup(c, x, z);
     Proof<Curve> proof = pm.prove(pk, c, r_a);
     printf("dummy %s n=%llu %s\n", tname, (unsigned long long)pk.n, to_hex(proof.to_bytes()).c_str());
+    // tests/dummy.rs:69-72: assert!(Polymath::verify(&vk, &[product], &proof))
+    VerifyingKey vk = Polymath<Curve, T>::make_vk(pk, x, z);
+    std::vector<Fr> pub{F::mul(a, b)};
+    bool ok = Polymath<Curve, T>::verify(vk, pub, proof);
+    Proof<Curve> bad = proof;
+    bad.a_at_x1 = F::add(bad.a_at_x1, Fr::one());
+    bool ok_bad = Polymath<Curve, T>::verify(vk, pub, bad);
+    pub[0] = F::add(pub[0], Fr::one());
+    bool ok_wrong_input = Polymath<Curve, T>::verify(vk, pub, proof);
+    printf("verify %s accept=%d tampered=%d wrong_input=%d\n", tname, ok, ok_bad, ok_wrong_input);
 }
 
 int main(int argc, char **argv) {
@@ -96,6 +106,13 @@ int main(int argc, char **argv) {
             Fr r_a[2] = {g.fr(), g.fr()};
             Proof<Curve> proof = pm.prove(pk, c, r_a);
             printf("mimc %d n=%llu %s\n", s, (unsigned long long)pk.n, to_hex(proof.to_bytes()).c_str());
+            if (s == 0) {   // tests/mimc.rs:214: assert!(Polymath::verify(&pvk, &[image], &proof))
+                ConstraintSystem<Curve> cs0;
+                c.generate_constraints(cs0);
+                VerifyingKey vk = Polymath<Curve, MerlinFieldTranscript<Curve>>::make_vk(pk, x, z);
+                std::vector<Fr> image{cs0.instance[1]};
+                printf("verify mimc accept=%d\n", (int)Polymath<Curve, MerlinFieldTranscript<Curve>>::verify(vk, image, proof));
+            }
         }
         // unsatisfied witness -> the reference's assert!(rem_poly.is_zero()) (prover.rs:108)
         ConstraintSystem<Curve> cs;

@@ -2,6 +2,7 @@
 #include <cstdio>
 #include "../../polymath_amd/host/hashes.hpp"
 #include "../../polymath_amd/csrc/field.cuh"
+#include "../../polymath_amd/host/pairing.hpp"
 using namespace pmhost;
 int main() {
     int fails = 0;
@@ -18,6 +19,32 @@ int main() {
     Bytes ch(32);
     m.challenge_bytes("challenge", ch.data(), 32);
     if (hex(ch) != "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615") { fails++; printf("merlin KAT %s\n", hex(ch).c_str()); }
+    {   // pairing: generators on their curves, bilinearity e(aP, bQ) e(-(ab)P, Q) == 1, and a negative
+        typedef Bls12Pairing B;
+        B::G2 g2 = B::g2_generator();
+        if (!B::g2_on_curve(g2)) { fails++; printf("G2 generator off curve\n"); }
+        pm::Affine<pm::BlsCurve> g1;
+        for (int i = 0; i < 12; ++i) { g1.x.l[i] = pm::BlsCurve::GX_MONT[i]; g1.y.l[i] = pm::BlsCurve::GY_MONT[i]; }
+        auto g1mul = [&](uint32_t k) {
+            pm::XYZZ<pm::BlsCurve> acc = pm::XYZZ<pm::BlsCurve>::identity();
+            for (int b = 31; b >= 0; --b) { acc = pm::xyzz_dbl<pm::BlsCurve>(acc); if ((k >> b) & 1) pm::xyzz_madd<pm::BlsCurve>(acc, g1, false); }
+            return pm::xyzz_to_affine<pm::BlsCurve>(acc);
+        };
+        uint32_t a = 0x1234567u, b = 0x89abcdu, ab_lo, ab_hi;
+        uint64_t ab = (uint64_t)a * b;
+        uint32_t kb[2] = {b, 0}, kab[2] = {(uint32_t)ab, (uint32_t)(ab >> 32)};
+        (void)ab_lo; (void)ab_hi;
+        pm::Affine<pm::BlsCurve> aP = g1mul(a);
+        B::G2 bQ = B::g2_mul(g2, kb, 1);
+        // -(ab) P via G2 side instead: e(aP, bQ) * e(-P, (ab) Q) == 1
+        pm::Affine<pm::BlsCurve> negP = g1;
+        negP.y = pm::neg<pm::BlsFqP>(negP.y);
+        B::G2 abQ = B::g2_mul(g2, kab, 2);
+        if (!B::product_is_one({{aP, false, bQ}, {negP, false, abQ}})) { fails++; printf("pairing bilinearity\n"); }
+        kab[0] += 1;
+        B::G2 wrong = B::g2_mul(g2, kab, 2);
+        if (B::product_is_one({{aP, false, bQ}, {negP, false, wrong}})) { fails++; printf("pairing false accept\n"); }
+    }
     printf("host selftest: %d failures\n", fails);
     return fails ? 1 : 0;
 }

@@ -36,7 +36,12 @@ def test_cpp_dummy_and_mimc_match_oracle(tmp_path, oracle):
     rounds, samples = 40, 2
     out = subprocess.run([_build(tmp_path, "host_polymath.cpp", link=True), str(rounds), str(samples)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    lines = out.stdout.strip().splitlines()
+    all_lines = out.stdout.strip().splitlines()
+    verdicts = [l for l in all_lines if l.startswith("verify")]
+    # Polymath::verify (verifier.rs:19-62) in C++ with its own pairing: accepts, rejects tampering / wrong inputs
+    assert verdicts == ["verify merlin accept=1 tampered=0 wrong_input=0", "verify keccak256 accept=1 tampered=0 wrong_input=0",
+                        "verify blake3 accept=1 tampered=0 wrong_input=0", "verify mimc accept=1"], verdicts
+    lines = [l for l in all_lines if not l.startswith("verify")]
     TR = T.make_transcripts(c)
     # tests/dummy.rs
     for line, (tname, seed) in zip(lines[:3], [("merlin", 101), ("keccak256", 102), ("blake3", 103)]):
