@@ -145,6 +145,10 @@ void pm_pk_free(pm_pk *pk);
  * On a sharded pk the outputs are this shard's PARTIAL sums; combine with pm_g1_sum. */
 int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
                     uint64_t *a_g1_xy, int *a_inf, uint64_t *c_g1_xy, int *c_inf);
+/* Same with the assignment ALREADY RESIDENT in HBM: d_x (m0 Fr) and d_w (mw Fr) are device pointers (e.g. the
+ * output of a GPU witness generator); r_a stays a host pointer (2 Fr). */
+int pm_prove_phase1_device(pm_ctx *ctx, const pm_pk *pk, const uint64_t *d_x, const uint64_t *d_w, const uint64_t *r_a,
+                           uint64_t *a_g1_xy, int *a_inf, uint64_t *c_g1_xy, int *c_inf);
 /* Phase 2 (prover.rs:132): u(x1), the only O(n) part of a_at_x1; the caller adds r_a(x1)*y1^alpha. */
 int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
 /* Phase 3 (prover.rs:142-229): assemble the Y^-gamma-scaled numerator, divide by (X - x1),

@@ -224,52 +224,83 @@ static inline unsigned get_bits(const u64 *k, unsigned lo, unsigned c) {
     return (unsigned)(v & ((1ull << c) - 1));
 }
 
+// One Pippenger window over a contiguous range: sum_b (b+1) * bucket_b for the window's signed digits.
 template <class C>
-static Jac<C> msm_serial(const uint8_t *bases, size_t stride, const u64 *scalars, size_t len) {
-    typedef typename C::Fr Fr;
-    if (len == 0) return Jac<C>::identity();
-    unsigned c = 3;
-    if (len >= 32) { c = 0; size_t t = len; while (t >>= 1) ++c; c = c > 4 ? c - 3 : 3; if (c > 16) c = 16; }
-    const unsigned nbits = 256, nwin = (nbits + c - 1) / c + 1;
-    std::vector<Fr> canon(len);
-    for (size_t i = 0; i < len; ++i) canon[i] = Fr::from_raw(scalars + 4 * i).from_mont();
-    std::vector<Jac<C>> buckets((size_t)1 << (c - 1));
-    std::vector<int> carry(len, 0);
-    std::vector<Jac<C>> wsum(nwin);
-    for (unsigned w = 0; w < nwin; ++w) {
-        for (auto &b : buckets) b = Jac<C>::identity();
-        for (size_t i = 0; i < len; ++i) {
-            int d = (int)get_bits(canon[i].l, w * c, c) + carry[i];
-            carry[i] = 0;
-            if (d > (1 << (c - 1))) { d -= (1 << c); carry[i] = 1; }
-            if (d == 0) continue;
-            Aff<C> p = load_affine<C>(bases + i * stride, stride);
-            if (p.inf) continue;
-            if (d < 0) { p.y = p.y.neg(); d = -d; }
-            buckets[d - 1] = buckets[d - 1].add_affine(p);
-        }
-        Jac<C> run = Jac<C>::identity(), acc = Jac<C>::identity();
-        for (size_t b = buckets.size(); b-- > 0;) { run = run.add(buckets[b]); acc = acc.add(run); }
-        wsum[w] = acc;
+static Jac<C> msm_window(const uint8_t *bases, size_t stride, const typename C::Fr *canon, const unsigned char *carry_in,
+                         size_t len, unsigned w, unsigned c) {
+    std::vector<Jac<C>> buckets((size_t)1 << (c - 1), Jac<C>::identity());
+    for (size_t i = 0; i < len; ++i) {
+        int d = (int)get_bits(canon[i].l, w * c, c) + (int)carry_in[i];
+        if (d > (1 << (c - 1))) d -= (1 << c);
+        if (d == 0) continue;
+        Aff<C> p = load_affine<C>(bases + i * stride, stride);
+        if (p.inf) continue;
+        if (d < 0) { p.y = p.y.neg(); d = -d; }
+        buckets[d - 1] = buckets[d - 1].add_affine(p);
     }
-    Jac<C> total = Jac<C>::identity();
-    for (unsigned w = nwin; w-- > 0;) {
-        for (unsigned k = 0; k < c; ++k) total = total.dbl();
-        total = total.add(wsum[w]);
-    }
-    return total;
+    Jac<C> run = Jac<C>::identity(), acc = Jac<C>::identity();
+    for (size_t b = buckets.size(); b-- > 0;) { run = run.add(buckets[b]); acc = acc.add(run); }
+    return acc;
 }
 
+// Parallel Pippenger: the pairs are cut into chunks, every (chunk, window) is an independent task pulled
+// from a shared counter (so 100+ host threads stay busy -- arkworks itself only parallelises over the
+// ~16 windows), then Horner per chunk and a sum over chunks.
 template <class C>
 static Jac<C> msm_parallel(const uint8_t *bases, size_t stride, const u64 *scalars, size_t len, int nthreads) {
+    typedef typename C::Fr Fr;
+    if (len == 0) return Jac<C>::identity();
     if (nthreads < 1) nthreads = 1;
-    if (len < 256) nthreads = 1;
-    std::vector<Jac<C>> part(nthreads, Jac<C>::identity());
-    parallel_for(len, nthreads, [&](size_t lo, size_t hi, int t) {
-        part[t] = msm_serial<C>(bases + lo * stride, stride, scalars + 4 * lo, hi - lo);
+    size_t nchunks = 1;
+    if (nthreads > 1 && len >= 4096) {
+        nchunks = (size_t)(nthreads + 15) / 16;                 // ~16 windows per chunk worth of tasks
+        while (nchunks > 1 && len / nchunks < 2048) --nchunks;
+    }
+    size_t chunk = (len + nchunks - 1) / nchunks;
+    unsigned c = 3;
+    if (chunk >= 32) { c = 0; size_t t = chunk; while (t >>= 1) ++c; c = c > 4 ? c - 3 : 3; if (c > 16) c = 16; }
+    const unsigned nwin = (256 + c - 1) / c + 1;
+    std::vector<Fr> canon(len);
+    std::vector<unsigned char> carries((size_t)nwin * len, 0);   // carry INTO window w of scalar i
+    parallel_for(len, nthreads, [&](size_t lo, size_t hi, int) {
+        for (size_t i = lo; i < hi; ++i) {
+            canon[i] = Fr::from_raw(scalars + 4 * i).from_mont();
+            unsigned carry = 0;
+            for (unsigned w = 0; w < nwin; ++w) {
+                carries[(size_t)w * len + i] = (unsigned char)carry;
+                int d = (int)get_bits(canon[i].l, w * c, c) + (int)carry;
+                carry = d > (1 << (c - 1)) ? 1 : 0;
+            }
+        }
     });
+    std::vector<Jac<C>> wsum(nchunks * nwin, Jac<C>::identity());
+    std::atomic<size_t> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            size_t t = next.fetch_add(1);
+            if (t >= nchunks * nwin) break;
+            size_t ch = t / nwin;
+            unsigned w = (unsigned)(t % nwin);
+            size_t lo = ch * chunk, hi = std::min(len, lo + chunk);
+            if (lo >= hi) continue;
+            wsum[t] = msm_window<C>(bases + lo * stride, stride, canon.data() + lo, carries.data() + (size_t)w * len + lo, hi - lo, w, c);
+        }
+    };
+    if (nthreads == 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+        for (auto &x : th) x.join();
+    }
     Jac<C> total = Jac<C>::identity();
-    for (auto &p : part) total = total.add(p);
+    for (size_t ch = 0; ch < nchunks; ++ch) {
+        Jac<C> acc = Jac<C>::identity();
+        for (unsigned w = nwin; w-- > 0;) {
+            for (unsigned k = 0; k < c; ++k) acc = acc.dbl();
+            acc = acc.add(wsum[ch * nwin + w]);
+        }
+        total = total.add(acc);
+    }
     return total;
 }
 

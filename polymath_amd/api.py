@@ -46,7 +46,7 @@ EXPORTS = [
     "pm_device_count", "pm_ctx_create", "pm_ctx_destroy", "pm_last_error", "pm_last_timings", "pm_ntt",
     "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
     "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
-    "pm_pk_info", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase2", "pm_prove_phase3",
+    "pm_pk_info", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3",
     "pm_prove_tap",
 ]
 
@@ -92,6 +92,7 @@ def load_library():
     L.pm_pk_free.argtypes = [vp]
     L.pm_pk_free.restype = None
     L.pm_prove_phase1.argtypes = [vp, vp, u64p, u64p, u64p, u64p, intp, u64p, intp]
+    L.pm_prove_phase1_device.argtypes = [vp, vp, vp, vp, u64p, u64p, intp, u64p, intp]
     L.pm_prove_phase2.argtypes = [vp, u64p, u64p]
     L.pm_prove_phase3.argtypes = [vp, u64p, u64p, u64p, u64p, u64p, intp]
     L.pm_prove_tap.argtypes = [vp, i, u64p, sz, ct.POINTER(sz)]
@@ -294,6 +295,15 @@ class ProvingKey:
         ai, ci = ct.c_int(0), ct.c_int(0)
         w = _c(w) if len(w) else np.zeros((1, 4), dtype=np.uint64)
         rc = self.ctx.L.pm_prove_phase1(self.ctx.h, self.h, _p(_c(x)), _p(w), _p(_c(r_a)), _p(a), ct.byref(ai), _p(c), ct.byref(ci))
+        return rc, a, ai.value, c, ci.value
+
+    def phase1_device(self, d_x, d_w, r_a):
+        """assignment already in HBM: d_x, d_w are device pointers (ints) to m0 / mw Montgomery Fr."""
+        a = np.zeros(2 * self.nq, dtype=np.uint64)
+        c = np.zeros(2 * self.nq, dtype=np.uint64)
+        ai, ci = ct.c_int(0), ct.c_int(0)
+        rc = self.ctx.L.pm_prove_phase1_device(self.ctx.h, self.h, ct.c_void_p(d_x), ct.c_void_p(d_w), _p(_c(r_a)), _p(a), ct.byref(ai),
+                                               _p(c), ct.byref(ci))
         return rc, a, ai.value, c, ci.value
 
     def phase2(self, x1):

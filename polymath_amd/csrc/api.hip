@@ -642,8 +642,17 @@ extern "C" int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, 
     if (!ctx || !pk || !x || !r_a || !a_g1_xy || !a_inf || !c_g1_xy || !c_inf || (pk->mw && !w)) return PM_ERR_INVALID_ARG;
     if (pk->device != ctx->device) return PM_ERR_INVALID_ARG;
     PM_TRY(set_device(ctx));
-    return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf),
-                       prove_phase1_impl<BnCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf));
+    return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false),
+                       prove_phase1_impl<BnCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false));
+}
+
+extern "C" int pm_prove_phase1_device(pm_ctx *ctx, const pm_pk *pk, const uint64_t *d_x, const uint64_t *d_w, const uint64_t *r_a,
+                                      uint64_t *a_g1_xy, int *a_inf, uint64_t *c_g1_xy, int *c_inf) {
+    if (!ctx || !pk || !d_x || !r_a || !a_g1_xy || !a_inf || !c_g1_xy || !c_inf || (pk->mw && !d_w)) return PM_ERR_INVALID_ARG;
+    if (pk->device != ctx->device) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true),
+                       prove_phase1_impl<BnCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true));
 }
 
 extern "C" int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1) {

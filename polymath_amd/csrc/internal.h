@@ -188,7 +188,7 @@ int powers_fill(pm_ctx *ctx, Fp<typename C::FrP> *d_out, size_t count, const Fp<
 
 template <class C>
 int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
-                      uint64_t *a_xy, int *a_inf, uint64_t *c_xy, int *c_inf);
+                      uint64_t *a_xy, int *a_inf, uint64_t *c_xy, int *c_inf, bool assignment_on_device);
 template <class C>
 int prove_phase2_impl(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
 template <class C>

@@ -330,7 +330,7 @@ static int msm_shard(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename 
 // ------------------------------------------------------------------------------- phase 1
 template <class C>
 int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
-                      uint64_t *a_xy, int *a_inf, uint64_t *c_xy, int *c_inf) {
+                      uint64_t *a_xy, int *a_inf, uint64_t *c_xy, int *c_inf, bool assignment_on_device) {
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
     const uint64_t n = pk->n, m0 = pk->m0, mw = pk->mw, nr = pk->nr;
@@ -358,8 +358,9 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     Fr *ra = ctx->ra.as<Fr>();
     unsigned *flags = ctx->flags.as<unsigned>();
     PM_HIP(ctx, hipMemsetAsync(flags, 0, 64, st));
-    PM_HIP(ctx, hipMemcpyAsync(xw, x, m0 * sizeof(Fr), hipMemcpyHostToDevice, st));
-    if (mw) PM_HIP(ctx, hipMemcpyAsync(xw + m0, w, mw * sizeof(Fr), hipMemcpyHostToDevice, st));
+    const hipMemcpyKind kind = assignment_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    PM_HIP(ctx, hipMemcpyAsync(xw, x, m0 * sizeof(Fr), kind, st));
+    if (mw) PM_HIP(ctx, hipMemcpyAsync(xw + m0, w, mw * sizeof(Fr), kind, st));
     PM_HIP(ctx, hipMemcpyAsync(ra, r_a, 2 * sizeof(Fr), hipMemcpyHostToDevice, st));
     {
         StageTimer t(ctx, T_WITNESS_MAP);
@@ -531,7 +532,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
 
 #define PM_INST(C)                                                                                                     \
     template int prove_phase1_impl<C>(pm_ctx *, const pm_pk *, const uint64_t *, const uint64_t *, const uint64_t *,   \
-                                      uint64_t *, int *, uint64_t *, int *);                                           \
+                                      uint64_t *, int *, uint64_t *, int *, bool);                                         \
     template int prove_phase2_impl<C>(pm_ctx *, const uint64_t *, uint64_t *);                                         \
     template int prove_phase3_impl<C>(pm_ctx *, const uint64_t *, const uint64_t *, const uint64_t *,                  \
                                       const uint64_t *, uint64_t *, int *);

@@ -199,9 +199,13 @@ class Polymath:
         w = f.fr_limbs(witness)
         return self.prove_limbs(pk, instance, x, w, r_a, combine)
 
-    def prove_limbs(self, pk, instance, x_limbs, w_limbs, r_a, combine=None):
+    def prove_limbs(self, pk, instance, x_limbs, w_limbs, r_a, combine=None, device_ptrs=None):
+        """device_ptrs = (d_x, d_w): the assignment is already resident in HBM (pm_prove_phase1_device)."""
         f, r = self.field, self.field.r
-        rc, a_xy, a_inf, c_xy, c_inf = pk.phase1(x_limbs, w_limbs, f.fr_limbs(r_a))
+        if device_ptrs is not None:
+            rc, a_xy, a_inf, c_xy, c_inf = pk.phase1_device(device_ptrs[0], device_ptrs[1], f.fr_limbs(r_a))
+        else:
+            rc, a_xy, a_inf, c_xy, c_inf = pk.phase1(x_limbs, w_limbs, f.fr_limbs(r_a))
         if rc:
             raise PolymathProverError(1, rc)
         if combine:

@@ -395,3 +395,32 @@ def test_full_size_2p20_proof_passes_pairing_verifier(oracle):
         pm.prove(pk, (r1cs, inst, wit2), r_a)
     assert (e.value.phase, e.value.status) == (1, 4)
     pk.free()
+
+
+def test_phase1_device_resident_assignment_equals_host(gpu_ctx, oracle, api):
+    """pm_prove_phase1_device (assignment already in HBM) == pm_prove_phase1 (host buffers).  Device buffers
+    come straight from the HIP runtime the library itself uses (no torch in this process)."""
+    import ctypes as ct
+    hip = ct.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ct.POINTER(ct.c_void_p), ct.c_size_t]
+    hip.hipMemcpy.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int]
+    hip.hipFree.argtypes = [ct.c_void_p]
+
+    def to_device(arr):
+        p = ct.c_void_p()
+        assert hip.hipMalloc(ct.byref(p), arr.nbytes) == 0
+        assert hip.hipMemcpy(p, arr.ctypes.data_as(ct.c_void_p), arr.nbytes, 1) == 0   # hipMemcpyHostToDevice
+        return p
+
+    curve = "bls12_381"
+    c = CURVES[curve]
+    q, inst, wit = CI.synthetic_r1cs(c, 300)
+    pk = _gpu_pk(api, gpu_ctx, curve, q, 1357, 2468, oracle)
+    x, w = oracle.fr_to_mont_limbs(curve, inst), oracle.fr_to_mont_limbs(curve, wit)
+    ra = oracle.fr_to_mont_limbs(curve, [11, 13])
+    rc, a, ai, cc, ci = pk.phase1(x, w, ra)
+    dx, dw = to_device(x), to_device(w)
+    rc2, a2, ai2, cc2, ci2 = pk.phase1_device(dx.value, dw.value, ra)
+    assert rc == rc2 == 0 and np.array_equal(a, a2) and np.array_equal(cc, cc2) and (ai, ci) == (ai2, ci2)
+    hip.hipFree(dx)
+    hip.hipFree(dw)
