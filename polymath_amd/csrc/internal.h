@@ -150,7 +150,7 @@ struct pm_ctx {
     // proof in flight
     const pm_pk *pk;
     int phase;
-    pm::DevBuf xw, ue, we, u, w, wit_u, u2, sc_a, sc_c, quotient, ztail, lvl[4], ra;
+    pm::DevBuf xw, ue, we, u, w, wit_u, u2, sc_a, sc_c, quotient, ztail, lvl[6], ra;
 };
 
 namespace pm {
@@ -158,6 +158,9 @@ namespace pm {
 // ---- per-curve entry points implemented in the .hip translation units -----------------------
 template <class C>
 int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d_data, unsigned log_n, bool inverse);
+// device table of omega_{2^log_n}^j (or its inverse), j < 2^(log_n - 1); cached per context
+template <class C>
+int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out);
 
 // tables == nullptr (or c == 0): d_bases points at the MSM's first base.  Otherwise d_bases is the start of
 // the table array and tables->base_index locates the MSM's first base inside window 0.

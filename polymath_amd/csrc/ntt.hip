@@ -96,7 +96,7 @@ __global__ void k_scale(Fp<P> *a, size_t n, Fp<P> s) {
 }
 
 template <class C>
-static int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out) {
+int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out) {
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
     const int cid = C::ID;
@@ -166,6 +166,8 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     return PM_OK;
 }
 
+template int twiddles_get<BlsCurve>(pm_ctx *, unsigned, bool, const Fp<BlsFrP> **);
+template int twiddles_get<BnCurve>(pm_ctx *, unsigned, bool, const Fp<BnFrP> **);
 template int ntt_run<BlsCurve>(pm_ctx *, Fp<BlsFrP> *, unsigned, bool);
 template int ntt_run<BnCurve>(pm_ctx *, Fp<BnFrP> *, unsigned, bool);
 

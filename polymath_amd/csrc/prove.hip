@@ -99,6 +99,24 @@ __global__ void k_pad_copy(const Fp<P> *src, Fp<P> *dst, uint64_t n_src, uint64_
     if (i < n_dst) dst[i] = i < n_src ? src[i] : Fp<P>::zero();
 }
 
+// u^2 without a size-2n transform.  Once (Uz)^2 == Wz holds on the domain (k_check_sap), u^2 = w  (mod X^n - 1),
+// i.e. lo + hi = w for u^2 = lo + X^n hi.  The negacyclic product neg = u^2 mod (X^n + 1) = lo - hi comes from ONE
+// size-n transform pair on the twisted input u_k psi^k (psi = omega_2n):  lo = (w + neg) / 2, hi = (w - neg) / 2.
+// Same coefficients as square_polynomial (prover.rs:315-328) at half the NTT work.
+template <class P>
+__global__ void k_twist(const Fp<P> *u, const Fp<P> *psi_pow, Fp<P> *out, uint64_t n) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = mul<P>(u[k], psi_pow[k]);
+}
+template <class P>
+__global__ void k_untwist_combine(const Fp<P> *neg_tw, const Fp<P> *psi_inv_pow, const Fp<P> *w, Fp<P> *u2, uint64_t n, Fp<P> half) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Fp<P> neg = mul<P>(neg_tw[k], psi_inv_pow[k]), wk = w[k];
+    u2[k] = mul<P>(add<P>(wk, neg), half);
+    u2[n + k] = mul<P>(sub<P>(wk, neg), half);
+}
+
 template <class P>
 __global__ void k_square(Fp<P> *a, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,13 +405,24 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     PM_TRY(ntt_run<C>(ctx, u, pk->log_n, true));
     PM_TRY(ntt_run<C>(ctx, wv, pk->log_n, true));
     PM_TRY(ntt_run<C>(ctx, wit_u, pk->log_n, true));
-    // square_polynomial (prover.rs:315-328): N3, pointwise square, N4
-    hipLaunchKernelGGL(k_pad_copy<P>, dim3(nblk(2 * n)), dim3(256), 0, st, u, u2, n, 2 * n);
-    PM_HIP(ctx, hipGetLastError());
-    PM_TRY(ntt_run<C>(ctx, u2, pk->log_n + 1, false));
-    hipLaunchKernelGGL(k_square<P>, dim3(nblk(2 * n)), dim3(256), 0, st, u2, 2 * n);
-    PM_HIP(ctx, hipGetLastError());
-    PM_TRY(ntt_run<C>(ctx, u2, pk->log_n + 1, true));
+    // square_polynomial (prover.rs:315-328) via the negacyclic half (see k_twist); the 2n-point domain of
+    // the reference must still exist (checked above), its root psi = omega_2n is the twist.
+    {
+        const Fr *psi = nullptr, *psi_inv = nullptr;
+        PM_TRY(twiddles_get<C>(ctx, pk->log_n + 1, false, &psi));
+        PM_TRY(twiddles_get<C>(ctx, pk->log_n + 1, true, &psi_inv));
+        PM_HIP(ctx, ctx->scratch.reserve(n * sizeof(Fr)));
+        Fr *tmp = ctx->scratch.as<Fr>();
+        hipLaunchKernelGGL(k_twist<P>, dim3(nblk(n)), dim3(256), 0, st, u, psi, tmp, n);
+        PM_HIP(ctx, hipGetLastError());
+        PM_TRY(ntt_run<C>(ctx, tmp, pk->log_n, false));
+        hipLaunchKernelGGL(k_square<P>, dim3(nblk(n)), dim3(256), 0, st, tmp, n);
+        PM_HIP(ctx, hipGetLastError());
+        PM_TRY(ntt_run<C>(ctx, tmp, pk->log_n, true));
+        Fr half = inverse<P>(from_u64<P>(2));
+        hipLaunchKernelGGL(k_untwist_combine<P>, dim3(nblk(n)), dim3(256), 0, st, tmp, psi_inv, wv, u2, n, half);
+        PM_HIP(ctx, hipGetLastError());
+    }
     {
         StageTimer t(ctx, T_POLY);
         hipLaunchKernelGGL(k_phase1_scalars<P>, dim3(nblk(n + 1)), dim3(256), 0, st, u, u2, ra, sc_c + Lz, sc_a, n, flags);
@@ -467,15 +496,15 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     nc.minus_const = neg<P>(add<P>(a_at, mul<P>(x2, c_at)));
     // levels of the chunked recurrence
     const unsigned L = 32;
-    uint64_t cnt[6];
+    uint64_t cnt[8];
     cnt[0] = np.len;
     int levels = 0;
-    while (cnt[levels] > 4096 && levels < 4) {
+    while (cnt[levels] > 64 && levels < 5) {   // the top level is one lane: keep it to <= 64 values
         cnt[levels + 1] = (cnt[levels] + L - 1) / L;
         ++levels;
     }
     // buffers: V[l] (values of level l, l >= 1) and H[l] (suffix values of level l, l >= 1)
-    Fr *V[6] = {nullptr}, *H[6] = {nullptr};
+    Fr *V[8] = {nullptr}, *H[8] = {nullptr};
     for (int l = 1; l <= levels; ++l) {
         PM_HIP(ctx, ctx->lvl[l - 1].reserve((2 * cnt[l] + 2) * sizeof(Fr)));
         V[l] = ctx->lvl[l - 1].as<Fr>();
@@ -488,7 +517,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     {
         StageTimer t(ctx, T_POLY);
         PM_HIP(ctx, hipMemsetAsync(flags, 0, 64, st));
-        Fr xp[6];
+        Fr xp[8];
         xp[0] = x1;
         for (int l = 1; l <= levels; ++l) xp[l] = pow_u64<P>(xp[l - 1], L);
         if (levels == 0) {
