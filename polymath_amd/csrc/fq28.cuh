@@ -465,6 +465,39 @@ PM_HD void xyzz28_dbl(XYZZ28<C> &a) {
     a.Y = Y3;
 }
 
+template <class C>
+PM_HD_COLD XYZZ28<C> xyzz28_add_exceptional(XYZZ28<C> a, XYZZ28<C> b);
+
+// mem += a, where `mem` lives in LDS (or any memory) and is streamed coordinate by coordinate, `a` stays
+// intact in registers.  Same formulas and invariants as xyzz28_add; only ~one operand plus the temporaries are
+// live at a time, which is what lets the bucket-reduction kernels run two waves per SIMD.
+template <class C>
+PM_HD bool xyzz28_add_into(XYZZ28<C> *mem, const XYZZ28<C> &a) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(a.ZZ)) return true;
+    if (f28_all_zero<RR>(mem->ZZ)) { *mem = a; return true; }
+    const F U1 = f28_mul<RR>(a.X, mem->ZZ), U2 = f28_mul<RR>(mem->X, a.ZZ);
+    const F S1 = f28_mul<RR>(a.Y, mem->ZZZ), S2 = f28_mul<RR>(mem->Y, a.ZZZ);
+    const F P = f28_sub_k4<RR>(U2, U1), R = f28_sub_k4<RR>(S2, S1);
+    const F PP = f28_sqr<RR>(P);
+    if (f28_is_zero_mod_p<RR>(PP)) return false;
+    const F PPP = f28_mul<RR>(P, PP), Q = f28_mul<RR>(U1, PP), RR2 = f28_sqr<RR>(R);
+    F X3 = f28_sub_k4<RR>(RR2, PPP);
+    X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(X3, f28_add<RR>(Q, Q)));
+    const F QX = f28_sub_k16<RR>(Q, X3);
+    const F Y3 = f28_mul2_add<RR>(R, QX, S1, f28_sub_k4<RR>(f28_zero<RR>(), PPP));
+    mem->X = X3;
+    mem->Y = Y3;
+    mem->ZZ = f28_mul<RR>(f28_mul<RR>(a.ZZ, mem->ZZ), PP);
+    mem->ZZZ = f28_mul<RR>(f28_mul<RR>(a.ZZZ, mem->ZZZ), PPP);
+    return true;
+}
+template <class C>
+PM_HD void xyzz28_add_into_full(XYZZ28<C> *mem, const XYZZ28<C> &a) {
+    if (!xyzz28_add_into<C>(mem, a)) *mem = xyzz28_add_exceptional<C>(*mem, a);
+}
+
 // exceptional case of xyzz28_add, complete dense formulas (cold)
 template <class C>
 PM_HD_COLD XYZZ28<C> xyzz28_add_exceptional(XYZZ28<C> a, XYZZ28<C> b) {

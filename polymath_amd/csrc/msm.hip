@@ -278,44 +278,43 @@ __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, cons
 // RED_K = 4 keeps the dependent chain short (8 adds + <= 15 doublings) and puts 8192 lanes on a window.
 constexpr unsigned RED_K = 4;
 
+// sh[threadIdx.x] holds each lane's value on entry; on exit sh[0] holds the workgroup sum
 template <class C>
-__device__ __forceinline__ XYZZ28<C> lds_tree_sum(XYZZ28<C> *sh, const XYZZ28<C> &mine) {
-    sh[threadIdx.x] = mine;
+__device__ __forceinline__ void lds_tree_sum(XYZZ28<C> *sh) {
     __syncthreads();
     for (unsigned off = blockDim.x >> 1; off > 0; off >>= 1) {
         if (threadIdx.x < off) {
-            XYZZ28<C> a = sh[threadIdx.x];
-            xyzz28_add_full<C>(a, sh[threadIdx.x + off]);
-            sh[threadIdx.x] = a;
+            const XYZZ28<C> b = sh[threadIdx.x + off];
+            xyzz28_add_into_full<C>(&sh[threadIdx.x], b);
         }
         __syncthreads();
     }
-    return sh[0];
 }
 
 // DIRECT = false: input bucket b = sum of its task partials, weight b + 1 (a Pippenger window).
 // DIRECT = true : input i = partials[w * nbuckets + i] itself, weight i (level-1 input of the table mode).
 template <class C, bool DIRECT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, unsigned nbuckets,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, unsigned nbuckets,
                                                        unsigned lanes_per_window, unsigned bpw, XYZZ<C> *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
     typedef typename C::FqRR RR;
     const unsigned w = blockIdx.x / bpw, bw = blockIdx.x % bpw;
     const unsigned j = bw * blockDim.x + threadIdx.x;
-    XYZZ28<C> run, acc;
+    XYZZ28<C> run;
     run.X = run.Y = run.ZZ = run.ZZZ = f28_zero<RR>();
-    acc = run;
+    XYZZ28<C> *acc = &sh[threadIdx.x];     // the weighted accumulator lives in LDS (register pressure)
+    *acc = run;
     if (j < lanes_per_window) {
         const size_t gbase = (size_t)w * nbuckets + (size_t)j * RED_K;
         for (int i = (int)RED_K - 1; i >= 0; --i) {
             if ((size_t)j * RED_K + i >= nbuckets) continue;
             if (DIRECT) {
                 xyzz28_add_full<C>(run, xyzz28_load<C>(partials[gbase + i]));
-                if (i > 0) xyzz28_add_full<C>(acc, run);      // weight i (zero-based)
+                if (i > 0) xyzz28_add_into_full<C>(acc, run);      // weight i (zero-based)
             } else {
                 for (uint32_t q = task_off[gbase + i]; q < task_off[gbase + i + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
-                xyzz28_add_full<C>(acc, run);                 // weight i + 1
+                xyzz28_add_into_full<C>(acc, run);                 // weight i + 1
             }
         }
         const uint32_t s = j * RED_K;          // acc += s * run
@@ -325,23 +324,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 xyzz28_dbl<C>(m);
                 if ((s >> b) & 1) xyzz28_add_full<C>(m, run);
             }
-            xyzz28_add_full<C>(acc, m);
+            xyzz28_add_into_full<C>(acc, m);
         }
     }
-    XYZZ28<C> tot = lds_tree_sum<C>(sh, acc);
-    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(tot);
+    lds_tree_sum<C>(sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
 }
 
 // out[w] = sum of parts[w * count .. + count)
 template <class C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_sum_parts(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sum_parts(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
     __shared__ XYZZ28<C> sh[64];
     typedef typename C::FqRR RR;
-    XYZZ28<C> acc;
-    acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
-    for (unsigned i = threadIdx.x; i < count; i += 64) xyzz28_add_full<C>(acc, xyzz28_load<C>(parts[(size_t)blockIdx.x * count + i]));
-    XYZZ28<C> tot = lds_tree_sum<C>(sh, acc);
-    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(tot);
+    XYZZ28<C> *acc = &sh[threadIdx.x];
+    acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
+    for (unsigned i = threadIdx.x; i < count; i += 64) xyzz28_add_into_full<C>(acc, xyzz28_load<C>(parts[(size_t)blockIdx.x * count + i]));
+    lds_tree_sum<C>(sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
 }
 
 // =====================================================================================================
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 // kernels (k_hist2 / k_scatter2) exactly like a Pippenger window.
 // =====================================================================================================
 constexpr unsigned LO_BITS = 15;
-constexpr unsigned TBL_PER_BLOCK = 1024;   // scalars per partition workgroup (4 per lane)
+constexpr unsigned TBL_PER_BLOCK = 512;    // scalars per partition workgroup (2 per lane)
 constexpr unsigned RED_K0 = 16;            // level-0 fan-in of the table-mode bucket reduction
 
 // canonical scalars (zeroed when the base is the point at infinity): digits are then pure bit extraction
@@ -448,38 +447,48 @@ __global__ __launch_bounds__(256) void k_tbl_partition(const Fp<P> *canon, size_
     __shared__ uint32_t cnt[1024], base[1024];
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
     __syncthreads();
-    for (unsigned q = 0; q < TBL_PER_BLOCK / 256; ++q) {
-        size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
-        if (i >= len) break;
-        Fp<P> k = canon[i];
-        uint32_t carry = 0, b, neg;
-        for (unsigned w = 0; w < L.nwin; ++w)
-            if (digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
+    // pass 1: count per region -- the counting atomic returns the entry's rank inside this workgroup, kept in
+    // registers (QN scalars x <= 32 windows per lane) so that pass 2 needs no second LDS atomic
+    constexpr unsigned QN = TBL_PER_BLOCK / 256;
+    uint32_t rank[QN][32];
+#pragma unroll
+    for (unsigned q = 0; q < QN; ++q) {
+        const size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
+        if (i < len) {
+            const Fp<P> k = canon[i];
+            uint32_t carry = 0, b, neg;
+#pragma unroll
+            for (unsigned w = 0; w < 32; ++w)
+                if (w < L.nwin && digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) rank[q][w] = atomicAdd(&cnt[b >> LO_BITS], 1u);
+        }
     }
     __syncthreads();
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) {
         uint32_t v = cnt[r];
         base[r] = v ? region_off[r] + atomicAdd(&region_cursor[r], v) : 0u;
-        cnt[r] = 0;
     }
     __syncthreads();
-    for (unsigned q = 0; q < TBL_PER_BLOCK / 256; ++q) {
-        size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
-        if (i >= len) break;
-        Fp<P> k = canon[i];
-        uint32_t carry = 0, b, neg;
-        for (unsigned w = 0; w < L.nwin; ++w)
-            if (digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) {
-                const unsigned r = b >> LO_BITS;
-                const uint32_t pos = base[r] + atomicAdd(&cnt[r], 1u);
-                keys[pos] = (uint16_t)(b & ((1u << LO_BITS) - 1));
-                vals[pos] = (uint32_t)(((size_t)w * tbl_stride + base_index + i) << 1) | neg;
-            }
+#pragma unroll
+    for (unsigned q = 0; q < QN; ++q) {
+        const size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
+        if (i < len) {
+            const Fp<P> k = canon[i];
+            uint32_t carry = 0, b, neg;
+#pragma unroll
+            for (unsigned w = 0; w < 32; ++w)
+                if (w < L.nwin && digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) {
+                    const uint32_t pos = base[b >> LO_BITS] + rank[q][w];
+                    keys[pos] = (uint16_t)(b & ((1u << LO_BITS) - 1));
+                    vals[pos] = (uint32_t)(((size_t)w * tbl_stride + base_index + i) << 1) | neg;
+                }
+        }
     }
 }
 
 // Level 2: workgroup `blockIdx.x` owns entries [x CH, (x+1) CH) of the region-partitioned array and
 // handles each region segment inside it with the LDS table (usually exactly one segment).
+constexpr unsigned RS_CHUNK_LOG = 15, RS_PER_LANE = (1u << RS_CHUNK_LOG) / 1024;   // entries per lane of a 1024-lane workgroup
+
 template <bool SCATTER>
 __global__ __launch_bounds__(1024) void k_region_sort(const uint16_t *keys, const uint32_t *vals, const uint32_t *region_off,
                                                       unsigned regions, unsigned lo_buckets, unsigned chunk, uint32_t *counts,
@@ -504,23 +513,37 @@ __global__ __launch_bounds__(1024) void k_region_sort(const uint16_t *keys, cons
         if (s0 >= s1) continue;
         for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) h[b] = 0;
         __syncthreads();
-        for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) atomicAdd(&h[keys[e]], 1u);
-        __syncthreads();
         const size_t gbase = (size_t)r * lo_buckets;
         if (!SCATTER) {
+            for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) atomicAdd(&h[keys[e]], 1u);
+            __syncthreads();
             for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) {
                 uint32_t v = h[b];
                 if (v) atomicAdd(&counts[gbase + b], v);
             }
         } else {
+            // the counting atomic already returns the entry's rank inside this workgroup: keep it in a
+            // register (<= RS_PER_LANE entries per lane) instead of a second LDS atomic per entry
+            uint32_t rank[RS_PER_LANE];
+            uint16_t key[RS_PER_LANE];
+#pragma unroll
+            for (unsigned q = 0; q < RS_PER_LANE; ++q) {
+                const uint32_t e = s0 + q * blockDim.x + threadIdx.x;
+                if (e < s1) {
+                    key[q] = keys[e];
+                    rank[q] = atomicAdd(&h[key[q]], 1u);
+                }
+            }
+            __syncthreads();
             for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) {
                 uint32_t v = h[b];
                 if (v) h[b] = bucket_off[gbase + b] + atomicAdd(&cursor[gbase + b], v);
             }
             __syncthreads();
-            for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) {
-                uint32_t pos = atomicAdd(&h[keys[e]], 1u);
-                sorted[pos] = vals[e];
+#pragma unroll
+            for (unsigned q = 0; q < RS_PER_LANE; ++q) {
+                const uint32_t e = s0 + q * blockDim.x + threadIdx.x;
+                if (e < s1) sorted[h[key[q]] + rank[q]] = vals[e];
             }
         }
         __syncthreads();
@@ -531,26 +554,27 @@ __global__ __launch_bounds__(1024) void k_region_sort(const uint16_t *keys, cons
 //   A_t = sum B_b  -> outA[t];   acc_t = sum (b - t K0 + 1) B_b  -> LDS tree -> one partial per workgroup.
 // S = sum_t acc_t + K0 * sum_t t A_t; the second sum is k_bucket_reduce<DIRECT> on outA.
 template <class C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, size_t nbuckets, size_t lanes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, size_t nbuckets, size_t lanes,
                                                        XYZZ<C> *outA, XYZZ<C> *outAcc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
     typedef typename C::FqRR RR;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    XYZZ28<C> run, acc;
+    XYZZ28<C> run;
     run.X = run.Y = run.ZZ = run.ZZZ = f28_zero<RR>();
-    acc = run;
+    XYZZ28<C> *acc = &sh[threadIdx.x];
+    *acc = run;
     if (t < lanes) {
         for (int j = (int)RED_K0 - 1; j >= 0; --j) {
             const size_t g = t * RED_K0 + (size_t)j;
             if (g >= nbuckets) continue;
             for (uint32_t q = task_off[g]; q < task_off[g + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
-            xyzz28_add_full<C>(acc, run);
+            xyzz28_add_into_full<C>(acc, run);
         }
         outA[t] = xyzz28_store<C>(run);
     }
-    XYZZ28<C> tot = lds_tree_sum<C>(sh, acc);
-    if (threadIdx.x == 0) outAcc[blockIdx.x] = xyzz28_store<C>(tot);
+    lds_tree_sum<C>(sh);
+    if (threadIdx.x == 0) outAcc[blockIdx.x] = xyzz28_store<C>(sh[0]);
 }
 
 // Final combine on the host: S = sum_w 2^(c w) S_w by Horner (c doublings per window) and one inversion
@@ -661,7 +685,7 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
     if (seg < 64) seg = 64;
     if (const char *e = getenv("PM_MSM_SEG")) seg = (size_t)atoi(e);
     const size_t max_tasks = NB + Emax / seg + 1;
-    const unsigned chunk = 1u << 15;
+    const unsigned chunk = 1u << RS_CHUNK_LOG;
     const size_t keys_bytes = (Emax * 2 + 15) & ~(size_t)15;
     PM_HIP(ctx, ws.canon.reserve(len * sizeof(Fr)));
     PM_HIP(ctx, ws.digits.reserve(keys_bytes + Emax * 4));

@@ -96,16 +96,24 @@ static int run(const char *name, int iters) {
         XYZZ<C> dsum = XYZZ<C>::identity();
         XYZZ28<C> rsum;
         rsum.X = rsum.Y = rsum.ZZ = rsum.ZZZ = f28_zero<RR>();
+        XYZZ28<C> msum = rsum;
         for (int k = 0; k + 1 < NP; k += 2) {
             XYZZ<C> pair = XYZZ<C>::from_affine(pts[k]);
             xyzz_madd<C>(pair, pts[k + 1], (k & 2) != 0);
             dsum = xyzz_add<C>(dsum, pair);
             XYZZ<C> rec = xyzz_std_to_internal<C>(pair);                    // what a task partial looks like in memory
             xyzz28_add_full<C>(rsum, xyzz28_load<C>(rec));
-            if (k == 10) { xyzz28_add_full<C>(rsum, xyzz28_load<C>(xyzz28_store<C>(rsum))); dsum = xyzz_add<C>(dsum, dsum); }   // a + a: exceptional
+            xyzz28_add_into_full<C>(&msum, xyzz28_load<C>(rec));           // streamed-operand form (LDS accumulator)
+            if (k == 10) {   // a + a: exceptional
+                xyzz28_add_full<C>(rsum, xyzz28_load<C>(xyzz28_store<C>(rsum)));
+                xyzz28_add_into_full<C>(&msum, xyzz28_load<C>(xyzz28_store<C>(msum)));
+                dsum = xyzz_add<C>(dsum, dsum);
+            }
         }
         Affine<C> b1 = xyzz_to_affine<C>(dsum), b2 = xyzz_to_affine<C>(xyzz_internal_to_std<C>(xyzz28_store<C>(rsum)));
         if (!(b1.x.eq(b2.x) && b1.y.eq(b2.y))) { fails++; printf("%s full-add chain mismatch\n", name); }
+        Affine<C> b3 = xyzz_to_affine<C>(xyzz_internal_to_std<C>(xyzz28_store<C>(msum)));
+        if (!(b1.x.eq(b3.x) && b1.y.eq(b3.y))) { fails++; printf("%s add-into chain mismatch\n", name); }
     }
     // 2c. doubling on F28 registers vs dense
     {
