@@ -156,6 +156,10 @@ int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
 int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
                     const uint64_t *c_at_x1, uint64_t *d_g1_xy, int *d_inf);
 
+/* Host helper: Keccak-f[1600] on 25 little-endian lanes, shared by the host mirrors' Merlin / Keccak256
+ * transcripts (the reference's transcripts are host code too: src/transcript/*.rs). */
+void pm_host_keccak_f1600(uint64_t state[25]);
+
 /* Debug / parity taps: copy an intermediate vector of the proof in flight back to the host.
  * which: 0 u_evals(n) 1 w_evals(n) 2 u coeffs(n) 3 w coeffs(n) 4 h coeffs(n) 5 witness-u coeffs(n)
  *        6 z_tail(M-m0) 7 quotient (10n+23) */

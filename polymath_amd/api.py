@@ -47,7 +47,7 @@ EXPORTS = [
     "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
     "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
     "pm_pk_info", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3",
-    "pm_prove_tap",
+    "pm_prove_tap", "pm_host_keccak_f1600",
 ]
 
 _lib = None
@@ -96,6 +96,8 @@ def load_library():
     L.pm_prove_phase2.argtypes = [vp, u64p, u64p]
     L.pm_prove_phase3.argtypes = [vp, u64p, u64p, u64p, u64p, u64p, intp]
     L.pm_prove_tap.argtypes = [vp, i, u64p, sz, ct.POINTER(sz)]
+    L.pm_host_keccak_f1600.argtypes = [u64p]
+    L.pm_host_keccak_f1600.restype = None
     _lib = L
     return L
 

@@ -9,8 +9,11 @@
 #include <new>
 
 #include "internal.h"
+#include "../host/hashes.hpp"
 
 using namespace pm;
+
+extern "C" void pm_host_keccak_f1600(uint64_t state[25]) { pmhost::keccak_f1600(state); }
 
 // ------------------------------------------------------------------------------ helpers
 template <class C>
