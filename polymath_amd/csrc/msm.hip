@@ -485,39 +485,47 @@ __global__ __launch_bounds__(256) void k_tbl_partition(const Fp<P> *canon, size_
     }
 }
 
-// Level 2: workgroup `blockIdx.x` owns entries [x CH, (x+1) CH) of the region-partitioned array and
-// handles each region segment inside it with the LDS table (usually exactly one segment).
+// Levels 2 and 3: one generic LDS-staged pass over a segment-partitioned (key, val) array.  Workgroup
+// `blockIdx.x` owns entries [x CH, (x+1) CH) and handles each segment piece inside it: bin = key >> bin_shift
+// (nbins per segment, global bin id = segment * nbins + bin).
+//   RS_HIST : counts[global bin] += occurrences
+//   RS_MID  : entries move to (keys_out, vals_out) at out_off[global bin] + rank, key keeps its low bin_shift bits
+//   RS_FINAL: sorted[out_off[global bin] + rank] = val
+// With 64 regions -> 128 sub-regions -> 256 buckets every pass writes runs of ~100+ entries per bin instead
+// of single scattered words (the two-level version spent most of its time on 4-byte scattered stores).
+enum { RS_HIST = 0, RS_MID = 1, RS_FINAL = 2 };
 constexpr unsigned RS_CHUNK_LOG = 15, RS_PER_LANE = (1u << RS_CHUNK_LOG) / 1024;   // entries per lane of a 1024-lane workgroup
 
-template <bool SCATTER>
-__global__ __launch_bounds__(1024) void k_region_sort(const uint16_t *keys, const uint32_t *vals, const uint32_t *region_off,
-                                                      unsigned regions, unsigned lo_buckets, unsigned chunk, uint32_t *counts,
-                                                      const uint32_t *bucket_off, uint32_t *cursor, uint32_t *sorted) {
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_region_pass(const uint16_t *keys, const uint32_t *vals, const uint32_t *seg_off,
+                                                      unsigned nseg, unsigned bin_shift, unsigned nbins, unsigned chunk,
+                                                      uint32_t *counts, const uint32_t *out_off, uint32_t *cursor,
+                                                      uint32_t *sorted, uint16_t *keys_out, uint32_t *vals_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *h = (uint32_t *)smem_raw;
-    const uint32_t total = region_off[regions];
+    const uint32_t total = seg_off[nseg];
     const uint32_t lo = blockIdx.x * chunk;
     if (lo >= total) return;
     uint32_t hi = lo + chunk;
     if (hi > total) hi = total;
-    // region containing `lo`: largest r with region_off[r] <= lo
-    unsigned ra = 0, rb = regions;
+    unsigned ra = 0, rb = nseg;   // segment containing `lo`: largest r with seg_off[r] <= lo
     while (rb - ra > 1) {
         unsigned mid = (ra + rb) >> 1;
-        if (region_off[mid] <= lo) ra = mid; else rb = mid;
+        if (seg_off[mid] <= lo) ra = mid; else rb = mid;
     }
-    for (unsigned r = ra; r < regions; ++r) {
-        const uint32_t s0 = region_off[r] > lo ? region_off[r] : lo;
-        const uint32_t s1 = region_off[r + 1] < hi ? region_off[r + 1] : hi;
+    const uint16_t low_mask = (uint16_t)((1u << bin_shift) - 1);
+    for (unsigned r = ra; r < nseg; ++r) {
+        const uint32_t s0 = seg_off[r] > lo ? seg_off[r] : lo;
+        const uint32_t s1 = seg_off[r + 1] < hi ? seg_off[r + 1] : hi;
         if (s0 >= hi) break;
         if (s0 >= s1) continue;
-        for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) h[b] = 0;
+        for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
         __syncthreads();
-        const size_t gbase = (size_t)r * lo_buckets;
-        if (!SCATTER) {
-            for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) atomicAdd(&h[keys[e]], 1u);
+        const size_t gbase = (size_t)r * nbins;
+        if (MODE == RS_HIST) {
+            for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) atomicAdd(&h[keys[e] >> bin_shift], 1u);
             __syncthreads();
-            for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) {
+            for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {
                 uint32_t v = h[b];
                 if (v) atomicAdd(&counts[gbase + b], v);
             }
@@ -531,23 +539,144 @@ __global__ __launch_bounds__(1024) void k_region_sort(const uint16_t *keys, cons
                 const uint32_t e = s0 + q * blockDim.x + threadIdx.x;
                 if (e < s1) {
                     key[q] = keys[e];
-                    rank[q] = atomicAdd(&h[key[q]], 1u);
+                    rank[q] = atomicAdd(&h[key[q] >> bin_shift], 1u);
                 }
             }
             __syncthreads();
-            for (unsigned b = threadIdx.x; b < lo_buckets; b += blockDim.x) {
+            for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {
                 uint32_t v = h[b];
-                if (v) h[b] = bucket_off[gbase + b] + atomicAdd(&cursor[gbase + b], v);
+                if (v) h[b] = out_off[gbase + b] + atomicAdd(&cursor[gbase + b], v);
             }
             __syncthreads();
 #pragma unroll
             for (unsigned q = 0; q < RS_PER_LANE; ++q) {
                 const uint32_t e = s0 + q * blockDim.x + threadIdx.x;
-                if (e < s1) sorted[h[key[q]] + rank[q]] = vals[e];
+                if (e < s1) {
+                    const uint32_t pos = h[key[q] >> bin_shift] + rank[q];
+                    if (MODE == RS_FINAL) {
+                        sorted[pos] = vals[e];
+                    } else {
+                        keys_out[pos] = key[q] & low_mask;
+                        vals_out[pos] = vals[e];
+                    }
+                }
             }
         }
         __syncthreads();
     }
+}
+
+// The same pass for SMALL bin counts (<= 256), with the chunk staged through LDS in bin order so that
+// the global stores are coalesced: consecutive lanes write consecutive addresses of a bin's run
+// (the direct version above issues 64 scattered 4-byte stores per wave-instruction).
+//   LDS: h[nbins] | start[nbins] | delta[nbins] | staged vals (u32 x ST_CHUNK) | staged keys (u16 x ST_CHUNK)
+constexpr unsigned ST_CHUNK = 8192, ST_PER_LANE = ST_CHUNK / 1024, ST_MAX_BINS = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_region_pass_staged(const uint16_t *keys, const uint32_t *vals, const uint32_t *seg_off,
+                                                             unsigned nseg, unsigned bin_shift, unsigned nbins,
+                                                             const uint32_t *out_off, uint32_t *cursor, uint32_t *sorted,
+                                                             uint16_t *keys_out, uint32_t *vals_out) {
+    __shared__ uint32_t h[ST_MAX_BINS], start[ST_MAX_BINS], delta[ST_MAX_BINS];
+    __shared__ uint32_t st_val[ST_CHUNK];
+    __shared__ uint16_t st_key[ST_CHUNK];
+    const uint32_t total = seg_off[nseg];
+    const uint32_t lo = blockIdx.x * ST_CHUNK;
+    if (lo >= total) return;
+    uint32_t hi = lo + ST_CHUNK;
+    if (hi > total) hi = total;
+    unsigned ra = 0, rb = nseg;
+    while (rb - ra > 1) {
+        unsigned mid = (ra + rb) >> 1;
+        if (seg_off[mid] <= lo) ra = mid; else rb = mid;
+    }
+    const uint16_t low_mask = (uint16_t)((1u << bin_shift) - 1);
+    const unsigned t = threadIdx.x;
+    for (unsigned r = ra; r < nseg; ++r) {
+        const uint32_t s0 = seg_off[r] > lo ? seg_off[r] : lo;
+        const uint32_t s1 = seg_off[r + 1] < hi ? seg_off[r + 1] : hi;
+        if (s0 >= hi) break;
+        if (s0 >= s1) continue;
+        const uint32_t cnt = s1 - s0;
+        if (t < nbins) h[t] = 0;
+        __syncthreads();
+        uint32_t rank[ST_PER_LANE], val[ST_PER_LANE];
+        uint16_t key[ST_PER_LANE];
+#pragma unroll
+        for (unsigned q = 0; q < ST_PER_LANE; ++q) {
+            const uint32_t e = s0 + q * 1024 + t;
+            if (e < s1) {
+                key[q] = keys[e];
+                val[q] = vals[e];
+                rank[q] = atomicAdd(&h[key[q] >> bin_shift], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of h over the bins (<= 256) by the first 256 lanes; claim the global runs
+        if (t < ST_MAX_BINS) start[t] = t < nbins ? h[t] : 0u;
+        __syncthreads();
+        for (unsigned o = 1; o < ST_MAX_BINS; o <<= 1) {
+            uint32_t a = (t < ST_MAX_BINS && t >= o) ? start[t - o] : 0u;
+            __syncthreads();
+            if (t < ST_MAX_BINS) start[t] += a;
+            __syncthreads();
+        }
+        if (t < nbins) {
+            const uint32_t c = h[t], ex = start[t] - c;      // exclusive prefix
+            const size_t g = (size_t)r * nbins + t;
+            const uint32_t gpos = c ? out_off[g] + atomicAdd(&cursor[g], c) : 0u;
+            delta[t] = gpos - ex;                              // global position = delta[bin] + staged slot
+            h[t] = ex;                                         // h now = local start of the bin
+        }
+        __syncthreads();
+#pragma unroll
+        for (unsigned q = 0; q < ST_PER_LANE; ++q) {
+            const uint32_t e = s0 + q * 1024 + t;
+            if (e < s1) {
+                const uint32_t slot = h[key[q] >> bin_shift] + rank[q];
+                st_key[slot] = key[q];
+                st_val[slot] = val[q];
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < cnt; i += 1024) {
+            const uint16_t k = st_key[i];
+            const uint32_t pos = delta[k >> bin_shift] + i;
+            if (MODE == RS_FINAL) {
+                sorted[pos] = st_val[i];
+            } else {
+                keys_out[pos] = k & low_mask;
+                vals_out[pos] = st_val[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// exclusive scan of n <= 2^20 counters by one workgroup (sub-region offsets); off[n] = total; clears `zero`
+__global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *cnt, uint32_t *off, uint32_t *zero, unsigned n) {
+    __shared__ uint32_t s[1024];
+    __shared__ uint32_t carry;
+    const unsigned t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < n; base += 1024) {
+        const unsigned i = base + t;
+        const uint32_t v = i < n ? cnt[i] : 0u;
+        s[t] = v;
+        __syncthreads();
+        for (unsigned o = 1; o < 1024; o <<= 1) {
+            uint32_t a = t >= o ? s[t - o] : 0u;
+            __syncthreads();
+            s[t] += a;
+            __syncthreads();
+        }
+        if (i < n) { off[i] = carry + s[t] - v; zero[i] = 0; }
+        __syncthreads();
+        if (t == 1023) carry += s[1023];
+        __syncthreads();
+    }
+    if (t == 0) off[n] = carry;
 }
 
 // Level 0 of the table-mode reduction: lane t owns buckets [t K0, t K0 + K0) (weights b + 1):
@@ -727,28 +856,62 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
         hipLaunchKernelGGL(k_tbl_partition<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, L, regions, region_off,
                            region_cursor, tb.stride, tb.base_index, keys, vals);
         PM_HIP(ctx, hipGetLastError());
-        const size_t lds = (size_t)lo_buckets * 4;
-        if (lds > 48 * 1024) {
-            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_region_sort<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_region_sort<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
         const unsigned sblocks = (unsigned)((Emax + chunk - 1) / chunk);
-        hipLaunchKernelGGL(k_region_sort<false>, dim3(sblocks), dim3(1024), lds, ctx->stream, keys, vals, region_off, regions, lo_buckets,
-                           chunk, counts, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
-        PM_HIP(ctx, hipGetLastError());
         const unsigned ntiles = (unsigned)((NB + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, counts, ws.bucket_off.as<uint32_t>(),
-                           ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB, (unsigned)seg);
-        PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, ws.cursor.as<uint32_t>(), ntiles,
-                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), NB);
-        PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, ctx->stream, ws.bucket_off.as<uint32_t>(),
-                           ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB);
-        PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_region_sort<true>, dim3(sblocks), dim3(1024), lds, ctx->stream, keys, vals, region_off, regions, lo_buckets,
-                           chunk, counts, ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>());
-        PM_HIP(ctx, hipGetLastError());
+        auto bucket_scan = [&]() -> int {
+            hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, counts, ws.bucket_off.as<uint32_t>(),
+                               ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB, (unsigned)seg);
+            PM_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, ws.cursor.as<uint32_t>(), ntiles,
+                               ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), NB);
+            PM_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, ctx->stream, ws.bucket_off.as<uint32_t>(),
+                               ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB);
+            PM_HIP(ctx, hipGetLastError());
+            return PM_OK;
+        };
+        if (lo_buckets == (1u << LO_BITS)) {
+            // three levels: regions (2^15 buckets) -> 128 sub-regions of 256 buckets -> buckets
+            const unsigned SUB_BINS = 128, FIN_BINS = 256, FIN_BITS = 8;
+            const unsigned nsub = regions * SUB_BINS;
+            PM_HIP(ctx, ws.sub.reserve((3 * (size_t)nsub + 4) * 4));
+            PM_HIP(ctx, ws.digits2.reserve(keys_bytes + Emax * 4));
+            uint32_t *sub_count = ws.sub.as<uint32_t>(), *sub_off = sub_count + nsub, *sub_cursor = sub_off + nsub + 1;
+            uint16_t *keys2 = (uint16_t *)ws.digits2.p;
+            uint32_t *vals2 = (uint32_t *)((uint8_t *)ws.digits2.p + keys_bytes);
+            PM_HIP(ctx, hipMemsetAsync(sub_count, 0, (size_t)nsub * 4, ctx->stream));
+            hipLaunchKernelGGL(k_region_pass<RS_HIST>, dim3(sblocks), dim3(1024), SUB_BINS * 4, ctx->stream, keys, vals, region_off, regions,
+                               FIN_BITS, SUB_BINS, chunk, sub_count, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                               (uint16_t *)nullptr, (uint32_t *)nullptr);
+            PM_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, sub_count, sub_off, sub_cursor, nsub);
+            PM_HIP(ctx, hipGetLastError());
+            const unsigned stblocks = (unsigned)((Emax + ST_CHUNK - 1) / ST_CHUNK);
+            hipLaunchKernelGGL(k_region_pass_staged<RS_MID>, dim3(stblocks), dim3(1024), 0, ctx->stream, keys, vals, region_off, regions,
+                               FIN_BITS, SUB_BINS, sub_off, sub_cursor, (uint32_t *)nullptr, keys2, vals2);
+            PM_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_region_pass<RS_HIST>, dim3(sblocks), dim3(1024), FIN_BINS * 4, ctx->stream, keys2, vals2, sub_off, nsub, 0u,
+                               FIN_BINS, chunk, counts, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                               (uint16_t *)nullptr, (uint32_t *)nullptr);
+            PM_HIP(ctx, hipGetLastError());
+            PM_TRY(bucket_scan());
+            hipLaunchKernelGGL(k_region_pass_staged<RS_FINAL>, dim3(stblocks), dim3(1024), 0, ctx->stream, keys2, vals2, sub_off, nsub, 0u,
+                               FIN_BINS, ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>(), (uint16_t *)nullptr,
+                               (uint32_t *)nullptr);
+            PM_HIP(ctx, hipGetLastError());
+        } else {
+            // small bucket sets (< 2^15): one region, sorted directly with an nbuckets-entry LDS table
+            const size_t lds = (size_t)lo_buckets * 4;
+            hipLaunchKernelGGL(k_region_pass<RS_HIST>, dim3(sblocks), dim3(1024), lds, ctx->stream, keys, vals, region_off, regions, 0u,
+                               lo_buckets, chunk, counts, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                               (uint16_t *)nullptr, (uint32_t *)nullptr);
+            PM_HIP(ctx, hipGetLastError());
+            PM_TRY(bucket_scan());
+            hipLaunchKernelGGL(k_region_pass<RS_FINAL>, dim3(sblocks), dim3(1024), lds, ctx->stream, keys, vals, region_off, regions, 0u,
+                               lo_buckets, chunk, (uint32_t *)nullptr, ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>(),
+                               (uint16_t *)nullptr, (uint32_t *)nullptr);
+            PM_HIP(ctx, hipGetLastError());
+        }
     }
     {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
