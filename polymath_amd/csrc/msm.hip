@@ -237,18 +237,67 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t *digits, const 
     }
 }
 
+// ------------------------------------------------------------------------------ task order
+// k_accumulate gives every lane one task; a wave runs as long as its LONGEST task.  Bucket loads are
+// Poisson (mean m, sigma sqrt(m)), so in launch order the 64 lanes of a wave idle ~2.5 sigma / m of the
+// time (15 % at m = 168).  order[] lists the tasks by DESCENDING length (counting sort over the length,
+// LDS histogram per workgroup): the lanes of a wave then carry (almost) equal loads and the longest
+// tasks start first.  bin = (seg - L) >> lshift, L in [1, seg].
+constexpr unsigned TASK_MAX_BINS = 8192;
+
+template <bool SCATTER>
+__global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, const uint32_t *task_off, size_t G, unsigned seg,
+                                                    unsigned lshift, unsigned nbins, uint32_t *len_cnt, const uint32_t *len_off,
+                                                    uint32_t *len_cursor, uint32_t *order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *h = (uint32_t *)smem_raw;
+    for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = task_off[G];
+    unsigned bin = 0;
+    uint32_t rank = 0;
+    if (t < total) {
+        size_t lo = 0, hi = G;
+        while (hi - lo > 1) {
+            size_t mid = (lo + hi) >> 1;
+            if (task_off[mid] <= t) lo = mid; else hi = mid;
+        }
+        const uint32_t rem = counts[lo] - ((uint32_t)t - task_off[lo]) * seg;
+        const uint32_t L = rem < seg ? rem : seg;
+        bin = (seg - L) >> lshift;
+        rank = atomicAdd(&h[bin], 1u);
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {
+            const uint32_t v = h[b];
+            if (v) atomicAdd(&len_cnt[b], v);
+        }
+    } else {
+        for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {
+            const uint32_t v = h[b];
+            if (v) h[b] = len_off[b] + atomicAdd(&len_cursor[b], v);
+        }
+        __syncthreads();
+        if (t < total) order[h[bin] + rank] = (uint32_t)t;
+    }
+}
+
 // ---------------------------------------------------------------------------- accumulate
-// One lane per task.  The accumulator lives in reduced-radix registers (fq28.cuh): 10 carry-free
+// One lane per task (taken in order[]).  The accumulator lives in reduced-radix registers (fq28.cuh): 10 carry-free
 // Montgomery products and 7 lazy add/sub per mixed add.  `bases` are in INTERNAL Montgomery form.
 // The exceptional case acc == +-point (doubling / cancellation) is resolved on the dense path.
 template <class C>
 __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, const uint32_t *counts,
                                                     const uint32_t *bucket_off, const uint32_t *task_off,
-                                                    const Affine<C> *bases, XYZZ<C> *partials, size_t G, unsigned seg) {
+                                                    const uint32_t *order, const Affine<C> *bases, XYZZ<C> *partials, size_t G,
+                                                    unsigned seg) {
     typedef typename C::FqRR RR;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = task_off[G];
     if (t >= total) return;
+    t = order[t];   // tasks by descending length: equal loads inside a wave
     // bucket of task t: largest g with task_off[g] <= t  (empty buckets have zero tasks)
     size_t lo = 0, hi = G;
     while (hi - lo > 1) {
@@ -719,6 +768,28 @@ static void host_finish(const XYZZ<C> *S /*[nwin], internal form*/, unsigned nwi
     *out = xyzz_to_affine<C>(acc);
 }
 
+// order[] for k_accumulate (see k_task_bins); enqueued on the context's stream after the bucket scan.
+static int task_order(pm_ctx *ctx, const uint32_t *counts, size_t G, size_t seg, size_t max_tasks) {
+    MsmWorkspace &ws = ctx->msm;
+    unsigned lshift = 0;
+    while (((seg - 1) >> lshift) + 1 > TASK_MAX_BINS) ++lshift;
+    const unsigned nbins = (unsigned)(((seg - 1) >> lshift) + 1);
+    PM_HIP(ctx, ws.order.reserve(max_tasks * 4));
+    PM_HIP(ctx, ws.len_bins.reserve((3 * (size_t)nbins + 4) * 4));
+    uint32_t *len_cnt = ws.len_bins.as<uint32_t>(), *len_off = len_cnt + nbins, *len_cursor = len_off + nbins + 1;
+    PM_HIP(ctx, hipMemsetAsync(len_cnt, 0, (size_t)nbins * 4, ctx->stream));
+    const unsigned blocks = (unsigned)((max_tasks + 1023) / 1024);
+    hipLaunchKernelGGL(k_task_bins<false>, dim3(blocks), dim3(1024), nbins * 4, ctx->stream, counts, ws.task_off.as<uint32_t>(), G,
+                       (unsigned)seg, lshift, nbins, len_cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    PM_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, len_cnt, len_off, len_cursor, nbins);
+    PM_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_task_bins<true>, dim3(blocks), dim3(1024), nbins * 4, ctx->stream, counts, ws.task_off.as<uint32_t>(), G,
+                       (unsigned)seg, lshift, nbins, (uint32_t *)nullptr, len_off, len_cursor, ws.order.as<uint32_t>());
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+}
+
 // ------------------------------------------------------------------------------- driver
 // One bucket pipeline over at most MSM_MAX_PIECE pairs (sorted-entry positions are u32: W * len < 2^32).
 constexpr size_t MSM_MAX_PIECE = (size_t)1 << 27;
@@ -771,12 +842,13 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
         hipLaunchKernelGGL(k_scatter, dim3(p.nchunks, p.nwin), dim3(1024), lds, ctx->stream, ws.digits.as<uint32_t>(),
                            ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>(), len, p.chunk, p.nbuckets);
         PM_HIP(ctx, hipGetLastError());
+        PM_TRY(task_order(ctx, counts, G, p.seg, p.max_tasks));
     }
     {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
         size_t blocks = (p.max_tasks + 127) / 128;
         hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(),
-                           counts, ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), d_bases,
+                           counts, ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), d_bases,
                            ws.partials.as<XYZZ<C>>(), G, p.seg);
         PM_HIP(ctx, hipGetLastError());
     }
@@ -912,13 +984,14 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
                                (uint16_t *)nullptr, (uint32_t *)nullptr);
             PM_HIP(ctx, hipGetLastError());
         }
+        PM_TRY(task_order(ctx, counts, NB, seg, max_tasks));
     }
     {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
         size_t blocks = (max_tasks + 127) / 128;
         hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
-                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), d_table, ws.partials.as<XYZZ<C>>(), NB,
-                           (unsigned)seg);
+                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), d_table,
+                           ws.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
         PM_HIP(ctx, hipGetLastError());
     }
     XYZZ<C> hres[2];
