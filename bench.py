@@ -101,7 +101,12 @@ def main():
     g = PC.SplitMix64(0xBE7C4)
     x_trap, z_trap, r_a = g.fr(r), g.fr(r), [g.fr(r), g.fr(r)]
     t0 = time.time()
-    pk = pm.setup((r1cs, inst, wit), x_trap, z_trap, shard_rank=rank, shard_count=world)
+    # dev hook: BENCH_FAKE_SHARD="r/N" times ONE rank's share of an N-GPU proof on a single GPU (no exchange;
+    # the proof bytes are then not a valid proof) -- used to size the fixed per-rank costs without an 8-GPU node
+    shard_rank, shard_count = rank, world
+    if world == 1 and os.environ.get("BENCH_FAKE_SHARD"):
+        shard_rank, shard_count = (int(v) for v in os.environ["BENCH_FAKE_SHARD"].split("/"))
+    pk = pm.setup((r1cs, inst, wit), x_trap, z_trap, shard_rank=shard_rank, shard_count=shard_count)
     log(rank, "setup on device: n=%d, %d resident points (%.1f s)" % (pk.n, sum(pk.base_lens), time.time() - t0))
     x_l, w_l = pm.field.fr_limbs(inst), pm.field.fr_limbs(wit)
     combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local, backend_gloo=(backend != "nccl")) if world > 1 else None
@@ -139,6 +144,14 @@ def main():
     proof_host = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine)
     barrier()
     ms_host_inputs = (time.perf_counter() - t1) * 1e3
+    if os.environ.get("BENCH_PHASES"):             # dev hook: stage timings of all three phases (stderr)
+        pm.collect_timings = True
+        t1 = time.perf_counter()
+        pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs)
+        log(rank, "wall %.2f ms; phases:" % ((time.perf_counter() - t1) * 1e3))
+        for i, tm in enumerate(pm.phase_timings):
+            log(rank, " phase %d:" % (i + 1), {k: round(v, 2) for k, v in tm.items() if v})
+        pm.collect_timings = False
     assert proof_host.to_bytes() == proof.to_bytes()
     n = pk.n
     d_pairs_total = 10 * n + 22                     # quotient MSM M8 (prover.rs:229)

@@ -327,6 +327,8 @@ static void pk_release(pm_pk *pk) {
         if (pk->d_val[i]) (void)hipFree(pk->d_val[i]);
     }
     if (pk->d_bases) (void)hipFree(pk->d_bases);
+    for (int k = 0; k < 3; ++k)
+        if (pk->d_tab[k]) (void)hipFree(pk->d_tab[k]);
     delete pk;
 }
 
@@ -426,22 +428,12 @@ static bool tables_disabled_by_env() {
     return e && e[0] == '0';
 }
 
-// Allocates the resident base array (plus its window tables when they fit: sized for 288 GB of HBM),
-// fills window 0 through `fill`, then builds windows 1..W-1 on the device.
+// Allocates the resident base array and fills it through `fill`; then, when they fit (sized for 288 GB of
+// HBM), builds one set of window tables per merged MSM on the device.
 template <class C, class F>
 static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     const uint64_t resident = pk_resident_points(pk);
-    uint64_t total_pairs = 0;
-    for (int k = 0; k < 3; ++k) total_pairs += pk->res_hi[k] - pk->res_lo[k];
-    MsmTables tb = tables_plan((size_t)total_pairs, 3, (size_t)resident, (unsigned)C::FrP::BITS);
-    size_t free_b = 0, total_b = 0;
-    PM_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    // leave room for the per-proof vectors and the MSM workspace (~ 40 B per table entry of the longest MSM)
-    const double need = (double)resident * tb.nwin * sizeof(Affine<C>) + 48.0 * tb.nwin * (double)(pk->res_hi[2] - pk->res_lo[2]) +
-                        64.0 * 40.0 * (double)pk->n;
-    if (tables_disabled_by_env() || !tb.c || need > 0.9 * (double)free_b) tb = MsmTables();
-    const uint64_t windows = tb.c ? tb.nwin : 1;
-    PM_HIP(ctx, hipMalloc(&pk->d_bases, resident * windows * sizeof(Affine<C>)));
+    PM_HIP(ctx, hipMalloc(&pk->d_bases, (resident ? resident : 1) * sizeof(Affine<C>)));
     Affine<C> *d = (Affine<C> *)pk->d_bases;
     if (pk->shard_count == 1) {
         PM_TRY(for_cat_range<C>(pk, 0, pk->total_points, d, fill));
@@ -450,8 +442,27 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
             PM_TRY(for_cat_range<C>(pk, pk->msm_lo[k] + pk->res_lo[k], pk->msm_lo[k] + pk->res_hi[k], d + pk->res_dev_off[k], fill));
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    pk->tables = tb;
-    return tables_build<C>(ctx, d, (size_t)resident, tb);
+    if (tables_disabled_by_env()) return PM_OK;
+    MsmTables tb[3];
+    double need = 64.0 * 40.0 * (double)pk->n;   // per-proof vectors
+    for (int k = 0; k < 3; ++k) {
+        const uint64_t len = pk->res_hi[k] - pk->res_lo[k];
+        tb[k] = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS);
+        // the table itself + the MSM workspace (~ 48 B per table entry of the longest MSM, reused by the others)
+        need += (double)len * tb[k].nwin * sizeof(Affine<C>) + (k == 2 ? 48.0 * tb[k].nwin * (double)len : 0.0);
+    }
+    size_t free_b = 0, total_b = 0;
+    PM_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    if (need > 0.9 * (double)free_b) return PM_OK;   // no room: per-window Pippenger on the plain array
+    for (int k = 0; k < 3; ++k) {
+        const uint64_t len = pk->res_hi[k] - pk->res_lo[k];
+        if (!len || !tb[k].c) continue;
+        PM_HIP(ctx, hipMalloc(&pk->d_tab[k], len * tb[k].nwin * sizeof(Affine<C>)));
+        PM_HIP(ctx, hipMemcpyAsync(pk->d_tab[k], d + pk->res_dev_off[k], len * sizeof(Affine<C>), hipMemcpyDeviceToDevice, ctx->stream));
+        PM_TRY(tables_build<C>(ctx, (Affine<C> *)pk->d_tab[k], (size_t)len, tb[k]));
+        pk->tables[k] = tb[k];
+    }
+    return PM_OK;
 }
 
 template <class C>

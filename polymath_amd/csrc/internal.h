@@ -129,7 +129,10 @@ struct pm_pk {
     // stored at d_bases + res_dev_off[k]
     uint64_t res_lo[3], res_hi[3], res_dev_off[3];
     uint64_t msm_lo[3], msm_len[3];  // logical pair range of each merged MSM inside the concatenation
-    pm::MsmTables tables;            // window tables over ALL resident points (stride = resident point count)
+    // Window tables, ONE SET PER MERGED MSM (its own window width: the optimum depends on the pair count):
+    // d_tab[k] holds [nwin_k][res_hi[k] - res_lo[k]] points, window 0 being a copy of the MSM's resident slice.
+    pm::MsmTables tables[3];
+    void *d_tab[3];
 };
 
 struct PendingTimer {

@@ -340,9 +340,8 @@ __device__ __forceinline__ void lds_tree_sum(XYZZ28<C> *sh) {
     }
 }
 
-// DIRECT = false: input bucket b = sum of its task partials, weight b + 1 (a Pippenger window).
-// DIRECT = true : input i = partials[w * nbuckets + i] itself, weight i (level-1 input of the table mode).
-template <class C, bool DIRECT>
+// Input bucket b = sum of its task partials, weight b + 1 (a Pippenger window).
+template <class C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, unsigned nbuckets,
                                                        unsigned lanes_per_window, unsigned bpw, XYZZ<C> *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -358,13 +357,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const size_t gbase = (size_t)w * nbuckets + (size_t)j * RED_K;
         for (int i = (int)RED_K - 1; i >= 0; --i) {
             if ((size_t)j * RED_K + i >= nbuckets) continue;
-            if (DIRECT) {
-                xyzz28_add_full<C>(run, xyzz28_load<C>(partials[gbase + i]));
-                if (i > 0) xyzz28_add_into_full<C>(acc, run);      // weight i (zero-based)
-            } else {
-                for (uint32_t q = task_off[gbase + i]; q < task_off[gbase + i + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
-                xyzz28_add_into_full<C>(acc, run);                 // weight i + 1
-            }
+            for (uint32_t q = task_off[gbase + i]; q < task_off[gbase + i + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
+            xyzz28_add_into_full<C>(acc, run);                 // weight i + 1
         }
         const uint32_t s = j * RED_K;          // acc += s * run
         if (s) {
@@ -402,7 +396,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // =====================================================================================================
 constexpr unsigned LO_BITS = 15;
 constexpr unsigned TBL_PER_BLOCK = 512;    // scalars per partition workgroup (2 per lane)
-constexpr unsigned RED_K0 = 16;            // level-0 fan-in of the table-mode bucket reduction
 
 // canonical scalars (zeroed when the base is the point at infinity): digits are then pure bit extraction
 template <class C>
@@ -728,31 +721,84 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *cnt, uint32
     if (t == 0) off[n] = carry;
 }
 
-// Level 0 of the table-mode reduction: lane t owns buckets [t K0, t K0 + K0) (weights b + 1):
-//   A_t = sum B_b  -> outA[t];   acc_t = sum (b - t K0 + 1) B_b  -> LDS tree -> one partial per workgroup.
-// S = sum_t acc_t + K0 * sum_t t A_t; the second sum is k_bucket_reduce<DIRECT> on outA.
+// Table-mode bucket reduction  S = sum_b (b + 1) B_b  over ONE set of NB buckets.  Every step below is a
+// chain of DEPENDENT point additions (~21 us each on a lone wave), so the layout minimises chain length,
+// not work:
+//   level 0  lane t owns buckets [t K0, t K0 + K0):  A_t = sum B_b,  acc_t = sum (b - t K0 + 1) B_b
+//            (2 K0 adds; K0 is chosen so that NB / K0 ~ 2^17 lanes = one full round of the chip);
+//   level 1  lane j owns R level-0 outputs: running sums, (jR) * sum A by double-and-add, + acc_t; LDS tree
+//            per workgroup (2^15 lanes: a short chain on a quarter-full chip beats a full chip of scalar muls);
+//   final    one workgroup sums the level-1 partials.
+//   S = sum_t acc_t + sum_t (t K0) A_t.
 template <class C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, size_t nbuckets, size_t lanes,
-                                                       XYZZ<C> *outA, XYZZ<C> *outAcc) {
+                                                       unsigned K0, XYZZ<C> *outA, XYZZ<C> *outAcc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
     typedef typename C::FqRR RR;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
     XYZZ28<C> run;
     run.X = run.Y = run.ZZ = run.ZZZ = f28_zero<RR>();
-    XYZZ28<C> *acc = &sh[threadIdx.x];
+    XYZZ28<C> *acc = &sh[threadIdx.x];     // the weighted accumulator lives in LDS (register pressure)
     *acc = run;
-    if (t < lanes) {
-        for (int j = (int)RED_K0 - 1; j >= 0; --j) {
-            const size_t g = t * RED_K0 + (size_t)j;
-            if (g >= nbuckets) continue;
-            for (uint32_t q = task_off[g]; q < task_off[g + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
-            xyzz28_add_into_full<C>(acc, run);
+    for (int j = (int)K0 - 1; j >= 0; --j) {
+        const size_t g = t * K0 + (size_t)j;
+        if (g >= nbuckets) continue;
+        for (uint32_t q = task_off[g]; q < task_off[g + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
+        xyzz28_add_into_full<C>(acc, run);
+    }
+    outA[t] = xyzz28_store<C>(run);
+    outAcc[t] = xyzz28_store<C>(*acc);
+}
+
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level1(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0, unsigned K0,
+                                                       unsigned R, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    // lane j owns level-0 outputs t in [jR, jR + R):  sum_t (t K0) A_t + acc_t
+    //   = K0 * (jR * sum_i A_{jR+i} + sum_i i A_{jR+i}) + sum_i acc_{jR+i}
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t0 = j * R;
+    XYZZ28<C> *acc = &sh[threadIdx.x];
+    acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
+    if (t0 < lanes0) {
+        XYZZ28<C> run = *acc;
+        for (int i = (int)R - 1; i >= 0; --i) {
+            if (t0 + i >= lanes0) continue;
+            xyzz28_add_full<C>(run, xyzz28_load<C>(A[t0 + i]));
+            if (i > 0) xyzz28_add_into_full<C>(acc, run);          // weight i
         }
-        outA[t] = xyzz28_store<C>(run);
+        if (t0) {                                                    // acc += t0 * run
+            XYZZ28<C> m = run;
+            for (int b = 62 - __clzll((long long)t0); b >= 0; --b) {
+                xyzz28_dbl<C>(m);
+                if ((t0 >> b) & 1) xyzz28_add_full<C>(m, run);
+            }
+            xyzz28_add_into_full<C>(acc, m);
+        }
+        run = *acc;
+        for (unsigned k = 1; k < K0; k <<= 1) xyzz28_dbl<C>(run);  // K0 is a power of two
+        for (unsigned i = 0; i < R; ++i)
+            if (t0 + i < lanes0) xyzz28_add_full<C>(run, xyzz28_load<C>(Acc[t0 + i]));
+        *acc = run;
     }
     lds_tree_sum<C>(sh);
-    if (threadIdx.x == 0) outAcc[blockIdx.x] = xyzz28_store<C>(sh[0]);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
+}
+
+// out[0] = sum of parts[0 .. count) by one 256-lane workgroup
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sum_final(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    XYZZ28<C> *acc = &sh[threadIdx.x];
+    acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
+    for (unsigned i = threadIdx.x; i < count; i += 256) xyzz28_add_into_full<C>(acc, xyzz28_load<C>(parts[i]));
+    lds_tree_sum<C>(sh);
+    if (threadIdx.x == 0) out[0] = xyzz28_store<C>(sh[0]);
 }
 
 // Final combine on the host: S = sum_w 2^(c w) S_w by Horner (c doublings per window) and one inversion
@@ -856,7 +902,7 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
     {
         StageTimer t(ctx, T_MSM_REDUCE);
         XYZZ<C> *parts = ws.wsum.as<XYZZ<C>>(), *dS = parts + (size_t)p.nwin * bpw;
-        hipLaunchKernelGGL((k_bucket_reduce<C, false>), dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
+        hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
                            ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), p.nbuckets, red_lanes, bpw, parts);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_sum_parts<C>, dim3(p.nwin), dim3(64), 0, ctx->stream, parts, bpw, dS);
@@ -898,13 +944,17 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
     PM_HIP(ctx, ws.cursor.reserve(((NB + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
     PM_HIP(ctx, ws.partials.reserve(max_tasks * sizeof(XYZZ<C>)));
     const bool two_level = NB >= 4096;
-    const size_t lanes0 = (NB + RED_K0 - 1) / RED_K0, blocks0 = (lanes0 + 255) / 256;
-    const size_t nb1 = two_level ? lanes0 : NB;                                   // inputs of k_bucket_reduce
-    const unsigned red_lanes = (unsigned)((nb1 + RED_K - 1) / RED_K);
+    unsigned K0 = 8;                                   // level-0 fan-in: <= 2^17 lanes, one full round of the chip
+    while (NB / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;
+    if (const char *e = getenv("PM_RED_K0")) K0 = (unsigned)atoi(e);        // developer knobs (powers of two)
+    unsigned R1 = 2;                                   // swept on MI355X (tools/sweep_reduce.sh): K0 = 16, R = 2 at 2^21 buckets
+    if (const char *e = getenv("PM_RED_R")) R1 = (unsigned)atoi(e);
+    const size_t lanes0 = (NB + K0 - 1) / K0, lanes1 = (lanes0 + R1 - 1) / R1, blocks0 = (lanes0 + 255) / 256, blocks1 = (lanes1 + 255) / 256;
+    const unsigned red_lanes = (unsigned)((NB + RED_K - 1) / RED_K);              // single-level path (small NB)
     unsigned red_block = 64;
     while (red_block < red_lanes && red_block < 256) red_block <<= 1;
     const unsigned bpw = (red_lanes + red_block - 1) / red_block;
-    PM_HIP(ctx, ws.wsum.reserve((lanes0 + blocks0 + bpw + 4) * sizeof(XYZZ<C>)));
+    PM_HIP(ctx, ws.wsum.reserve((2 * lanes0 + blocks0 + bpw + 4) * sizeof(XYZZ<C>)));
     Fr *canon = ws.canon.as<Fr>();
     uint16_t *keys = (uint16_t *)ws.digits.p;
     uint32_t *vals = (uint32_t *)((uint8_t *)ws.digits.p + keys_bytes);
@@ -994,34 +1044,29 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
                            ws.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
         PM_HIP(ctx, hipGetLastError());
     }
-    XYZZ<C> hres[2];
+    XYZZ<C> hres;
     {
         StageTimer t(ctx, T_MSM_REDUCE);
-        XYZZ<C> *A = ws.wsum.as<XYZZ<C>>(), *parts0 = A + lanes0, *parts1 = parts0 + blocks0, *dres = parts1 + bpw;
+        XYZZ<C> *A = ws.wsum.as<XYZZ<C>>(), *Acc = A + lanes0, *parts = Acc + lanes0, *dres = parts + (blocks0 > bpw ? blocks0 : bpw);
         if (two_level) {
             hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
-                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), NB, lanes0, A, parts0);
+                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), NB, lanes0, K0, A, Acc);
             PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_sum_parts<C>, dim3(1), dim3(64), 0, ctx->stream, parts0, (unsigned)blocks0, dres);
+            hipLaunchKernelGGL(k_reduce_level1<C>, dim3((unsigned)blocks1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, A, Acc, lanes0,
+                               K0, R1, parts);
             PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL((k_bucket_reduce<C, true>), dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream, A,
-                               (const uint32_t *)nullptr, (unsigned)nb1, red_lanes, bpw, parts1);
+            hipLaunchKernelGGL(k_sum_final<C>, dim3(1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
         } else {
-            hipLaunchKernelGGL((k_bucket_reduce<C, false>), dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
-                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), (unsigned)nb1, red_lanes, bpw, parts1);
+            hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
+                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), (unsigned)NB, red_lanes, bpw, parts);
+            PM_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(k_sum_final<C>, dim3(1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, bpw, dres);
         }
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_sum_parts<C>, dim3(1), dim3(64), 0, ctx->stream, parts1, bpw, dres + 1);
-        PM_HIP(ctx, hipGetLastError());
-        PM_HIP(ctx, hipMemcpyAsync(hres, dres, sizeof(hres), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(ctx, hipMemcpyAsync(&hres, dres, sizeof(hres), hipMemcpyDeviceToHost, ctx->stream));
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // S = P0 + K0 * S1  (two-level)  or  S = S1
-    XYZZ<C> acc = xyzz_internal_to_std<C>(hres[1]);
-    if (two_level) {
-        for (unsigned k = 1; k < RED_K0; k <<= 1) acc = xyzz_dbl<C>(acc);
-        acc = xyzz_add<C>(acc, xyzz_internal_to_std<C>(hres[0]));
-    }
+    XYZZ<C> acc = xyzz_internal_to_std<C>(hres);
     *h_inf = acc.is_identity() ? 1 : 0;
     *h_out = xyzz_to_affine<C>(acc);
     return PM_OK;

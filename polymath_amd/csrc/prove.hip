@@ -334,10 +334,10 @@ static int msm_shard(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename 
     const Affine<C> *bases = (const Affine<C> *)pk->d_bases + pk->res_dev_off[which];
     Affine<C> r;
     int inf = 1;
-    if (pk->tables.c) {   // window tables cover every resident point; locate this MSM's slice inside window 0
-        MsmTables tb = pk->tables;
-        tb.base_index = pk->res_dev_off[which];
-        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)pk->d_bases, d_scalars + lo, (size_t)(hi - lo), &r, &inf, &tb));
+    if (pk->tables[which].c) {   // this MSM's own window tables (window 0 = its resident slice)
+        MsmTables tb = pk->tables[which];
+        tb.base_index = 0;
+        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)pk->d_tab[which], d_scalars + lo, (size_t)(hi - lo), &r, &inf, &tb));
     } else {
         PM_TRY(msm_run<C>(ctx, bases, d_scalars + lo, (size_t)(hi - lo), &r, &inf));
     }

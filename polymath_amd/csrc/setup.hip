@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "internal.h"
+#include <algorithm>
 #include "fq28.cuh"
 
 namespace pm {
@@ -255,8 +256,13 @@ int tables_build(pm_ctx *ctx, Affine<C> *d_table, size_t count, const MsmTables 
     return PM_OK;
 }
 
-// One layout for the whole key: minimise  W * (pairs of all MSMs) + n_msm * 3 * 2^(c-1)  (3 ~ mixed-add
-// equivalents the bucket reduction pays per bucket), subject to W * resident < 2^31 (u32 table indices).
+// Layout of one table set.  Cost model in units of one mixed add at full throughput (0.148 ns measured,
+// 6.75 G adds/s):  E = W * pairs bucket entries;
+//   accumulate = max(E, (E / buckets) * 135e3)   one lane per bucket: a lane's chain of mixed adds costs ~20 us
+//                                                each, so few, long buckets leave the machine latency-bound;
+//   reduce     = 8.1e6 + 2.7 * buckets           measured 1.41 ms at 2^19 and 2.04 ms at 2^21 buckets: a
+//                                                fixed dependent-add chain plus 2 full adds per bucket;
+// subject to W * resident < 2^31 (u32 table indices).
 static void tables_layout(MsmTables &t, unsigned nwin) {
     const unsigned total = 256, base = total / nwin, rem = total % nwin;
     t.nwin = nwin;
@@ -279,7 +285,9 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
         tables_layout(t, nwin);
         if (t.c < 4 || t.c > 23) continue;
         if ((double)nwin * (double)resident_points >= 2147483648.0) continue;
-        double cost = (double)nwin * (double)total_pairs + (double)n_msm * 3.0 * (double)((size_t)1 << (t.c - 1));
+        const double E = (double)nwin * (double)total_pairs, NB = (double)((size_t)1 << (t.c - 1));
+        const double acc = std::max(E, E / NB * 135e3);
+        double cost = acc + (double)n_msm * (8.1e6 + 2.7 * NB);
         if (cost < best) { best = cost; best_t = t; }
     }
     if (const char *e = getenv("PM_TABLE_C")) {   // developer knob for tuning sweeps: widest window

@@ -171,6 +171,7 @@ class Polymath:
         self.curve, self.field = curve, Field(curve)
         self.transcript_cls = TRANSCRIPTS[transcript] if isinstance(transcript, str) else transcript
         self.ctx = ctx if ctx is not None else api.Context(device)
+        self.collect_timings, self.phase_timings = False, []    # per-phase stage timings (pm_last_timings), opt-in
 
     # circuit_specific_setup (lib.rs:63-70) -> generate_proving_key (generator.rs:24-167)
     def setup(self, circuit, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1):
@@ -208,6 +209,8 @@ class Polymath:
             rc, a_xy, a_inf, c_xy, c_inf = pk.phase1(x_limbs, w_limbs, f.fr_limbs(r_a))
         if rc:
             raise PolymathProverError(1, rc)
+        if self.collect_timings:
+            self.phase_timings = [self.ctx.timings()]
         if combine:
             a_xy, a_inf = combine(a_xy, a_inf)
             c_xy, c_inf = combine(c_xy, c_inf)
@@ -220,6 +223,8 @@ class Polymath:
         rc, u_at = pk.phase2(f.fr_limbs([x1])[0])
         if rc:
             raise PolymathProverError(2, rc)
+        if self.collect_timings:
+            self.phase_timings.append(self.ctx.timings())
         a_at_x1 = (f.fr_int(u_at) + (r_a[0] + r_a[1] * x1) * y1_alpha) % r       # :132
         y1_gamma = pow(y1_inv, MINUS_GAMMA, r)                                   # :134
         pi_at_x1 = self.compute_pi_at_x1(pk.n, pk.omega, instance, x1, y1_gamma)  # :135
@@ -229,6 +234,8 @@ class Polymath:
         rc, d_xy, d_inf = pk.phase3(L(x1), L(x2), L(a_at_x1), L(c_at_x1))
         if rc:
             raise PolymathProverError(3, rc)
+        if self.collect_timings:
+            self.phase_timings.append(self.ctx.timings())
         if combine:
             d_xy, d_inf = combine(d_xy, d_inf)
         return Proof(f, a_g1, c_g1, a_at_x1, f.g1_affine(d_xy, d_inf))           # :231-236
