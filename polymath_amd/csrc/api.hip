@@ -195,13 +195,19 @@ static int bases_precompute_impl(pm_ctx *ctx, pm_bases *b) {
     void *d_new = nullptr;
     PM_HIP(ctx, hipMalloc(&d_new, b->len * tb.nwin * sizeof(Affine<C>)));
     PM_HIP(ctx, hipMemcpyAsync(d_new, b->d_points, b->len * sizeof(Affine<C>), hipMemcpyDeviceToDevice, ctx->stream));
-    int st = tables_build<C>(ctx, (Affine<C> *)d_new, b->len, tb);
+    void *d_flags = nullptr;
+    hipError_t he = hipMalloc(&d_flags, b->len);
+    int st = he == hipSuccess ? infinity_flags<C>(ctx, (const Affine<C> *)d_new, b->len, (unsigned char *)d_flags) : PM_ERR_HIP;
+    if (st == PM_OK) st = tables_build<C>(ctx, (Affine<C> *)d_new, b->len, tb);
     if (st != PM_OK) {
         (void)hipFree(d_new);
+        if (d_flags) (void)hipFree(d_flags);
         return st;
     }
     PM_HIP(ctx, hipFree(b->d_points));
     b->d_points = d_new;
+    b->d_inf = d_flags;
+    tb.inf = (const unsigned char *)d_flags;
     b->tables = tb;
     return PM_OK;
 }
@@ -218,6 +224,7 @@ extern "C" void pm_bases_free(pm_bases *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->d_points) (void)hipFree(b->d_points);
+    if (b->d_inf) (void)hipFree(b->d_inf);
     delete b;
 }
 
@@ -327,8 +334,10 @@ static void pk_release(pm_pk *pk) {
         if (pk->d_val[i]) (void)hipFree(pk->d_val[i]);
     }
     if (pk->d_bases) (void)hipFree(pk->d_bases);
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k) {
         if (pk->d_tab[k]) (void)hipFree(pk->d_tab[k]);
+        if (pk->d_tab_inf[k]) (void)hipFree(pk->d_tab_inf[k]);
+    }
     delete pk;
 }
 
@@ -459,7 +468,10 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
         if (!len || !tb[k].c) continue;
         PM_HIP(ctx, hipMalloc(&pk->d_tab[k], len * tb[k].nwin * sizeof(Affine<C>)));
         PM_HIP(ctx, hipMemcpyAsync(pk->d_tab[k], d + pk->res_dev_off[k], len * sizeof(Affine<C>), hipMemcpyDeviceToDevice, ctx->stream));
+        PM_HIP(ctx, hipMalloc(&pk->d_tab_inf[k], len));
+        PM_TRY(infinity_flags<C>(ctx, (const Affine<C> *)pk->d_tab[k], (size_t)len, (unsigned char *)pk->d_tab_inf[k]));
         PM_TRY(tables_build<C>(ctx, (Affine<C> *)pk->d_tab[k], (size_t)len, tb[k]));
+        tb[k].inf = (const unsigned char *)pk->d_tab_inf[k];
         pk->tables[k] = tb[k];
     }
     return PM_OK;

@@ -89,6 +89,7 @@ struct MsmTables {
     unsigned char width[32] = {0};   // bits of window w
     size_t stride = 0;               // points per window
     size_t base_index = 0;           // first point of this MSM inside window 0
+    const unsigned char *inf = nullptr;   // device: one flag byte per point of window 0 (1 = point at infinity)
 };
 
 struct TwiddleCache {
@@ -104,6 +105,7 @@ struct pm_bases {
     int device;
     size_t len;
     void *d_points;  // Affine<C>[len], or the window tables [nwin][len] after pm_bases_precompute
+    void *d_inf;     // infinity flags of the table set (tables.inf)
     pm::MsmTables tables;
 };
 
@@ -132,7 +134,7 @@ struct pm_pk {
     // Window tables, ONE SET PER MERGED MSM (its own window width: the optimum depends on the pair count):
     // d_tab[k] holds [nwin_k][res_hi[k] - res_lo[k]] points, window 0 being a copy of the MSM's resident slice.
     pm::MsmTables tables[3];
-    void *d_tab[3];
+    void *d_tab[3], *d_tab_inf[3];   // tables and their infinity flags (tables[k].inf)
 };
 
 struct PendingTimer {
@@ -176,6 +178,9 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
 // fill windows 1..nwin-1 of a table array whose window 0 holds `count` internal-form affine points
 template <class C>
 int tables_build(pm_ctx *ctx, Affine<C> *d_table, size_t count, const MsmTables &t);
+// flags[i] = 1 iff points[i] is the point at infinity (all-zero x, y)
+template <class C>
+int infinity_flags(pm_ctx *ctx, const Affine<C> *d_points, size_t count, unsigned char *d_flags);
 
 template <class C>
 int bases_generate_multiples(pm_ctx *ctx, size_t len, Affine<C> *d_out);

@@ -395,20 +395,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // kernels (k_hist2 / k_scatter2) exactly like a Pippenger window.
 // =====================================================================================================
 constexpr unsigned LO_BITS = 15;
-constexpr unsigned TBL_PER_BLOCK = 512;    // scalars per partition workgroup (2 per lane)
+constexpr unsigned TBL_PER_BLOCK = 512;    // scalars per counting workgroup (2 per lane)
 
-// canonical scalars (zeroed when the base is the point at infinity): digits are then pure bit extraction
-template <class C>
-__global__ void k_canon(const Fp<typename C::FrP> *scalars, const Affine<C> *bases0, Fp<typename C::FrP> *canon, size_t len) {
-    typedef typename C::FrP P;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
+// canonical scalar (zero when the base is the point at infinity -- `inf` holds one flag byte per point of
+// window 0, setup.hip: tables_build): digits are then pure bit extraction
+template <class P>
+__device__ __forceinline__ Fp<P> canon_scalar(const Fp<P> *scalars, const unsigned char *inf, size_t i) {
     Fp<P> k = from_mont<P>(scalars[i]);
-    const uint32_t *bx = (const uint32_t *)&bases0[i];
-    uint32_t any = 0;
-#pragma unroll
-    for (int t = 0; t < 2 * C::FqP::N; ++t) any |= bx[t];
-    canon[i] = any ? k : Fp<P>::zero();
+    if (inf[i]) k = Fp<P>::zero();
+    return k;
 }
 
 // signed digit w of canonical scalar k: returns false for a zero digit; bucket = |d| - 1
@@ -445,7 +440,7 @@ __device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned lo, unsigned c
 }
 
 template <class P>
-__global__ __launch_bounds__(256) void k_tbl_count(const Fp<P> *canon, size_t len, WinLayout L, unsigned regions,
+__global__ __launch_bounds__(256) void k_tbl_count(const Fp<P> *scalars, const unsigned char *inf, size_t len, WinLayout L, unsigned regions,
                                                    uint32_t *region_count) {
     __shared__ uint32_t cnt[1024];
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
@@ -453,7 +448,7 @@ __global__ __launch_bounds__(256) void k_tbl_count(const Fp<P> *canon, size_t le
     for (unsigned q = 0; q < TBL_PER_BLOCK / 256; ++q) {
         size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
         if (i >= len) break;
-        Fp<P> k = canon[i];
+        const Fp<P> k = canon_scalar<P>(scalars, inf, i);
         uint32_t carry = 0, b, neg;
         for (unsigned w = 0; w < L.nwin; ++w)
             if (digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
@@ -481,49 +476,77 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *region_
     if (t == 1023) region_off[regions] = s[1023];
 }
 
-// entry (i, w) -> region of its bucket: key = low LO_BITS of the bucket, val = table index << 1 | negate
+// entry (i, w) -> region of its bucket: key = low LO_BITS of the bucket, val = table index << 1 | negate.
+// One scalar per lane.  The workgroup's entries are staged through LDS in region order so that the global
+// stores are coalesced (consecutive lanes -> consecutive addresses of a region's run).
+//   LDS: cnt[1024] | start[1024] | delta[1024] | staged vals (u32 x blockDim nwin) | staged region<<16|key (u32 x same)
 template <class P>
-__global__ __launch_bounds__(256) void k_tbl_partition(const Fp<P> *canon, size_t len, WinLayout L, unsigned regions,
-                                                       const uint32_t *region_off, uint32_t *region_cursor, size_t tbl_stride,
-                                                       size_t base_index, uint16_t *keys, uint32_t *vals) {
-    __shared__ uint32_t cnt[1024], base[1024];
-    for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
+__global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, const unsigned char *inf, size_t len, WinLayout L,
+                                                       unsigned regions, const uint32_t *region_off, uint32_t *region_cursor,
+                                                       size_t tbl_stride, size_t base_index, uint16_t *keys, uint32_t *vals) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *cnt = (uint32_t *)smem_raw, *start = cnt + 1024, *delta = start + 1024;
+    uint32_t *st_val = delta + 1024, *st_key = st_val + (size_t)blockDim.x * L.nwin;
+    __shared__ uint32_t tot;
+    const unsigned t = threadIdx.x, BD = blockDim.x;
+    for (unsigned r = t; r < 1024; r += BD) cnt[r] = 0;
     __syncthreads();
     // pass 1: count per region -- the counting atomic returns the entry's rank inside this workgroup, kept in
-    // registers (QN scalars x <= 32 windows per lane) so that pass 2 needs no second LDS atomic
-    constexpr unsigned QN = TBL_PER_BLOCK / 256;
-    uint32_t rank[QN][32];
+    // registers (<= 32 windows per lane) so that pass 2 needs no second LDS atomic
+    const size_t i = (size_t)blockIdx.x * BD + t;
+    uint32_t rank[32];
+    Fp<P> k = Fp<P>::zero();
+    if (i < len) {
+        k = canon_scalar<P>(scalars, inf, i);
+        uint32_t carry = 0, b, neg;
 #pragma unroll
-    for (unsigned q = 0; q < QN; ++q) {
-        const size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
-        if (i < len) {
-            const Fp<P> k = canon[i];
-            uint32_t carry = 0, b, neg;
-#pragma unroll
-            for (unsigned w = 0; w < 32; ++w)
-                if (w < L.nwin && digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) rank[q][w] = atomicAdd(&cnt[b >> LO_BITS], 1u);
-        }
+        for (unsigned w = 0; w < 32; ++w)
+            if (w < L.nwin && digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) rank[w] = atomicAdd(&cnt[b >> LO_BITS], 1u);
     }
     __syncthreads();
-    for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) {
-        uint32_t v = cnt[r];
-        base[r] = v ? region_off[r] + atomicAdd(&region_cursor[r], v) : 0u;
+    // inclusive scan of cnt over the (<= 1024) regions, blockDim lanes x (1024 / blockDim) values each
+    for (unsigned r = t; r < 1024; r += BD) start[r] = cnt[r];
+    __syncthreads();
+    for (unsigned o = 1; o < 1024; o <<= 1) {
+        uint32_t a[4];
+#pragma unroll
+        for (unsigned q = 0; q < 4; ++q) {
+            const unsigned r = t + q * BD;
+            a[q] = (r < 1024 && r >= o) ? start[r - o] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (unsigned q = 0; q < 4; ++q) {
+            const unsigned r = t + q * BD;
+            if (r < 1024) start[r] += a[q];
+        }
+        __syncthreads();
+    }
+    if (t == 0) tot = start[1023];
+    __syncthreads();
+    for (unsigned r = t; r < 1024; r += BD) {
+        const uint32_t c = cnt[r], ex = start[r] - c;
+        const uint32_t gpos = (c && r < regions) ? region_off[r] + atomicAdd(&region_cursor[r], c) : 0u;
+        delta[r] = gpos - ex;          // global position = delta[region] + staged slot
+        cnt[r] = ex;                   // cnt now = first staged slot of the region
     }
     __syncthreads();
+    if (i < len) {
+        uint32_t carry = 0, b, neg;
 #pragma unroll
-    for (unsigned q = 0; q < QN; ++q) {
-        const size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
-        if (i < len) {
-            const Fp<P> k = canon[i];
-            uint32_t carry = 0, b, neg;
-#pragma unroll
-            for (unsigned w = 0; w < 32; ++w)
-                if (w < L.nwin && digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) {
-                    const uint32_t pos = base[b >> LO_BITS] + rank[q][w];
-                    keys[pos] = (uint16_t)(b & ((1u << LO_BITS) - 1));
-                    vals[pos] = (uint32_t)(((size_t)w * tbl_stride + base_index + i) << 1) | neg;
-                }
-        }
+        for (unsigned w = 0; w < 32; ++w)
+            if (w < L.nwin && digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) {
+                const uint32_t rg = b >> LO_BITS, slot = cnt[rg] + rank[w];
+                st_key[slot] = (rg << 16) | (b & ((1u << LO_BITS) - 1));
+                st_val[slot] = (uint32_t)(((size_t)w * tbl_stride + base_index + i) << 1) | neg;
+            }
+    }
+    __syncthreads();
+    const uint32_t total = tot;
+    for (uint32_t s = t; s < total; s += BD) {
+        const uint32_t kv = st_key[s], pos = delta[kv >> 16] + s;
+        keys[pos] = (uint16_t)kv;
+        vals[pos] = st_val[s];
     }
 }
 
@@ -934,7 +957,6 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
     const size_t max_tasks = NB + Emax / seg + 1;
     const unsigned chunk = 1u << RS_CHUNK_LOG;
     const size_t keys_bytes = (Emax * 2 + 15) & ~(size_t)15;
-    PM_HIP(ctx, ws.canon.reserve(len * sizeof(Fr)));
     PM_HIP(ctx, ws.digits.reserve(keys_bytes + Emax * 4));
     PM_HIP(ctx, ws.sorted.reserve(Emax * 4));
     PM_HIP(ctx, ws.counts.reserve(2 * NB * 4));
@@ -955,7 +977,7 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
     while (red_block < red_lanes && red_block < 256) red_block <<= 1;
     const unsigned bpw = (red_lanes + red_block - 1) / red_block;
     PM_HIP(ctx, ws.wsum.reserve((2 * lanes0 + blocks0 + bpw + 4) * sizeof(XYZZ<C>)));
-    Fr *canon = ws.canon.as<Fr>();
+    const unsigned char *inf = tb.inf + tb.base_index;
     uint16_t *keys = (uint16_t *)ws.digits.p;
     uint32_t *vals = (uint32_t *)((uint8_t *)ws.digits.p + keys_bytes);
     uint32_t *counts = ws.counts.as<uint32_t>(), *cursor = counts + NB;
@@ -964,19 +986,19 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
         StageTimer t(ctx, T_MSM_SORT);
         PM_HIP(ctx, hipMemsetAsync(counts, 0, 2 * NB * 4, ctx->stream));
         PM_HIP(ctx, hipMemsetAsync(region_count, 0, (size_t)regions * 4, ctx->stream));
-        hipLaunchKernelGGL(k_canon<C>, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, d_scalars,
-                           d_table + tb.base_index, canon, len);
-        PM_HIP(ctx, hipGetLastError());
-        const unsigned pblocks = (unsigned)((len + TBL_PER_BLOCK - 1) / TBL_PER_BLOCK);
+        const unsigned cblocks = (unsigned)((len + TBL_PER_BLOCK - 1) / TBL_PER_BLOCK);
         WinLayout L;
         L.nwin = nwin;
         for (unsigned w = 0; w < 32; ++w) { L.off[w] = (unsigned short)(w < nwin ? tb.off[w] : 0); L.width[w] = w < nwin ? tb.width[w] : 0; }
-        hipLaunchKernelGGL(k_tbl_count<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, L, regions, region_count);
+        hipLaunchKernelGGL(k_tbl_count<FrP>, dim3(cblocks), dim3(256), 0, ctx->stream, d_scalars, inf, len, L, regions, region_count);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, region_count, region_off, region_cursor, regions);
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_tbl_partition<FrP>, dim3(pblocks), dim3(256), 0, ctx->stream, canon, len, L, regions, region_off,
-                           region_cursor, tb.stride, tb.base_index, keys, vals);
+        const unsigned pbd = nwin <= 16 ? 512 : 256;                       // scalars per partition workgroup
+        const size_t plds = 3 * 1024 * 4 + (size_t)pbd * nwin * 8;
+        PM_HIP(ctx, hipFuncSetAttribute((const void *)k_tbl_partition<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+        hipLaunchKernelGGL(k_tbl_partition<FrP>, dim3((unsigned)((len + pbd - 1) / pbd)), dim3(pbd), plds, ctx->stream, d_scalars, inf, len, L,
+                           regions, region_off, region_cursor, tb.stride, tb.base_index, keys, vals);
         PM_HIP(ctx, hipGetLastError());
         const unsigned sblocks = (unsigned)((Emax + chunk - 1) / chunk);
         const unsigned ntiles = (unsigned)((NB + SCAN_TILE - 1) / SCAN_TILE);

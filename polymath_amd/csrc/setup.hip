@@ -256,6 +256,25 @@ int tables_build(pm_ctx *ctx, Affine<C> *d_table, size_t count, const MsmTables 
     return PM_OK;
 }
 
+template <class C>
+__global__ void k_inf_flags(const Affine<C> *pts, size_t count, unsigned char *flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t *w = (const uint32_t *)&pts[i];
+    uint32_t any = 0;
+#pragma unroll
+    for (int t = 0; t < 2 * C::FqP::N; ++t) any |= w[t];
+    flags[i] = any ? 0 : 1;
+}
+
+template <class C>
+int infinity_flags(pm_ctx *ctx, const Affine<C> *d_points, size_t count, unsigned char *d_flags) {
+    if (!count) return PM_OK;
+    hipLaunchKernelGGL(k_inf_flags<C>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_points, count, d_flags);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+}
+
 // Layout of one table set.  Cost model in units of one mixed add at full throughput (0.148 ns measured,
 // 6.75 G adds/s):  E = W * pairs bucket entries;
 //   accumulate = max(E, (E / buckets) * 135e3)   one lane per bucket: a lane's chain of mixed adds costs ~20 us
@@ -304,7 +323,8 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
     template int fixed_base_batch<C>(pm_ctx *, const Fp<typename C::FrP> *, size_t, Affine<C> *);               \
     template int bases_generate_multiples<C>(pm_ctx *, size_t, Affine<C> *);                                    \
     template int bases_convert<C>(pm_ctx *, Affine<C> *, size_t, bool);                                          \
-    template int tables_build<C>(pm_ctx *, Affine<C> *, size_t, const MsmTables &);
+    template int tables_build<C>(pm_ctx *, Affine<C> *, size_t, const MsmTables &);                             \
+    template int infinity_flags<C>(pm_ctx *, const Affine<C> *, size_t, unsigned char *);
 PM_INST(BlsCurve)
 PM_INST(BnCurve)
 
