@@ -395,7 +395,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // kernels (k_hist2 / k_scatter2) exactly like a Pippenger window.
 // =====================================================================================================
 constexpr unsigned LO_BITS = 15;
-constexpr unsigned TBL_PER_BLOCK = 512;    // scalars per counting workgroup (2 per lane)
+
+// Inclusive scan of one value per lane across the workgroup (blockDim <= 1024): wave shuffles + one LDS hop
+// (2 barriers; the LDS Hillis-Steele it replaces needed 2 log2(n)).  wt: 64 words of LDS scratch.
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t *wt) {
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (unsigned o = 1; o < 64; o <<= 1) {
+        const uint32_t n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    if (lane == 63) wt[wave] = v;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < (blockDim.x >> 6) ? wt[lane] : 0u;
+#pragma unroll
+        for (unsigned o = 1; o < 16; o <<= 1) {
+            const uint32_t n = __shfl_up(w, o, 64);
+            if (lane >= o) w += n;
+        }
+        wt[lane] = w;
+    }
+    __syncthreads();
+    if (wave) v += wt[wave - 1];
+    return v;
+}
 
 // canonical scalar (zero when the base is the point at infinity -- `inf` holds one flag byte per point of
 // window 0, setup.hip: tables_build): digits are then pure bit extraction
@@ -407,55 +431,77 @@ __device__ __forceinline__ Fp<P> canon_scalar(const Fp<P> *scalars, const unsign
 }
 
 // signed digit w of canonical scalar k: returns false for a zero digit; bucket = |d| - 1
-struct WinLayout {   // by-value kernel argument (MsmTables::off / width)
-    unsigned nwin;
-    unsigned short off[32];
-    unsigned char width[32];
-};
+// Balanced window layout as a function of the window count (the same formula as setup.hip: tables_layout).
+// The kernels are instantiated per NWIN so that every bit offset, shift and limb index is an immediate:
+// with a run-time layout the compiler parks the scalar in LDS and fetches offsets with vector loads.
+__host__ __device__ constexpr unsigned win_width(unsigned nwin, unsigned w) { return 256 / nwin + (w < 256 % nwin ? 1u : 0u); }
+__host__ __device__ constexpr unsigned win_off(unsigned nwin, unsigned w) { return w * (256 / nwin) + (w < 256 % nwin ? w : 256 % nwin); }
 
 template <class P>
 __device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned lo, unsigned c, uint32_t &carry, uint32_t &bucket, uint32_t &neg) {
     const uint32_t half = 1u << (c - 1), full = 1u << c, mask = full - 1;
-    unsigned limb = lo >> 5, off = lo & 31;
+    const unsigned limb = lo >> 5, off = lo & 31;
     uint32_t v = 0;
     if (limb < (unsigned)P::N) {
         uint64_t two = k.l[limb];
         if (limb + 1 < (unsigned)P::N) two |= (uint64_t)k.l[limb + 1] << 32;
         v = (uint32_t)(two >> off) & mask;
     }
-    uint32_t d = v + carry;
-    if (d > half) {
-        uint32_t m = full - d;
-        carry = 1;
-        if (!m) return false;
-        bucket = m - 1;
-        neg = 1;
-        return true;
-    }
-    carry = 0;
-    if (!d) return false;
-    bucket = d - 1;
-    neg = 0;
-    return true;
+    // branch-free: the callers unroll this over compile-time (lo, c), lane divergence here would cost
+    // an exec-mask region per window
+    const uint32_t d = v + carry;
+    const bool over = d > half;
+    const uint32_t m = over ? full - d : d;
+    carry = over ? 1u : 0u;
+    neg = carry;
+    bucket = m - 1;
+    return m != 0;
 }
 
-template <class P>
-__global__ __launch_bounds__(256) void k_tbl_count(const Fp<P> *scalars, const unsigned char *inf, size_t len, WinLayout L, unsigned regions,
-                                                   uint32_t *region_count) {
+// Region populations PER WORKGROUP: block_cnt[workgroup][region], with the same workgroup -> scalar mapping
+// as k_tbl_partition (one scalar per lane).  A column-wise scan (k_block_scan) turns them into each
+// workgroup's offset inside each region, so neither kernel touches a global atomic: 41 K workgroups x 64
+// regions hammering 64 addresses serialised in L2 and cost more than the rest of the kernel.
+template <class P, unsigned NWIN>
+__global__ __launch_bounds__(512) void k_tbl_count(const Fp<P> *scalars, const unsigned char *inf, size_t len, unsigned regions,
+                                                   uint32_t *block_cnt) {
     __shared__ uint32_t cnt[1024];
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
     __syncthreads();
-    for (unsigned q = 0; q < TBL_PER_BLOCK / 256; ++q) {
-        size_t i = (size_t)blockIdx.x * TBL_PER_BLOCK + q * 256 + threadIdx.x;
-        if (i >= len) break;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) {
         const Fp<P> k = canon_scalar<P>(scalars, inf, i);
         uint32_t carry = 0, b, neg;
-        for (unsigned w = 0; w < L.nwin; ++w)
-            if (digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
+#pragma unroll
+        for (unsigned w = 0; w < NWIN; ++w)
+            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
     }
     __syncthreads();
-    for (unsigned r = threadIdx.x; r < regions; r += blockDim.x)
-        if (cnt[r]) atomicAdd(&region_count[r], cnt[r]);
+    for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) block_cnt[(size_t)blockIdx.x * regions + r] = cnt[r];
+}
+
+// Column r of block_cnt[nblocks][regions] -> exclusive prefix over the workgroups (in place), total -> region_count[r].
+__global__ __launch_bounds__(1024) void k_block_scan(uint32_t *block_cnt, unsigned nblocks, unsigned regions, uint32_t *region_count) {
+    __shared__ uint32_t s[1024];
+    const unsigned r = blockIdx.x, t = threadIdx.x;
+    const unsigned per = (nblocks + 1023) / 1024, b0 = t * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    uint32_t sum = 0;
+    for (unsigned b = b0; b < b1; ++b) sum += block_cnt[(size_t)b * regions + r];
+    s[t] = sum;
+    __syncthreads();
+    for (unsigned o = 1; o < 1024; o <<= 1) {
+        const uint32_t a = t >= o ? s[t - o] : 0u;
+        __syncthreads();
+        s[t] += a;
+        __syncthreads();
+    }
+    uint32_t run = s[t] - sum;
+    for (unsigned b = b0; b < b1; ++b) {
+        const uint32_t v = block_cnt[(size_t)b * regions + r];
+        block_cnt[(size_t)b * regions + r] = run;
+        run += v;
+    }
+    if (t == 1023) region_count[r] = s[1023];
 }
 
 // region_off = exclusive scan of region_count (regions <= 1024); also clears the claim cursors
@@ -479,63 +525,47 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *region_
 // entry (i, w) -> region of its bucket: key = low LO_BITS of the bucket, val = table index << 1 | negate.
 // One scalar per lane.  The workgroup's entries are staged through LDS in region order so that the global
 // stores are coalesced (consecutive lanes -> consecutive addresses of a region's run).
-//   LDS: cnt[1024] | start[1024] | delta[1024] | staged vals (u32 x blockDim nwin) | staged region<<16|key (u32 x same)
-template <class P>
-__global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, const unsigned char *inf, size_t len, WinLayout L,
-                                                       unsigned regions, const uint32_t *region_off, uint32_t *region_cursor,
-                                                       size_t tbl_stride, size_t base_index, uint16_t *keys, uint32_t *vals) {
+//   LDS: cnt[1024] | delta[1024] | staged vals (u32 x blockDim nwin) | staged region<<16|key (u32 x same)
+template <class P, unsigned NWIN>
+__global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, const unsigned char *inf, size_t len,
+                                                       unsigned regions, const uint32_t *region_off, const uint32_t *block_off, size_t tbl_stride, size_t base_index, uint16_t *keys,
+                                                       uint32_t *vals) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t *cnt = (uint32_t *)smem_raw, *start = cnt + 1024, *delta = start + 1024;
-    uint32_t *st_val = delta + 1024, *st_key = st_val + (size_t)blockDim.x * L.nwin;
-    __shared__ uint32_t tot;
+    uint32_t *cnt = (uint32_t *)smem_raw, *delta = cnt + 1024;
+    uint32_t *st_val = delta + 1024, *st_key = st_val + (size_t)blockDim.x * NWIN;
+    __shared__ uint32_t tot, wt[64];
     const unsigned t = threadIdx.x, BD = blockDim.x;
-    for (unsigned r = t; r < 1024; r += BD) cnt[r] = 0;
+    for (unsigned r = t; r < regions; r += BD) cnt[r] = 0;
     __syncthreads();
     // pass 1: count per region -- the counting atomic returns the entry's rank inside this workgroup, kept in
-    // registers (<= 32 windows per lane) so that pass 2 needs no second LDS atomic
+    // registers (NWIN per lane) so that pass 2 needs no second LDS atomic
     const size_t i = (size_t)blockIdx.x * BD + t;
-    uint32_t rank[32];
+    uint32_t rank[NWIN];
     Fp<P> k = Fp<P>::zero();
     if (i < len) {
         k = canon_scalar<P>(scalars, inf, i);
         uint32_t carry = 0, b, neg;
 #pragma unroll
-        for (unsigned w = 0; w < 32; ++w)
-            if (w < L.nwin && digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) rank[w] = atomicAdd(&cnt[b >> LO_BITS], 1u);
+        for (unsigned w = 0; w < NWIN; ++w)
+            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) rank[w] = atomicAdd(&cnt[b >> LO_BITS], 1u);
     }
     __syncthreads();
-    // inclusive scan of cnt over the (<= 1024) regions, blockDim lanes x (1024 / blockDim) values each
-    for (unsigned r = t; r < 1024; r += BD) start[r] = cnt[r];
-    __syncthreads();
-    for (unsigned o = 1; o < 1024; o <<= 1) {
-        uint32_t a[4];
-#pragma unroll
-        for (unsigned q = 0; q < 4; ++q) {
-            const unsigned r = t + q * BD;
-            a[q] = (r < 1024 && r >= o) ? start[r - o] : 0u;
+    {   // exclusive scan over the regions (regions <= blockDim, checked by the host): lane r owns region r
+        const uint32_t c = t < regions ? cnt[t] : 0u;
+        const uint32_t incl = block_inclusive_scan(c, wt);
+        if (t < regions) {
+            const uint32_t ex = incl - c;
+            cnt[t] = ex;                                                                  // first staged slot of the region
+            delta[t] = region_off[t] + block_off[(size_t)blockIdx.x * regions + t] - ex;  // global = delta[region] + slot
         }
-        __syncthreads();
-#pragma unroll
-        for (unsigned q = 0; q < 4; ++q) {
-            const unsigned r = t + q * BD;
-            if (r < 1024) start[r] += a[q];
-        }
-        __syncthreads();
-    }
-    if (t == 0) tot = start[1023];
-    __syncthreads();
-    for (unsigned r = t; r < 1024; r += BD) {
-        const uint32_t c = cnt[r], ex = start[r] - c;
-        const uint32_t gpos = (c && r < regions) ? region_off[r] + atomicAdd(&region_cursor[r], c) : 0u;
-        delta[r] = gpos - ex;          // global position = delta[region] + staged slot
-        cnt[r] = ex;                   // cnt now = first staged slot of the region
+        if (t == BD - 1) tot = incl;
     }
     __syncthreads();
     if (i < len) {
         uint32_t carry = 0, b, neg;
 #pragma unroll
-        for (unsigned w = 0; w < 32; ++w)
-            if (w < L.nwin && digit_at<P>(k, L.off[w], L.width[w], carry, b, neg)) {
+        for (unsigned w = 0; w < NWIN; ++w)
+            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) {
                 const uint32_t rg = b >> LO_BITS, slot = cnt[rg] + rank[w];
                 st_key[slot] = (rg << 16) | (b & ((1u << LO_BITS) - 1));
                 st_val[slot] = (uint32_t)(((size_t)w * tbl_stride + base_index + i) << 1) | neg;
@@ -642,7 +672,7 @@ __global__ __launch_bounds__(1024) void k_region_pass_staged(const uint16_t *key
                                                              unsigned nseg, unsigned bin_shift, unsigned nbins,
                                                              const uint32_t *out_off, uint32_t *cursor, uint32_t *sorted,
                                                              uint16_t *keys_out, uint32_t *vals_out) {
-    __shared__ uint32_t h[ST_MAX_BINS], start[ST_MAX_BINS], delta[ST_MAX_BINS];
+    __shared__ uint32_t h[ST_MAX_BINS], delta[ST_MAX_BINS], wt[64];
     __shared__ uint32_t st_val[ST_CHUNK];
     __shared__ uint16_t st_key[ST_CHUNK];
     const uint32_t total = seg_off[nseg];
@@ -677,21 +707,16 @@ __global__ __launch_bounds__(1024) void k_region_pass_staged(const uint16_t *key
             }
         }
         __syncthreads();
-        // exclusive scan of h over the bins (<= 256) by the first 256 lanes; claim the global runs
-        if (t < ST_MAX_BINS) start[t] = t < nbins ? h[t] : 0u;
-        __syncthreads();
-        for (unsigned o = 1; o < ST_MAX_BINS; o <<= 1) {
-            uint32_t a = (t < ST_MAX_BINS && t >= o) ? start[t - o] : 0u;
-            __syncthreads();
-            if (t < ST_MAX_BINS) start[t] += a;
-            __syncthreads();
-        }
-        if (t < nbins) {
-            const uint32_t c = h[t], ex = start[t] - c;      // exclusive prefix
-            const size_t g = (size_t)r * nbins + t;
-            const uint32_t gpos = c ? out_off[g] + atomicAdd(&cursor[g], c) : 0u;
-            delta[t] = gpos - ex;                              // global position = delta[bin] + staged slot
-            h[t] = ex;                                         // h now = local start of the bin
+        {   // exclusive scan of h over the bins (lane b owns bin b); claim the global runs
+            const uint32_t c = t < nbins ? h[t] : 0u;
+            const uint32_t incl = block_inclusive_scan(c, wt);
+            if (t < nbins) {
+                const uint32_t ex = incl - c;
+                const size_t g = (size_t)r * nbins + t;
+                const uint32_t gpos = c ? out_off[g] + atomicAdd(&cursor[g], c) : 0u;
+                delta[t] = gpos - ex;                          // global position = delta[bin] + staged slot
+                h[t] = ex;                                     // h now = local start of the bin
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -986,19 +1011,37 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
         StageTimer t(ctx, T_MSM_SORT);
         PM_HIP(ctx, hipMemsetAsync(counts, 0, 2 * NB * 4, ctx->stream));
         PM_HIP(ctx, hipMemsetAsync(region_count, 0, (size_t)regions * 4, ctx->stream));
-        const unsigned cblocks = (unsigned)((len + TBL_PER_BLOCK - 1) / TBL_PER_BLOCK);
-        WinLayout L;
-        L.nwin = nwin;
-        for (unsigned w = 0; w < 32; ++w) { L.off[w] = (unsigned short)(w < nwin ? tb.off[w] : 0); L.width[w] = w < nwin ? tb.width[w] : 0; }
-        hipLaunchKernelGGL(k_tbl_count<FrP>, dim3(cblocks), dim3(256), 0, ctx->stream, d_scalars, inf, len, L, regions, region_count);
-        PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, region_count, region_off, region_cursor, regions);
-        PM_HIP(ctx, hipGetLastError());
+        for (unsigned w = 0; w < nwin; ++w)   // the kernels derive the layout from nwin alone
+            if (tb.off[w] != win_off(nwin, w) || tb.width[w] != win_width(nwin, w)) return PM_ERR_INVALID_ARG;
         const unsigned pbd = nwin <= 16 ? 512 : 256;                       // scalars per partition workgroup
-        const size_t plds = 3 * 1024 * 4 + (size_t)pbd * nwin * 8;
-        PM_HIP(ctx, hipFuncSetAttribute((const void *)k_tbl_partition<FrP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-        hipLaunchKernelGGL(k_tbl_partition<FrP>, dim3((unsigned)((len + pbd - 1) / pbd)), dim3(pbd), plds, ctx->stream, d_scalars, inf, len, L,
-                           regions, region_off, region_cursor, tb.stride, tb.base_index, keys, vals);
+        if (regions > pbd) return PM_ERR_INVALID_ARG;                      // one scan lane per region
+        const size_t plds = 2 * 1024 * 4 + (size_t)pbd * nwin * 8;
+        const unsigned pblocks = (unsigned)((len + pbd - 1) / pbd);
+        PM_HIP(ctx, ws.block_cnt.reserve((size_t)pblocks * regions * 4));
+        uint32_t *block_cnt = ws.block_cnt.as<uint32_t>();
+        int launched = 0;
+#define PM_TBL_CASE(NW)                                                                                                     \
+        case NW:                                                                                                                \
+            hipLaunchKernelGGL((k_tbl_count<FrP, NW>), dim3(pblocks), dim3(pbd), 0, ctx->stream, d_scalars, inf, len, regions,  \
+                               block_cnt);                                                                                      \
+            hipLaunchKernelGGL(k_block_scan, dim3(regions), dim3(1024), 0, ctx->stream, block_cnt, pblocks, regions, region_count); \
+            hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, region_count, region_off, region_cursor,  \
+                               regions);                                                                                        \
+            if (hipFuncSetAttribute((const void *)k_tbl_partition<FrP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                    (int)plds) != hipSuccess) break;                                                            \
+            hipLaunchKernelGGL((k_tbl_partition<FrP, NW>), dim3(pblocks), dim3(pbd), plds, ctx->stream, d_scalars, inf, len,    \
+                               regions, region_off, block_cnt, tb.stride, tb.base_index, keys, vals);                           \
+            launched = 1;                                                                                                       \
+            break;
+        switch (nwin) {
+            PM_TBL_CASE(10) PM_TBL_CASE(11) PM_TBL_CASE(12) PM_TBL_CASE(13) PM_TBL_CASE(14) PM_TBL_CASE(15) PM_TBL_CASE(16)
+            PM_TBL_CASE(17) PM_TBL_CASE(18) PM_TBL_CASE(19) PM_TBL_CASE(20) PM_TBL_CASE(21) PM_TBL_CASE(22) PM_TBL_CASE(23)
+            PM_TBL_CASE(24) PM_TBL_CASE(25) PM_TBL_CASE(26) PM_TBL_CASE(27) PM_TBL_CASE(28) PM_TBL_CASE(29) PM_TBL_CASE(30)
+            PM_TBL_CASE(31) PM_TBL_CASE(32)
+            default: break;
+        }
+#undef PM_TBL_CASE
+        if (!launched) return PM_ERR_INVALID_ARG;
         PM_HIP(ctx, hipGetLastError());
         const unsigned sblocks = (unsigned)((Emax + chunk - 1) / chunk);
         const unsigned ntiles = (unsigned)((NB + SCAN_TILE - 1) / SCAN_TILE);
