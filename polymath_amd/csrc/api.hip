@@ -72,7 +72,7 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
                       &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra})
         b->release();
     for (auto &b : ctx->lvl) b.release();
-    for (auto &t : ctx->tw) { t.fwd.release(); t.inv.release(); }
+    for (auto &t : ctx->tw) { t.fwd.release(); t.inv.release(); t.fwd_int.release(); t.inv_int.release(); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

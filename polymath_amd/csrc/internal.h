@@ -95,7 +95,8 @@ struct MsmTables {
 struct TwiddleCache {
     int curve = -1;
     unsigned log_n = 0;
-    DevBuf fwd, inv;  // n/2 twiddles each
+    DevBuf fwd, inv;          // n/2 twiddles each, standard Montgomery form
+    DevBuf fwd_int, inv_int;  // the same powers in the reduced-radix internal form (ntt.hip butterflies)
 };
 
 }  // namespace pm
@@ -165,7 +166,7 @@ template <class C>
 int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d_data, unsigned log_n, bool inverse);
 // device table of omega_{2^log_n}^j (or its inverse), j < 2^(log_n - 1); cached per context
 template <class C>
-int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out);
+int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out, bool internal = false);
 
 // tables == nullptr (or c == 0): d_bases points at the MSM's first base.  Otherwise d_bases is the start of
 // the table array and tables->base_index locates the MSM's first base inside window 0.

@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "internal.h"
+#include "fq28.cuh"
 
 namespace pm {
 
@@ -21,14 +22,20 @@ struct PowTable {
     Fp<P> w[33];  // w[k] = omega^(2^k)
 };
 
-template <class P>
-__global__ void k_twiddles(Fp<P> *out, size_t count, PowTable<P> tab, unsigned nbits) {
+// out[j] = omega^j in the standard Montgomery form; out_int[j] = the same power as the plain integer
+// omega^j 2^(28 N) mod r ("internal" form of fq28.cuh): a reduced-radix product of a standard-form value with
+// it stays in the standard form, so the butterflies need no conversion of the data.
+template <class P, class RR>
+__global__ void k_twiddles(Fp<P> *out, Fp<P> *out_int, size_t count, PowTable<P> tab, unsigned nbits) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     Fp<P> acc = Fp<P>::one();
     for (unsigned k = 0; k < nbits; ++k)
         if ((j >> k) & 1) acc = mul<P>(acc, tab.w[k]);
     out[j] = acc;
+    Fp<P> c;
+    for (int i = 0; i < P::N; ++i) c.l[i] = RR::STD2INT[i];
+    out_int[j] = mul<P>(acc, c);
 }
 
 template <class P>
@@ -51,7 +58,10 @@ __global__ void k_bitrev(Fp<P> *a, unsigned log_n) {
 constexpr int LOG_TILE = 8;
 constexpr int COLS = 8;
 
-template <class P>
+// The butterfly product runs on 28-bit limbs (fq28.cuh: 200 carry-free mads + 70 instead of the dense
+// 32-bit-limb Montgomery product the compiler lowers to ~700 instructions, half of them register moves);
+// `tw` holds INTERNAL-form twiddles (k_twiddles), the tile stays canonical standard-form Fr.
+template <class P, class RR>
 __global__ __launch_bounds__(256) void k_ntt_pass(Fp<P> *a, const Fp<P> *tw, unsigned log_n, unsigned s0, unsigned ns,
                                                    unsigned log_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -68,18 +78,40 @@ __global__ __launch_bounds__(256) void k_ntt_pass(Fp<P> *a, const Fp<P> *tw, uns
         tile[e] = a[base + ((size_t)r << s0) + c];
     }
     __syncthreads();
+    const unsigned nbf = (rows >> 1) * cols;    // butterflies per stage
     for (unsigned t = 0; t < ns; ++t) {
         const unsigned s = s0 + t + 1;          // global stage, 1-based
         const unsigned half = 1u << t;          // distance in rows
-        for (unsigned e = tid; e < (rows >> 1) * cols; e += blockDim.x) {
-            unsigned c = e & (cols - 1), k = e >> log_cols;
-            unsigned r0 = ((k >> t) << (t + 1)) | (k & (half - 1)), r1 = r0 + half;
-            // position of the butterfly inside its size-2^s block: j = (r0 mod 2^(t+1)) * 2^s0 + lo
-            size_t j = ((size_t)(r0 & (half - 1)) << s0) + lo0 + c;
-            Fp<P> w = tw[j << (log_n - s)];
-            Fp<P> x = tile[r0 * cols + c], y = mul<P>(tile[r1 * cols + c], w);
+        auto bfly = [&](unsigned r0, unsigned r1, unsigned c, const Fp<P> &w) {
+            const Fp<P> x = tile[r0 * cols + c], y0 = tile[r1 * cols + c];
+            Fp<P> y;
+            f28_pack_reduced<RR>(f28_mul<RR>(f28_unpack<RR>(y0.l), f28_unpack<RR>(w.l)), y.l);
             tile[r0 * cols + c] = add<P>(x, y);
             tile[r1 * cols + c] = sub<P>(x, y);
+        };
+        // position of the butterfly inside its size-2^s block: j = (r0 mod 2^(t+1)) * 2^s0 + lo
+        if (nbf == 4 * blockDim.x) {
+            // full tile: issue the four twiddle gathers of this lane's butterflies before the arithmetic
+            // (2 waves/SIMD cannot hide a dependent global load per butterfly)
+            Fp<P> w[4];
+            unsigned r0v[4], cv[4];
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) {
+                const unsigned e = tid + q * blockDim.x, c = e & (cols - 1), k = e >> log_cols;
+                r0v[q] = ((k >> t) << (t + 1)) | (k & (half - 1));
+                cv[q] = c;
+                const size_t j = ((size_t)(r0v[q] & (half - 1)) << s0) + lo0 + c;
+                w[q] = tw[j << (log_n - s)];
+            }
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) bfly(r0v[q], r0v[q] + half, cv[q], w[q]);
+        } else {
+            for (unsigned e = tid; e < nbf; e += blockDim.x) {
+                const unsigned c = e & (cols - 1), k = e >> log_cols;
+                const unsigned r0 = ((k >> t) << (t + 1)) | (k & (half - 1));
+                const size_t j = ((size_t)(r0 & (half - 1)) << s0) + lo0 + c;
+                bfly(r0, r0 + half, c, tw[j << (log_n - s)]);
+            }
         }
         __syncthreads();
     }
@@ -96,7 +128,7 @@ __global__ void k_scale(Fp<P> *a, size_t n, Fp<P> s) {
 }
 
 template <class C>
-int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out) {
+int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out, bool internal) {
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
     const int cid = C::ID;
@@ -111,6 +143,8 @@ int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C:
         size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
         PM_HIP(ctx, slot->fwd.reserve(half * sizeof(Fr)));
         PM_HIP(ctx, slot->inv.reserve(half * sizeof(Fr)));
+        PM_HIP(ctx, slot->fwd_int.reserve(half * sizeof(Fr)));
+        PM_HIP(ctx, slot->inv_int.reserve(half * sizeof(Fr)));
         Fr root;
         for (int i = 0; i < P::N; ++i) root.l[i] = C::ROOT_MONT[i];
         for (unsigned i = log_n; i < (unsigned)C::TWO_ADICITY; ++i) root = sqr<P>(root);
@@ -123,13 +157,14 @@ int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C:
                 w = sqr<P>(w);
             }
             Fr *dst = dir ? slot->inv.as<Fr>() : slot->fwd.as<Fr>();
+            Fr *dst_int = dir ? slot->inv_int.as<Fr>() : slot->fwd_int.as<Fr>();
             unsigned blocks = (unsigned)((half + 255) / 256);
-            hipLaunchKernelGGL(k_twiddles<P>, dim3(blocks), dim3(256), 0, ctx->stream, dst, half, tab,
+            hipLaunchKernelGGL((k_twiddles<P, typename C::FrRR>), dim3(blocks), dim3(256), 0, ctx->stream, dst, dst_int, half, tab,
                                log_n ? log_n - 1 : 0);
             PM_HIP(ctx, hipGetLastError());
         }
     }
-    *out = inv_dir ? slot->inv.as<Fr>() : slot->fwd.as<Fr>();
+    *out = internal ? (inv_dir ? slot->inv_int.as<Fr>() : slot->fwd_int.as<Fr>()) : (inv_dir ? slot->inv.as<Fr>() : slot->fwd.as<Fr>());
     return PM_OK;
 }
 
@@ -142,7 +177,7 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     StageTimer timer(ctx, T_NTT);
     const size_t n = (size_t)1 << log_n;
     const Fr *tw = nullptr;
-    PM_TRY(twiddles_get<C>(ctx, log_n, inv_dir, &tw));
+    PM_TRY(twiddles_get<C>(ctx, log_n, inv_dir, &tw, true));
     hipLaunchKernelGGL(k_bitrev<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, log_n);
     PM_HIP(ctx, hipGetLastError());
     unsigned s0 = 0;
@@ -153,7 +188,7 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         if (s0 < log_cols) log_cols = s0;
         size_t tiles = n >> (ns + log_cols);
         size_t lds = ((size_t)1 << (ns + log_cols)) * sizeof(Fr);
-        hipLaunchKernelGGL(k_ntt_pass<P>, dim3((unsigned)tiles), dim3(256), lds, ctx->stream, d, tw, log_n, s0, ns,
+        hipLaunchKernelGGL((k_ntt_pass<P, typename C::FrRR>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, d, tw, log_n, s0, ns,
                            log_cols);
         PM_HIP(ctx, hipGetLastError());
         s0 += ns;
@@ -166,8 +201,8 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     return PM_OK;
 }
 
-template int twiddles_get<BlsCurve>(pm_ctx *, unsigned, bool, const Fp<BlsFrP> **);
-template int twiddles_get<BnCurve>(pm_ctx *, unsigned, bool, const Fp<BnFrP> **);
+template int twiddles_get<BlsCurve>(pm_ctx *, unsigned, bool, const Fp<BlsFrP> **, bool);
+template int twiddles_get<BnCurve>(pm_ctx *, unsigned, bool, const Fp<BnFrP> **, bool);
 template int ntt_run<BlsCurve>(pm_ctx *, Fp<BlsFrP> *, unsigned, bool);
 template int ntt_run<BnCurve>(pm_ctx *, Fp<BnFrP> *, unsigned, bool);
 
