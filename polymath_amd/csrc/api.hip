@@ -452,27 +452,34 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tables_disabled_by_env()) return PM_OK;
-    MsmTables tb[3];
-    double need = 64.0 * 40.0 * (double)pk->n;   // per-proof vectors
-    for (int k = 0; k < 3; ++k) {
-        const uint64_t len = pk->res_hi[k] - pk->res_lo[k];
-        tb[k] = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS);
-        // the table itself + the MSM workspace (~ 48 B per table entry of the longest MSM, reused by the others)
-        need += (double)len * tb[k].nwin * sizeof(Affine<C>) + (k == 2 ? 48.0 * tb[k].nwin * (double)len : 0.0);
-    }
+    // Budget: free HBM minus the per-proof vectors (~40 Fr per domain point) and the MSM workspace (~48 B per
+    // table entry of one <= 2^27-pair piece).  Tables are granted per MSM, smallest first, while they fit;
+    // an MSM without tables runs the per-window pipeline on the plain array.
     size_t free_b = 0, total_b = 0;
     PM_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    if (need > 0.9 * (double)free_b) return PM_OK;   // no room: per-window Pippenger on the plain array
-    for (int k = 0; k < 3; ++k) {
+    double budget = 0.9 * (double)free_b - 64.0 * 40.0 * (double)pk->n;
+    {
+        const uint64_t len_d = pk->res_hi[2] - pk->res_lo[2];
+        budget -= 48.0 * 16.0 * (double)(len_d < ((uint64_t)1 << 27) ? len_d : ((uint64_t)1 << 27));
+    }
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int x, int y) { return pk->res_hi[x] - pk->res_lo[x] < pk->res_hi[y] - pk->res_lo[y]; });
+    for (int q = 0; q < 3; ++q) {
+        const int k = order[q];
         const uint64_t len = pk->res_hi[k] - pk->res_lo[k];
-        if (!len || !tb[k].c) continue;
-        PM_HIP(ctx, hipMalloc(&pk->d_tab[k], len * tb[k].nwin * sizeof(Affine<C>)));
+        if (!len) continue;
+        MsmTables tb = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS);
+        if (!tb.c) continue;
+        const double need = (double)len * tb.nwin * sizeof(Affine<C>) + (double)len;
+        if (need > budget) continue;
+        budget -= need;
+        PM_HIP(ctx, hipMalloc(&pk->d_tab[k], len * tb.nwin * sizeof(Affine<C>)));
         PM_HIP(ctx, hipMemcpyAsync(pk->d_tab[k], d + pk->res_dev_off[k], len * sizeof(Affine<C>), hipMemcpyDeviceToDevice, ctx->stream));
         PM_HIP(ctx, hipMalloc(&pk->d_tab_inf[k], len));
         PM_TRY(infinity_flags<C>(ctx, (const Affine<C> *)pk->d_tab[k], (size_t)len, (unsigned char *)pk->d_tab_inf[k]));
-        PM_TRY(tables_build<C>(ctx, (Affine<C> *)pk->d_tab[k], (size_t)len, tb[k]));
-        tb[k].inf = (const unsigned char *)pk->d_tab_inf[k];
-        pk->tables[k] = tb[k];
+        PM_TRY(tables_build<C>(ctx, (Affine<C> *)pk->d_tab[k], (size_t)len, tb));
+        tb.inf = (const unsigned char *)pk->d_tab_inf[k];
+        pk->tables[k] = tb;
     }
     return PM_OK;
 }

@@ -48,6 +48,16 @@ struct FrOps {
         Fr c = pm::from_mont<P>(a);
         memcpy(out, c.l, 32);
     }
+    // CanonicalDeserialize of Fp: 32 little-endian bytes, rejected when >= r
+    static Fr from_le_bytes_canonical(const uint8_t b[32]) {
+        Fr v;
+        memcpy(v.l, b, 32);
+        for (int i = 7; i >= 0; --i) {
+            if (v.l[i] < P::MOD[i]) break;
+            if (v.l[i] > P::MOD[i] || i == 0) throw std::runtime_error("Fr: non-canonical encoding");
+        }
+        return pm::to_mont<P>(v);
+    }
     // F::from_be_bytes_mod_order on a 32-byte digest (keccak256.rs:36, blake3.rs:36)
     static Fr from_be_bytes_mod_order(const uint8_t d[32]) {
         Fr v;

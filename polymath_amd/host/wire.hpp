@@ -1,0 +1,341 @@
+// ProvingKey / VerifyingKey wire format above the C ABI.
+//
+// Restates the `#[derive(CanonicalSerialize, CanonicalDeserialize)]` layout of
+// /root/reference/src/data_structures.rs:25-73 and src/common.rs:112-127 in compressed mode:
+//   VerifyingKey { e: PairingVK { one_g1, one_g2, x_g2, z_g2 }, n, m0, sigma, omega }
+//   ProvingKey   { vk, sap_matrices { num_instance_variables, num_r1cs_witness_variables, num_r1cs_constraints,
+//                  a, b, c : Vec<Vec<(F, usize)>> }, x_powers_g1, x_powers_y_alpha_g1, x_powers_zh_by_y_alpha_g1,
+//                  x_powers_y_gamma_g1, x_powers_y_gamma_z_g1, uj_wj_lcs_by_y_alpha_g1 : Vec<G1Affine> }
+// usize / u64 = 8 B little-endian, Vec = u64 length prefix, Fr = 32 B little-endian canonical, BLS12-381
+// G1 / G2 in the zcash encoding (big-endian x, 3 flag bits; G2 = x.c1 || x.c0) [ark, from memory -- SURVEY App. C].
+// A WireKey is the host-side image (points decompressed, matrices with row-duplicate columns KEPT, as the
+// reference serialises what the synthesiser produced); pk_load / pk_export move it through pm_pk_load /
+// pm_pk_export_bases.  Pinned by tests/golden/pk_wire.json and the published generator encodings.
+#pragma once
+#include "polymath.hpp"
+
+namespace pmhost {
+
+struct WireError : std::runtime_error {
+    explicit WireError(const std::string &m) : std::runtime_error(m) {}
+};
+
+struct Reader {
+    const uint8_t *p;
+    size_t len, off = 0;
+    Reader(const uint8_t *d, size_t n) : p(d), len(n) {}
+    const uint8_t *take(size_t n) {
+        if (off + n > len) throw WireError("truncated key");
+        const uint8_t *r = p + off;
+        off += n;
+        return r;
+    }
+    uint64_t u64() {
+        const uint8_t *b = take(8);
+        uint64_t v = 0;
+        for (int i = 7; i >= 0; --i) v = (v << 8) | b[i];
+        return v;
+    }
+};
+
+// ------------------------------------------------------------------ square roots (p = 3 mod 4)
+template <class Q>
+pm::Fp<Q> fq_pow_limbs(const pm::Fp<Q> &a, const uint32_t *e, int nlimbs) {
+    pm::Fp<Q> acc = pm::Fp<Q>::one();
+    for (int i = nlimbs - 1; i >= 0; --i)
+        for (int b = 31; b >= 0; --b) {
+            acc = pm::sqr<Q>(acc);
+            if ((e[i] >> b) & 1) acc = pm::mul<Q>(acc, a);
+        }
+    return acc;
+}
+
+// sqrt(a) = a^((p+1)/4); false when a is a non-residue
+template <class Q>
+bool fq_sqrt(const pm::Fp<Q> &a, pm::Fp<Q> &out) {
+    uint32_t e[Q::N];
+    uint64_t carry = 1;   // (p + 1) >> 2
+    for (int i = 0; i < Q::N; ++i) {
+        uint64_t v = (uint64_t)Q::MOD[i] + carry;
+        e[i] = (uint32_t)v;
+        carry = v >> 32;
+    }
+    for (int i = 0; i < Q::N; ++i) e[i] = (e[i] >> 2) | (i + 1 < Q::N ? e[i + 1] << 30 : (uint32_t)(carry << 30));
+    out = fq_pow_limbs<Q>(a, e, Q::N);
+    return pm::sqr<Q>(out).eq(a);
+}
+
+// canonical-integer comparison of two Montgomery-form elements
+template <class Q>
+int fq_cmp(const pm::Fp<Q> &a, const pm::Fp<Q> &b) {
+    pm::Fp<Q> x = pm::from_mont<Q>(a), y = pm::from_mont<Q>(b);
+    for (int i = Q::N - 1; i >= 0; --i)
+        if (x.l[i] != y.l[i]) return x.l[i] > y.l[i] ? 1 : -1;
+    return 0;
+}
+
+struct Fq2Ops {   // BLS12-381 Fq2 = Fq[u]/(u^2+1)
+    typedef Bls12Pairing B;
+    typedef B::Fq Fq;
+    typedef B::Fq2 Fq2;
+    typedef pm::BlsFqP Q;
+    static bool sqrt(const Fq2 &a, Fq2 &out) {   // complex method
+        Fq s;
+        if (a.c1.is_zero()) {
+            if (fq_sqrt<Q>(a.c0, s)) { out = Fq2{s, Fq::zero()}; return true; }
+            if (fq_sqrt<Q>(B::fneg(a.c0), s)) { out = Fq2{Fq::zero(), s}; return true; }
+            return false;
+        }
+        Fq alpha;
+        if (!fq_sqrt<Q>(B::fadd(B::fmul(a.c0, a.c0), B::fmul(a.c1, a.c1)), alpha)) return false;
+        const Fq inv2 = B::finv(B::small(2));
+        Fq x0;
+        if (!fq_sqrt<Q>(B::fmul(B::fadd(a.c0, alpha), inv2), x0) && !fq_sqrt<Q>(B::fmul(B::fsub(a.c0, alpha), inv2), x0)) return false;
+        out = Fq2{x0, B::fmul(a.c1, B::finv(B::fadd(x0, x0)))};
+        return true;
+    }
+    // a > b in arkworks' Fq2 order: c1 first, then c0
+    static bool gt(const Fq2 &a, const Fq2 &b) {
+        int c = fq_cmp<Q>(a.c1, b.c1);
+        return c ? c > 0 : fq_cmp<Q>(a.c0, b.c0) > 0;
+    }
+};
+
+// ---------------------------------------------------------------------------- point codecs
+inline void put_fq_be(const pm::Fp<pm::BlsFqP> &mont, Bytes &out) {
+    pm::Fp<pm::BlsFqP> x = pm::from_mont<pm::BlsFqP>(mont);
+    uint8_t le[48];
+    memcpy(le, x.l, 48);
+    for (int i = 47; i >= 0; --i) out.push_back(le[i]);
+}
+inline bool get_fq_be(const uint8_t *b, uint8_t top_mask, pm::Fp<pm::BlsFqP> &mont) {
+    typedef pm::BlsFqP Q;
+    uint8_t le[48];
+    for (int i = 0; i < 48; ++i) le[i] = b[47 - i];
+    le[47] &= top_mask;
+    pm::Fp<Q> x;
+    memcpy(x.l, le, 48);
+    for (int i = Q::N - 1; i >= 0; --i) {      // x < p
+        if (x.l[i] < Q::MOD[i]) break;
+        if (x.l[i] > Q::MOD[i] || i == 0) return false;
+    }
+    mont = pm::to_mont<Q>(x);
+    return true;
+}
+
+inline void ser_g2(const Bls12Pairing::G2 &g, Bytes &out) {
+    if (g.inf) { out.push_back(0xC0); out.insert(out.end(), 95, 0); return; }
+    const size_t at = out.size();
+    put_fq_be(g.x.c1, out);
+    put_fq_be(g.x.c0, out);
+    out[at] |= 0x80 | (Fq2Ops::gt(g.y, Bls12Pairing::neg2(g.y)) ? 0x20 : 0);
+}
+
+inline Bls12Pairing::G2 deser_g2(Reader &rd) {
+    typedef Bls12Pairing B;
+    const uint8_t *b = rd.take(96);
+    if (!(b[0] & 0x80)) throw WireError("G2: not a compressed point");
+    B::G2 g;
+    g.inf = (b[0] & 0x40) != 0;
+    if (g.inf) { g.x = g.y = B::Fq2{B::Fq::zero(), B::Fq::zero()}; return g; }
+    if (!get_fq_be(b, 0x1F, g.x.c1) || !get_fq_be(b + 48, 0xFF, g.x.c0)) throw WireError("G2: coordinate >= p");
+    B::Fq2 rhs = B::add2(B::mul2(B::mul2(g.x, g.x), g.x), B::Fq2{B::small(4), B::small(4)});
+    if (!Fq2Ops::sqrt(rhs, g.y)) throw WireError("G2: not on the twist");
+    if (Fq2Ops::gt(g.y, B::neg2(g.y)) != ((b[0] & 0x20) != 0)) g.y = B::neg2(g.y);
+    return g;
+}
+
+template <class C>
+G1Point<C> deser_g1(Reader &rd) {
+    typedef typename C::FqP Q;
+    const int NB = Q::N * 4;
+    const uint8_t *b = rd.take(NB);
+    G1Point<C> g;
+    memset(&g.p, 0, sizeof(g.p));
+    uint8_t le[64];
+    bool larger;
+    if (C::ID == 0) {
+        if (!(b[0] & 0x80)) throw WireError("G1: not a compressed point");
+        g.inf = (b[0] & 0x40) != 0;
+        larger = (b[0] & 0x20) != 0;
+        for (int i = 0; i < NB; ++i) le[i] = b[NB - 1 - i];
+        le[NB - 1] &= 0x1F;
+    } else {
+        g.inf = (b[NB - 1] & 0x40) != 0;
+        larger = (b[NB - 1] & 0x80) != 0;
+        memcpy(le, b, NB);
+        le[NB - 1] &= 0x3F;
+    }
+    if (g.inf) return g;
+    pm::Fp<Q> x;
+    memcpy(x.l, le, NB);
+    for (int i = Q::N - 1; i >= 0; --i) {
+        if (x.l[i] < Q::MOD[i]) break;
+        if (x.l[i] > Q::MOD[i] || i == 0) throw WireError("G1: coordinate >= p");
+    }
+    g.p.x = pm::to_mont<Q>(x);
+    pm::Fp<Q> bb;
+    for (int i = 0; i < Q::N; ++i) bb.l[i] = C::B_MONT[i];
+    pm::Fp<Q> rhs = pm::add<Q>(pm::mul<Q>(pm::sqr<Q>(g.p.x), g.p.x), bb), y;
+    if (!fq_sqrt<Q>(rhs, y)) throw WireError("G1: not on the curve");
+    if ((fq_cmp<Q>(y, pm::neg<Q>(y)) > 0) != larger) y = pm::neg<Q>(y);
+    g.p.y = y;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------ keys
+inline void ser_vk(const VerifyingKey &vk, Bytes &out) {
+    typedef pm::BlsCurve C;
+    ser_g1<C>(vk.one_g1, out);
+    ser_g2(vk.one_g2, out);
+    ser_g2(vk.x_g2, out);
+    ser_g2(vk.z_g2, out);
+    ser_u64(vk.n, out);
+    ser_u64(vk.m0, out);
+    ser_u64(vk.sigma, out);
+    ser_fr<C>(vk.omega, out);
+}
+
+inline VerifyingKey read_vk(Reader &rd) {
+    typedef pm::BlsCurve C;
+    VerifyingKey vk;
+    vk.one_g1 = deser_g1<C>(rd);
+    vk.one_g2 = deser_g2(rd);
+    vk.x_g2 = deser_g2(rd);
+    vk.z_g2 = deser_g2(rd);
+    vk.n = rd.u64();
+    vk.m0 = rd.u64();
+    vk.sigma = rd.u64();
+    vk.omega = FrOps<C>::from_le_bytes_canonical(rd.take(32));
+    return vk;
+}
+
+// pm_base_vec ids in the struct's declaration order (data_structures.rs:60-72)
+static const int PK_WIRE_VECTORS[6] = {PM_X_POWERS, PM_X_POWERS_Y_ALPHA, PM_X_POWERS_ZH_BY_Y_ALPHA, PM_X_POWERS_Y_GAMMA,
+                                       PM_X_POWERS_Y_GAMMA_Z, PM_UJ_WJ_LCS_BY_Y_ALPHA};
+
+template <class C>
+struct WireKey {
+    VerifyingKey vk;
+    uint64_t m0 = 0, mw = 0, nr = 0;          // num_instance_variables, num_r1cs_witness_variables, num_r1cs_constraints
+    CsrHost a, b, c;                           // rows of (value Montgomery, column), duplicates kept
+    std::vector<G1Point<C>> vec[PM_NUM_BASE_VECS];   // indexed by pm_base_vec
+
+    static void put_matrix(const CsrHost &m, Bytes &out) {
+        const size_t rows = m.rowptr.size() - 1;
+        ser_u64(rows, out);
+        for (size_t r = 0; r < rows; ++r) {
+            ser_u64(m.rowptr[r + 1] - m.rowptr[r], out);
+            for (uint64_t k = m.rowptr[r]; k < m.rowptr[r + 1]; ++k) {
+                typename FrOps<C>::Fr v;
+                memcpy(v.l, &m.val[4 * k], 32);
+                ser_fr<C>(v, out);
+                ser_u64(m.col[k], out);
+            }
+        }
+    }
+    static CsrHost get_matrix(Reader &rd) {
+        CsrHost m;
+        const uint64_t rows = rd.u64();
+        for (uint64_t r = 0; r < rows; ++r) {
+            const uint64_t cnt = rd.u64();
+            for (uint64_t k = 0; k < cnt; ++k) {
+                typename FrOps<C>::Fr v = FrOps<C>::from_le_bytes_canonical(rd.take(32));
+                const uint64_t col = rd.u64();
+                if (col > 0xffffffffull) throw WireError("matrix column out of range");
+                m.col.push_back((uint32_t)col);
+                const uint64_t *limbs = (const uint64_t *)v.l;
+                m.val.insert(m.val.end(), limbs, limbs + 4);
+            }
+            m.rowptr.push_back(m.col.size());
+        }
+        return m;
+    }
+
+    Bytes to_bytes() const {
+        Bytes out;
+        ser_vk(vk, out);
+        ser_u64(m0, out);
+        ser_u64(mw, out);
+        ser_u64(nr, out);
+        put_matrix(a, out);
+        put_matrix(b, out);
+        put_matrix(c, out);
+        for (int which : PK_WIRE_VECTORS) {
+            ser_u64(vec[which].size(), out);
+            for (const auto &g : vec[which]) ser_g1<C>(g, out);
+        }
+        return out;
+    }
+
+    static WireKey parse(const uint8_t *data, size_t len) {
+        static_assert(C::ID == 0, "the reference instantiates Bls12_381 only (Cargo.toml:35); G2 codecs are BLS12-381");
+        Reader rd(data, len);
+        WireKey k;
+        k.vk = read_vk(rd);
+        k.m0 = rd.u64();
+        k.mw = rd.u64();
+        k.nr = rd.u64();
+        k.a = get_matrix(rd);
+        k.b = get_matrix(rd);
+        k.c = get_matrix(rd);
+        for (int which : PK_WIRE_VECTORS) {
+            const uint64_t cnt = rd.u64();
+            if (cnt > (len - rd.off) / (C::FqP::N * 4)) throw WireError("truncated key");
+            k.vec[which].reserve(cnt);
+            for (uint64_t i = 0; i < cnt; ++i) k.vec[which].push_back(deser_g1<C>(rd));
+        }
+        if (rd.off != len) throw WireError("trailing bytes after the key");
+        return k;
+    }
+};
+
+// WireKey -> device-resident key (pm_pk_load uploads, shards and builds the window tables)
+template <class C>
+ProvingKey<C> pk_load(Context &ctx, const WireKey<C> &k, int shard_rank = 0, int shard_count = 1) {
+    std::vector<pm::Affine<C>> flat[PM_NUM_BASE_VECS];
+    pm_base_array arr[PM_NUM_BASE_VECS];
+    for (int v = 0; v < PM_NUM_BASE_VECS; ++v) {
+        flat[v].resize(k.vec[v].size());
+        for (size_t i = 0; i < k.vec[v].size(); ++i) {
+            if (k.vec[v][i].inf) memset(&flat[v][i], 0, sizeof(pm::Affine<C>));   // the ABI's infinity: all-zero x, y
+            else flat[v][i] = k.vec[v][i].p;
+        }
+        arr[v] = pm_base_array{flat[v].data(), flat[v].size(), sizeof(pm::Affine<C>)};
+    }
+    pm_csr va = k.a.view(), vb = k.b.view(), vc = k.c.view();
+    ProvingKey<C> pk;
+    int st = pm_pk_load(ctx.h, C::ID, k.vk.n, k.m0, k.mw, k.nr, k.vk.sigma, &va, &vb, &vc, arr, shard_rank, shard_count, &pk.h);
+    if (st) throw PolymathError(0, st, std::string("pm_pk_load: ") + pm_last_error(ctx.h));
+    pk.n = k.vk.n; pk.m0 = k.vk.m0; pk.sigma = k.vk.sigma; pk.omega = k.vk.omega;
+    return pk;
+}
+
+// device-resident key + its vk + the matrices as synthesised -> WireKey (bases come back from HBM)
+template <class C>
+WireKey<C> pk_export(Context &ctx, const ProvingKey<C> &pk, const VerifyingKey &vk, uint64_t mw, uint64_t nr, const CsrHost &a,
+                     const CsrHost &b, const CsrHost &c) {
+    WireKey<C> k;
+    k.vk = vk;
+    k.m0 = pk.m0; k.mw = mw; k.nr = nr;
+    k.a = a; k.b = b; k.c = c;
+    uint64_t lens[PM_NUM_BASE_VECS];
+    pm_pk_info(pk.h, nullptr, nullptr, nullptr, nullptr, lens);
+    for (int v = 0; v < PM_NUM_BASE_VECS; ++v) {
+        std::vector<pm::Affine<C>> flat(lens[v]);
+        if (lens[v]) {
+            int st = pm_pk_export_bases(ctx.h, pk.h, v, 0, lens[v], (uint64_t *)flat.data());
+            if (st) throw PolymathError(0, st, std::string("pm_pk_export_bases: ") + pm_last_error(ctx.h));
+        }
+        k.vec[v].resize(lens[v]);
+        for (size_t i = 0; i < flat.size(); ++i) {
+            const uint32_t *w = (const uint32_t *)&flat[i];
+            uint32_t any = 0;
+            for (size_t t = 0; t < sizeof(pm::Affine<C>) / 4; ++t) any |= w[t];
+            k.vec[v][i] = G1Point<C>{flat[i], any == 0};
+        }
+    }
+    return k;
+}
+
+}  // namespace pmhost

@@ -149,6 +149,136 @@ def ser_g1_slice(field, Ps):
     return struct.pack("<Q", len(Ps)) + b"".join(ser_g1(field, P) for P in Ps)
 
 
+# ProvingKey / VerifyingKey wire format (data_structures.rs:25-73, common.rs:112-127): the
+# derive(CanonicalSerialize) field order, compressed mode.  The key's base vectors come back from HBM through
+# pm_pk_export_bases; loading decompresses the points on the host and goes through pm_pk_load.
+PK_WIRE_VECTORS = (0, 1, 4, 2, 3, 5)   # pm_base_vec ids in declaration order: x_powers, y_alpha, zh_by_y_alpha, y_gamma, y_gamma_z, lcs
+FQ2_B = (4, 4)                          # BLS12-381 twist: y^2 = x^3 + 4(1 + u)
+
+
+def _u64(v):
+    return struct.pack("<Q", v)
+
+
+def _fq2_gt(a, b):
+    return (a[1], a[0]) > (b[1], b[0])
+
+
+def ser_g2(field, Q):
+    """BLS12-381 G2, zcash format: x.c1 || x.c0 big-endian, flags as for G1, sign = y > -y in Fq2 order."""
+    assert field.curve == "bls12_381"
+    if Q is None:
+        return bytes([0xC0]) + bytes(95)
+    (x0, x1), (y0, y1) = Q
+    b = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if _fq2_gt((y0, y1), ((-y0) % field.p, (-y1) % field.p)) else 0)
+    return bytes(b)
+
+
+def _fq_sqrt(p, a):
+    s = pow(a, (p + 1) // 4, p)            # p = 3 mod 4 (BLS12-381 and BN254 base fields)
+    return s if s * s % p == a % p else None
+
+
+def _fq2_sqrt(p, a):
+    a0, a1 = a
+    if a1 == 0:
+        s = _fq_sqrt(p, a0)
+        if s is not None:
+            return (s, 0)
+        s = _fq_sqrt(p, (-a0) % p)
+        return None if s is None else (0, s)
+    alpha = _fq_sqrt(p, (a0 * a0 + a1 * a1) % p)
+    if alpha is None:
+        return None
+    inv2 = pow(2, -1, p)
+    x0 = _fq_sqrt(p, (a0 + alpha) * inv2 % p)
+    if x0 is None:
+        x0 = _fq_sqrt(p, (a0 - alpha) * inv2 % p)
+        if x0 is None:
+            return None
+    return (x0, a1 * pow(2 * x0, -1, p) % p)
+
+
+def deser_g1(field, b):
+    p = field.p
+    if field.curve == "bls12_381":
+        if len(b) != 48 or not b[0] & 0x80:
+            raise ValueError("G1: not a compressed BLS12-381 point")
+        if b[0] & 0x40:
+            return None
+        x, larger, curve_b = int.from_bytes(bytes([b[0] & 0x1F]) + b[1:], "big"), bool(b[0] & 0x20), 4
+    else:
+        if len(b) != 32:
+            raise ValueError("G1: wrong length")
+        if b[31] & 0x40:
+            return None
+        x, larger, curve_b = int.from_bytes(b[:31] + bytes([b[31] & 0x3F]), "little"), bool(b[31] & 0x80), 3
+    y = _fq_sqrt(p, (x * x * x + curve_b) % p) if x < p else None
+    if y is None:
+        raise ValueError("G1: not on the curve")
+    return (x, p - y if (y > (p - 1) // 2) != larger else y)
+
+
+def deser_g2(field, b):
+    p = field.p
+    if field.curve != "bls12_381" or len(b) != 96 or not b[0] & 0x80:
+        raise ValueError("G2: not a compressed BLS12-381 point")
+    if b[0] & 0x40:
+        return None
+    x1, x0 = int.from_bytes(bytes([b[0] & 0x1F]) + b[1:48], "big"), int.from_bytes(b[48:], "big")
+    xx = ((x0 * x0 - x1 * x1) % p, 2 * x0 * x1 % p)
+    x3 = ((xx[0] * x0 - xx[1] * x1) % p, (xx[0] * x1 + xx[1] * x0) % p)
+    y = _fq2_sqrt(p, ((x3[0] + FQ2_B[0]) % p, (x3[1] + FQ2_B[1]) % p))
+    if y is None:
+        raise ValueError("G2: not on the twist")
+    neg = ((-y[0]) % p, (-y[1]) % p)
+    return ((x0, x1), neg if _fq2_gt(y, neg) != bool(b[0] & 0x20) else y)
+
+
+def ser_matrix(field, rows):
+    out = [_u64(len(rows))]
+    for row in rows:
+        out.append(_u64(len(row)))
+        out.extend(ser_fr(field, v) + _u64(j) for v, j in row)
+    return b"".join(out)
+
+
+class VerifyingKey:
+    """data_structures.rs:38-52 with PairingVK (:25-35); G2 points as ((x0, x1), (y0, y1)) canonical ints."""
+
+    def __init__(self, field, one_g1, one_g2, x_g2, z_g2, n, m0, sigma, omega):
+        self.field, self.one_g1, self.one_g2, self.x_g2, self.z_g2 = field, one_g1, one_g2, x_g2, z_g2
+        self.n, self.m0, self.sigma, self.omega = n, m0, sigma, omega
+
+    def to_bytes(self):
+        f = self.field
+        return (ser_g1(f, self.one_g1) + ser_g2(f, self.one_g2) + ser_g2(f, self.x_g2) + ser_g2(f, self.z_g2) +
+                _u64(self.n) + _u64(self.m0) + _u64(self.sigma) + ser_fr(f, self.omega))
+
+    @classmethod
+    def read(cls, field, rd):
+        g1n = 48 if field.curve == "bls12_381" else 32
+        one_g1, one_g2, x_g2, z_g2 = deser_g1(field, rd.take(g1n)), deser_g2(field, rd.take(96)), deser_g2(field, rd.take(96)), deser_g2(field, rd.take(96))
+        n, m0, sigma = rd.u64(), rd.u64(), rd.u64()
+        return cls(field, one_g1, one_g2, x_g2, z_g2, n, m0, sigma, int.from_bytes(rd.take(32), "little"))
+
+
+class _Reader:
+    def __init__(self, b):
+        self.b, self.o = bytes(b), 0
+
+    def take(self, n):
+        if self.o + n > len(self.b):
+            raise ValueError("truncated key")
+        v = self.b[self.o:self.o + n]
+        self.o += n
+        return v
+
+    def u64(self):
+        return struct.unpack("<Q", self.take(8))[0]
+
+
 class Proof:
     """data_structures.rs:10-19."""
 
@@ -239,6 +369,52 @@ class Polymath:
         if combine:
             d_xy, d_inf = combine(d_xy, d_inf)
         return Proof(f, a_g1, c_g1, a_at_x1, f.g1_affine(d_xy, d_inf))           # :231-236
+
+    # ---- ProvingKey wire format (§8 f-4)
+    def pk_to_bytes(self, pk, r1cs, vk):
+        """ProvingKey { vk, sap_matrices, six Vec<G1Affine> } (data_structures.rs:56-73).  `r1cs` carries the
+        matrices as synthesised (the device copy has row-duplicate columns dropped, common.rs:100-105)."""
+        f = self.field
+        out = [vk.to_bytes(), _u64(r1cs.m0), _u64(r1cs.mw), _u64(r1cs.nr), ser_matrix(f, r1cs.a), ser_matrix(f, r1cs.b),
+               ser_matrix(f, r1cs.c)]
+        for which in PK_WIRE_VECTORS:
+            xy = pk.export_bases(which)
+            inf = ~xy.any(axis=1)
+            out.append(ser_g1_slice(f, [f.g1_affine(xy[i], bool(inf[i])) for i in range(xy.shape[0])]))
+        return b"".join(out)
+
+    def pk_from_bytes(self, data, shard_rank=0, shard_count=1):
+        """-> (device-resident ProvingKey through pm_pk_load, VerifyingKey, R1CS)."""
+        f, rd = self.field, _Reader(data)
+        vk = VerifyingKey.read(f, rd)
+        m0, mw, nr = rd.u64(), rd.u64(), rd.u64()
+        mats = []
+        for _ in range(3):
+            rows = []
+            for _ in range(rd.u64()):
+                row = []
+                for _ in range(rd.u64()):
+                    v = int.from_bytes(rd.take(32), "little")
+                    row.append((v, rd.u64()))
+                rows.append(row)
+            mats.append(rows)
+        g1n = 48 if f.curve == "bls12_381" else 32
+        arrays = [None] * 6
+        for which in PK_WIRE_VECTORS:
+            pts = [deser_g1(f, rd.take(g1n)) for _ in range(rd.u64())]
+            arr = np.zeros((len(pts), 2 * f.nq), dtype=np.uint64)
+            live = [i for i, P in enumerate(pts) if P is not None]
+            if live:
+                arr[live, :f.nq] = _to_limbs([pts[i][0] * f.Rq % f.p for i in live], f.nq)
+                arr[live, f.nq:] = _to_limbs([pts[i][1] * f.Rq % f.p for i in live], f.nq)
+            arrays[which] = arr
+        if rd.o != len(rd.b):
+            raise ValueError("trailing bytes after the key")
+        r1cs = R1CS(m0, mw, mats[0], mats[1], mats[2])
+        A, B, C = _csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)
+        pk = api.ProvingKey.load(self.ctx, self.curve, vk.n, m0, mw, nr, vk.sigma, A, B, C, arrays, shard_rank, shard_count)
+        pk.omega = vk.omega
+        return pk, vk, r1cs
 
     # ---- common.rs:21-71
     def compute_x1(self, t, public_inputs, commitments):

@@ -110,10 +110,38 @@ def proof_fixtures():
     return out
 
 
+def pk_wire_fixtures():
+    """ProvingKey / VerifyingKey wire bytes of the small proof fixtures: same circuits and
+    trapdoors as proofs.json (which must exist), so a key loaded from these bytes reproduces those proofs."""
+    c = CURVES["bls12_381"]
+    cases = {e["name"]: e for e in json.load(open(os.path.join(OUT, "proofs.json")))}
+    I = lambda h: int(h, 16)
+    out = []
+    for name in ["dummy", "dup_column", "mimc2"]:
+        e = cases[name]
+        rows = lambda m: [[(I(v), j) for v, j in rw] for rw in m]
+        q = PR.R1CS(e["r1cs"]["m0"], e["r1cs"]["mw"], rows(e["r1cs"]["a"]), rows(e["r1cs"]["b"]), rows(e["r1cs"]["c"]))
+        pk = PR.generate_proving_key(c, q, I(e["x_trapdoor"]), I(e["z_trapdoor"]))
+        vk = PA.make_vk(pk)
+        pkb = SE.ser_pk(c, pk, vk)
+        vk2, sap, vecs = SE.deser_pk(c, pkb)
+        assert vk2 == vk and sap == (q.m0, q.mw, q.nr, q.a, q.b, q.c) and all(vecs[n] == getattr(pk, n) for n in SE.PK_VECTORS)
+        G2 = lambda Q: [[H(Q[0][0]), H(Q[0][1])], [H(Q[1][0]), H(Q[1][1])]]
+        out.append(dict(name=name, vk=dict(one_g2=G2(vk["one_g2"]), x_g2=G2(vk["x_g2"]), z_g2=G2(vk["z_g2"]), bytes=SE.ser_vk(c, vk).hex()),
+                        pk_bytes=pkb.hex()))
+        print("pk wire fixture", name, len(pkb), "bytes, round trip ok")
+    kats = dict(g1_generator=SE.ser_g1(c, c.g1).hex(), g2_generator=SE.ser_g2(c, PA.make_vk(pk)["one_g2"]).hex(),
+                g1_infinity=SE.ser_g1(c, None).hex(), g2_infinity=SE.ser_g2(c, None).hex())
+    return dict(kats=kats, keys=out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
     for fname, fn in [("field_curve_kats.json", field_and_curve_kats), ("ntt_msm.json", ntt_msm_vectors),
-                      ("proofs.json", proof_fixtures)]:
+                      ("proofs.json", proof_fixtures), ("pk_wire.json", pk_wire_fixtures)]:
+        if only and fname not in only:
+            continue
         with open(os.path.join(OUT, fname), "w") as f:
             json.dump(fn(), f, separators=(",", ":"))
         print("wrote", fname)
