@@ -25,6 +25,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MSM_BYTES_PER_PAIR = {"bls12_381": 128, "bn254": 96}   # 32 B scalar + affine base
+# SURVEY.md §8d also asks for achieved MAD/s against a measured v_mad_u64_u32 peak: tools/microbench_valu.hip on
+# MI355X, >= 2 waves/SIMD (profiles/r01_microbench_valu.txt): 442.75 G wave-instr/s = 28.3 T lane-mads/s.
+VALU_MAD_PEAK = 28.34e12
+# v_mad_u64_u32 per XYZZ mixed add on 28-bit limbs (8M + 2S, 9 Montgomery reductions): N = 14 / 10 limbs
+MADS_PER_MIXED_ADD = {"bls12_381": 3542, "bn254": 1810}
 
 
 def log(rank, *a):
@@ -161,6 +166,8 @@ def main():
     if rank == 0:
         bpp = MSM_BYTES_PER_PAIR[curve]
         acc_s = avg(acc_ms) * 1e-3
+        msm_windows = pk.msm_windows(2)                # mixed adds per pair of the quotient MSM (table windows, or ceil(bits/c))
+        mads_rank = float(MADS_PER_MIXED_ADD[curve]) * msm_windows * d_pairs_rank
         achieved = (bpp * d_pairs_rank / acc_s / 1e9) if acc_s > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -189,7 +196,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "note": "algorithmic bytes = %d B/pair x %d pairs per launch; the kernel is integer-ALU-bound "
-                                 "(~16 mixed adds x ~3000 v_mad_u64_u32-class ops per pair), see DESIGN.md" % (bpp, d_pairs_rank)},
+                                 "(%d mixed adds x %d v_mad_u64_u32 per pair: see `valu` and DESIGN.md §4.2)" %
+                                 (bpp, d_pairs_rank, msm_windows, MADS_PER_MIXED_ADD[curve])},
+            "valu": {"kernel": "k_accumulate", "unit": "lane-mads/s (v_mad_u64_u32)", "mads_per_mixed_add": MADS_PER_MIXED_ADD[curve],
+                     "mixed_adds_per_pair": msm_windows, "achieved": mads_rank / acc_s if acc_s > 0 else None, "peak": VALU_MAD_PEAK,
+                     "frac": (mads_rank / acc_s / VALU_MAD_PEAK) if acc_s > 0 else None,
+                     "note": "the real bound of this kernel: mads are 76 % of its instruction stream (3 542 of 4 635 per mixed add)"},
             "proof_bytes": proof.to_bytes().hex(),
         }
         if not args.no_cpu_baseline:

@@ -132,6 +132,10 @@ int pm_pk_generate(pm_ctx *ctx, int curve, uint64_t m0, uint64_t mw, uint64_t nr
                    int shard_rank, int shard_count, pm_pk **out);
 int pm_pk_info(const pm_pk *pk, uint64_t *n, uint64_t *m0, uint64_t *sigma, uint64_t *omega /*Fr*/,
                uint64_t base_lens[PM_NUM_BASE_VECS]);
+/* How merged MSM `which` (0 = [a]_1: prover.rs:118,330-338; 1 = [c]_1: :121,340-357; 2 = [d]_1: :229) runs on
+ * this key/shard: resident pairs, bucket additions per pair (windows), widest window in bits, and whether the
+ * key holds window tables for it.  Measurement aid (bench.py's VALU roofline); no reference counterpart. */
+int pm_pk_msm_plan(const pm_pk *pk, int which, uint64_t *pairs, unsigned *windows, unsigned *window_bits, int *tables);
 /* Copy (a range of) one base vector back to the host, x||y Montgomery, 16*fq_limbs bytes apart. */
 int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_t offset, size_t len, uint64_t *out_xy);
 void pm_pk_free(pm_pk *pk);

@@ -46,7 +46,7 @@ EXPORTS = [
     "pm_device_count", "pm_ctx_create", "pm_ctx_destroy", "pm_last_error", "pm_last_timings", "pm_ntt",
     "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
     "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
-    "pm_pk_info", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3",
+    "pm_pk_info", "pm_pk_msm_plan", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3",
     "pm_prove_tap", "pm_host_keccak_f1600",
 ]
 
@@ -88,6 +88,7 @@ def load_library():
     L.pm_pk_generate.argtypes = [vp, i, u64, u64, u64, ct.POINTER(PmCsr), ct.POINTER(PmCsr), ct.POINTER(PmCsr), u64p,
                                  u64p, i, i, ct.POINTER(vp)]
     L.pm_pk_info.argtypes = [vp, u64p, u64p, u64p, u64p, u64p]
+    L.pm_pk_msm_plan.argtypes = [vp, ct.c_int, u64p, ct.POINTER(ct.c_uint), ct.POINTER(ct.c_uint), intp]
     L.pm_pk_export_bases.argtypes = [vp, vp, i, sz, sz, u64p]
     L.pm_pk_free.argtypes = [vp]
     L.pm_pk_free.restype = None
@@ -282,6 +283,15 @@ class ProvingKey:
         ctx.check(ctx.L.pm_pk_load(ctx.h, CURVE_IDS[curve], n, m0, mw, nr, sigma, ct.byref(a.struct), ct.byref(b.struct),
                                    ct.byref(c.struct), BA, shard_rank, shard_count, ct.byref(h)))
         return cls(ctx, curve, h, (a, b, c))
+
+    def msm_plan(self, which):
+        """(pairs, windows = bucket additions per pair, window bits, has tables) of merged MSM 0 = a, 1 = c, 2 = d."""
+        pairs, win, bits, tb = ct.c_uint64(), ct.c_uint(), ct.c_uint(), ct.c_int()
+        self.ctx.check(self.ctx.L.pm_pk_msm_plan(self.h, which, ct.byref(pairs), ct.byref(win), ct.byref(bits), ct.byref(tb)))
+        return pairs.value, win.value, bits.value, bool(tb.value)
+
+    def msm_windows(self, which):
+        return self.msm_plan(which)[1]
 
     def export_bases(self, which, offset=0, length=None):
         if length is None:

@@ -647,6 +647,24 @@ extern "C" int pm_pk_info(const pm_pk *pk, uint64_t *n, uint64_t *m0, uint64_t *
     return PM_OK;
 }
 
+extern "C" int pm_pk_msm_plan(const pm_pk *pk, int which, uint64_t *pairs, unsigned *windows, unsigned *window_bits, int *tables) {
+    if (!pk || which < 0 || which > 2) return PM_ERR_INVALID_ARG;
+    const uint64_t len = pk->res_hi[which] - pk->res_lo[which];
+    unsigned nwin = 0, c = 0;
+    if (pk->tables[which].c) {
+        nwin = pk->tables[which].nwin;
+        c = pk->tables[which].c;
+    } else {
+        const uint64_t piece = len < ((uint64_t)1 << 27) ? len : ((uint64_t)1 << 27);   // msm.hip: MSM_MAX_PIECE
+        pm::msm_plan_query((size_t)piece, pk->curve == PM_BLS12_381 ? (unsigned)BlsFrP::BITS : (unsigned)BnFrP::BITS, &nwin, &c);
+    }
+    if (pairs) *pairs = len;
+    if (windows) *windows = nwin;
+    if (window_bits) *window_bits = c;
+    if (tables) *tables = pk->tables[which].c ? 1 : 0;
+    return PM_OK;
+}
+
 extern "C" int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_t offset, size_t len, uint64_t *out_xy) {
     if (!ctx || !pk || !out_xy || which < 0 || which >= PM_NUM_BASE_VECS) return PM_ERR_INVALID_ARG;
     if (offset + len > pk->base_len[which]) return PM_ERR_INVALID_ARG;

@@ -175,6 +175,7 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
             Affine<C> *h_out, int *h_inf, const MsmTables *tables = nullptr);
 
 // choose c and the number of windows for a key whose longest MSM has `max_len` pairs
+void msm_plan_query(size_t len, unsigned scalar_bits, unsigned *nwin, unsigned *c);
 MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits);
 // fill windows 1..nwin-1 of a table array whose window 0 holds `count` internal-form affine points
 template <class C>

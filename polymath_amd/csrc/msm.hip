@@ -70,6 +70,13 @@ static MsmPlan make_plan(size_t len, unsigned scalar_bits) {
     return p;
 }
 
+// windows (= bucket additions per pair) and window width the per-window pipeline picks for `len` pairs
+void msm_plan_query(size_t len, unsigned scalar_bits, unsigned *nwin, unsigned *c) {
+    MsmPlan p = make_plan(len ? len : 1, scalar_bits);
+    *nwin = p.nwin;
+    *c = p.c;
+}
+
 // ------------------------------------------------------------------------------ digits
 template <class C>
 __global__ void k_digits(const Fp<typename C::FrP> *scalars, const Affine<C> *bases, uint32_t *digits, size_t len,
