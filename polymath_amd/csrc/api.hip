@@ -52,6 +52,7 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     ctx->device = device;
     ctx->pk = nullptr;
     ctx->phase = 0;
+    ctx->aux = nullptr;
     timing_reset(ctx);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -63,6 +64,7 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
 
 extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->aux) pm_ctx_destroy(ctx->aux);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     timing_flush(ctx);
@@ -72,6 +74,7 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
                       &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra})
         b->release();
     for (auto &b : ctx->lvl) b.release();
+    for (auto &b : ctx->fb_table) b.release();
     for (auto &t : ctx->tw) { t.fwd.release(); t.inv.release(); t.fwd_int.release(); t.inv_int.release(); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -123,10 +126,21 @@ extern "C" int pm_ntt_device(pm_ctx *ctx, int curve, uint64_t *d_data, unsigned 
 }
 
 // ---------------------------------------------------------------------------------- MSM
+struct BasesDeleter {   // frees the device allocations with the handle: error paths cannot leak HBM
+    void operator()(pm_bases *b) const {
+        if (!b) return;
+        (void)hipSetDevice(b->device);
+        if (b->d_points) (void)hipFree(b->d_points);
+        if (b->d_inf) (void)hipFree(b->d_inf);
+        delete b;
+    }
+};
+typedef std::unique_ptr<pm_bases, BasesDeleter> BasesPtr;
+
 template <class C>
 static int bases_upload_impl(pm_ctx *ctx, const void *bases, size_t stride, size_t len, pm_bases **out) {
     if (stride < sizeof(Affine<C>)) return PM_ERR_INVALID_ARG;
-    std::unique_ptr<pm_bases> b(new pm_bases{C::ID, ctx->device, len, nullptr});
+    BasesPtr b(new pm_bases{C::ID, ctx->device, len, nullptr});
     if (len) {
         std::vector<Affine<C>> packed(len);
         repack_bases<C>(bases, stride, len, packed.data());
@@ -148,14 +162,10 @@ extern "C" int pm_bases_upload(pm_ctx *ctx, int curve, const void *bases, size_t
 
 template <class C>
 static int bases_multiples_impl(pm_ctx *ctx, size_t len, pm_bases **out) {
-    std::unique_ptr<pm_bases> b(new pm_bases{C::ID, ctx->device, len, nullptr});
+    BasesPtr b(new pm_bases{C::ID, ctx->device, len, nullptr});
     if (len) {
         PM_HIP(ctx, hipMalloc(&b->d_points, len * sizeof(Affine<C>)));
-        int st = bases_generate_multiples<C>(ctx, len, (Affine<C> *)b->d_points);
-        if (st != PM_OK) {
-            (void)hipFree(b->d_points);
-            return st;
-        }
+        PM_TRY(bases_generate_multiples<C>(ctx, len, (Affine<C> *)b->d_points));
     }
     *out = b.release();
     return PM_OK;
@@ -220,13 +230,7 @@ extern "C" int pm_bases_precompute(pm_ctx *ctx, pm_bases *b) {
 
 extern "C" size_t pm_bases_len(const pm_bases *b) { return b ? b->len : 0; }
 
-extern "C" void pm_bases_free(pm_bases *b) {
-    if (!b) return;
-    (void)hipSetDevice(b->device);
-    if (b->d_points) (void)hipFree(b->d_points);
-    if (b->d_inf) (void)hipFree(b->d_inf);
-    delete b;
-}
+extern "C" void pm_bases_free(pm_bases *b) { BasesDeleter()(b); }
 
 template <class C>
 static int msm_resident_impl(pm_ctx *ctx, const pm_bases *bases, size_t off, const uint64_t *scalars, int on_device,

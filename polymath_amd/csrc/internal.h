@@ -153,6 +153,8 @@ struct pm_ctx {
     pm::MsmWorkspace msm;
     pm::TwiddleCache tw[4];
     pm::DevBuf scratch, flags;
+    pm_ctx *aux;              // helper context (own stream + MSM workspace) for the second of two concurrent MSMs
+    pm::DevBuf fb_table[2];   // setup.hip: 8-bit-window multiples of the G1 generator, per curve id (built on first use)
     // proof in flight
     const pm_pk *pk;
     int phase;

@@ -6,6 +6,8 @@
 // w_evals come from the closed form of SURVEY.md App. A in O(nnz): one lane per R1CS row.
 #include <cstring>
 
+#include <thread>
+
 #include "internal.h"
 
 namespace pm {
@@ -433,8 +435,30 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     PM_HIP(ctx, hipStreamSynchronize(st));
     if (hflags & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
     if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
-    PM_TRY(msm_shard<C>(ctx, pk, 0, sc_a, a_xy, a_inf));  // [a]_1 = M1 + M2
-    PM_TRY(msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf));  // [c]_1 = M7 + M6 + M3 + M4 + M5
+    // [a]_1 = M1 + M2 and [c]_1 = M7 + M6 + M3 + M4 + M5 are independent: the smaller one runs on a helper
+    // context (own stream and workspace) from a second host thread, so its sort, bucket reduction and host
+    // finish -- dependent chains that leave the chip mostly idle -- hide under the larger one's accumulation.
+    // PM_MSM_OVERLAP=0 runs them back to back.
+    static const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
+    if (overlap && ctx->aux) {
+        pm_ctx *aux = ctx->aux;
+        timing_reset(aux);
+        int st_a = PM_OK;
+        std::thread helper([&] {
+            if (hipSetDevice(aux->device) != hipSuccess) { st_a = PM_ERR_HIP; aux->err = "hipSetDevice (helper thread)"; return; }
+            st_a = msm_shard<C>(aux, pk, 0, sc_a, a_xy, a_inf);
+            timing_flush(aux);
+        });
+        const int st_c = msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
+        helper.join();
+        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += aux->timing_ms[s];
+        if (st_a != PM_OK) { ctx->err = aux->err; return st_a; }
+        PM_TRY(st_c);
+    } else {
+        PM_TRY(msm_shard<C>(ctx, pk, 0, sc_a, a_xy, a_inf));
+        PM_TRY(msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf));
+    }
     t_phase.stop();
     timing_flush(ctx);
     ctx->phase = 1;

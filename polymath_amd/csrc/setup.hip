@@ -91,11 +91,8 @@ template <class C>
 static int fixed_base_table(pm_ctx *ctx, const Affine<C> **d_table) {
     typedef typename C::FqP Q;
     typedef Fp<Q> Fq;
-    static DevBuf tables[2][16];  // per curve, per device
-    static bool ready[2][16] = {{false}};
-    int dev = ctx->device & 15;
-    DevBuf &buf = tables[C::ID][dev];
-    if (!ready[C::ID][dev]) {
+    DevBuf &buf = ctx->fb_table[C::ID];   // owned by the context: no process-wide state, freed with it
+    if (!buf.p) {
         const int NT = FB_WINDOWS * 255;
         std::vector<XYZZ<C>> pts(NT);
         Affine<C> g;
@@ -123,8 +120,11 @@ static int fixed_base_table(pm_ctx *ctx, const Affine<C> **d_table) {
             aff[i].y = mul<Q>(pts[i].Y, i3);
         }
         PM_HIP(ctx, buf.reserve(NT * sizeof(Affine<C>)));
-        PM_HIP(ctx, hipMemcpy(buf.p, aff.data(), NT * sizeof(Affine<C>), hipMemcpyHostToDevice));
-        ready[C::ID][dev] = true;
+        hipError_t he = hipMemcpy(buf.p, aff.data(), NT * sizeof(Affine<C>), hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            buf.release();
+            PM_HIP(ctx, he);
+        }
     }
     *d_table = buf.as<Affine<C>>();
     return PM_OK;
