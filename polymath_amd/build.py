@@ -14,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpolymath_hip.so")
 SOURCES = ["api.hip", "ntt.hip", "msm.hip", "prove.hip", "setup.hip"]
-HEADERS = ["field.cuh", "ec.cuh", "constants.cuh", "internal.h", os.path.join("..", "..", "include", "polymath_hip.h")]
+HEADERS = ["field.cuh", "ec.cuh", "fq28.cuh", "constants.cuh", "internal.h", os.path.join("..", "host", "hashes.hpp"),
+           os.path.join("..", "..", "include", "polymath_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -9,6 +9,7 @@
 #include <new>
 
 #include "internal.h"
+#include "fq28.cuh"
 #include "../host/hashes.hpp"
 
 using namespace pm;
@@ -132,6 +133,7 @@ struct BasesDeleter {   // frees the device allocations with the handle: error p
         (void)hipSetDevice(b->device);
         if (b->d_points) (void)hipFree(b->d_points);
         if (b->d_inf) (void)hipFree(b->d_inf);
+        if (b->d_table) (void)hipFree(b->d_table);
         delete b;
     }
 };
@@ -202,22 +204,23 @@ static int bases_precompute_impl(pm_ctx *ctx, pm_bases *b) {
     if (b->tables.c || !b->len) return PM_OK;
     MsmTables tb = tables_plan(b->len, 1, b->len, (unsigned)C::FrP::BITS);
     if (!tb.c) return PM_OK;
-    void *d_new = nullptr;
-    PM_HIP(ctx, hipMalloc(&d_new, b->len * tb.nwin * sizeof(Affine<C>)));
-    PM_HIP(ctx, hipMemcpyAsync(d_new, b->d_points, b->len * sizeof(Affine<C>), hipMemcpyDeviceToDevice, ctx->stream));
-    void *d_flags = nullptr;
-    hipError_t he = hipMalloc(&d_flags, b->len);
-    int st = he == hipSuccess ? infinity_flags<C>(ctx, (const Affine<C> *)d_new, b->len, (unsigned char *)d_flags) : PM_ERR_HIP;
-    if (st == PM_OK) st = tables_build<C>(ctx, (Affine<C> *)d_new, b->len, tb);
+    void *d_table = nullptr, *d_flags = nullptr;
+    int st = PM_OK;
+    if (hipMalloc(&d_table, b->len * tb.nwin * sizeof(TablePoint<C>)) != hipSuccess || hipMalloc(&d_flags, b->len) != hipSuccess) {
+        ctx->err = "pm_bases_precompute: out of device memory for the window tables";
+        st = PM_ERR_HIP;
+    }
+    if (st == PM_OK) st = infinity_flags<C>(ctx, (const Affine<C> *)b->d_points, b->len, (unsigned char *)d_flags);
+    if (st == PM_OK) st = tables_build<C>(ctx, (const Affine<C> *)b->d_points, (TablePoint<C> *)d_table, b->len, tb);
     if (st != PM_OK) {
-        (void)hipFree(d_new);
+        if (d_table) (void)hipFree(d_table);
         if (d_flags) (void)hipFree(d_flags);
         return st;
     }
-    PM_HIP(ctx, hipFree(b->d_points));
-    b->d_points = d_new;
+    b->d_table = d_table;
     b->d_inf = d_flags;
     tb.inf = (const unsigned char *)d_flags;
+    tb.table = d_table;
     b->tables = tb;
     return PM_OK;
 }
@@ -248,7 +251,7 @@ static int msm_resident_impl(pm_ctx *ctx, const pm_bases *bases, size_t off, con
     if (bases->tables.c) {
         MsmTables tb = bases->tables;
         tb.base_index = off;
-        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)bases->d_points, d_sc, len, &r, &inf, &tb));
+        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)nullptr, d_sc, len, &r, &inf, &tb));
     } else {
         PM_TRY(msm_run<C>(ctx, (const Affine<C> *)bases->d_points + off, d_sc, len, &r, &inf));
     }
@@ -474,15 +477,15 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
         if (!len) continue;
         MsmTables tb = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS);
         if (!tb.c) continue;
-        const double need = (double)len * tb.nwin * sizeof(Affine<C>) + (double)len;
+        const double need = (double)len * tb.nwin * sizeof(TablePoint<C>) + (double)len;
         if (need > budget) continue;
         budget -= need;
-        PM_HIP(ctx, hipMalloc(&pk->d_tab[k], len * tb.nwin * sizeof(Affine<C>)));
-        PM_HIP(ctx, hipMemcpyAsync(pk->d_tab[k], d + pk->res_dev_off[k], len * sizeof(Affine<C>), hipMemcpyDeviceToDevice, ctx->stream));
+        PM_HIP(ctx, hipMalloc(&pk->d_tab[k], len * tb.nwin * sizeof(TablePoint<C>)));
         PM_HIP(ctx, hipMalloc(&pk->d_tab_inf[k], len));
-        PM_TRY(infinity_flags<C>(ctx, (const Affine<C> *)pk->d_tab[k], (size_t)len, (unsigned char *)pk->d_tab_inf[k]));
-        PM_TRY(tables_build<C>(ctx, (Affine<C> *)pk->d_tab[k], (size_t)len, tb));
+        PM_TRY(infinity_flags<C>(ctx, d + pk->res_dev_off[k], (size_t)len, (unsigned char *)pk->d_tab_inf[k]));
+        PM_TRY(tables_build<C>(ctx, d + pk->res_dev_off[k], (TablePoint<C> *)pk->d_tab[k], (size_t)len, tb));
         tb.inf = (const unsigned char *)pk->d_tab_inf[k];
+        tb.table = pk->d_tab[k];
         pk->tables[k] = tb;
     }
     return PM_OK;

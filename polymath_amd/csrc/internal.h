@@ -90,6 +90,7 @@ struct MsmTables {
     size_t stride = 0;               // points per window
     size_t base_index = 0;           // first point of this MSM inside window 0
     const unsigned char *inf = nullptr;   // device: one flag byte per point of window 0 (1 = point at infinity)
+    const void *table = nullptr;          // device: TablePoint<C>[nwin][stride]
 };
 
 struct TwiddleCache {
@@ -105,8 +106,9 @@ struct pm_bases {
     int curve;
     int device;
     size_t len;
-    void *d_points;  // Affine<C>[len], or the window tables [nwin][len] after pm_bases_precompute
+    void *d_points;  // Affine<C>[len], internal Montgomery form
     void *d_inf;     // infinity flags of the table set (tables.inf)
+    void *d_table;   // TablePoint<C>[nwin][len] after pm_bases_precompute (tables.table)
     pm::MsmTables tables;
 };
 
@@ -170,8 +172,8 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d_data, unsigned log_n, bool inver
 template <class C>
 int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out, bool internal = false);
 
-// tables == nullptr (or c == 0): d_bases points at the MSM's first base.  Otherwise d_bases is the start of
-// the table array and tables->base_index locates the MSM's first base inside window 0.
+// tables == nullptr (or c == 0): d_bases points at the MSM's first base.  Otherwise d_bases is unused, the
+// points come from tables->table and tables->base_index locates the MSM's first base inside window 0.
 template <class C>
 int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len,
             Affine<C> *h_out, int *h_inf, const MsmTables *tables = nullptr);
@@ -179,9 +181,11 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
 // choose c and the number of windows for a key whose longest MSM has `max_len` pairs
 void msm_plan_query(size_t len, unsigned scalar_bits, unsigned *nwin, unsigned *c);
 MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits);
-// fill windows 1..nwin-1 of a table array whose window 0 holds `count` internal-form affine points
+// window 0 of d_table <- the `count` internal-form affine points at d_points; then windows 1..nwin-1
 template <class C>
-int tables_build(pm_ctx *ctx, Affine<C> *d_table, size_t count, const MsmTables &t);
+struct TablePoint;   // fq28.cuh: 128-byte, 28-bit-limb record
+template <class C>
+int tables_build(pm_ctx *ctx, const Affine<C> *d_points, TablePoint<C> *d_table, size_t count, const MsmTables &t);
 // flags[i] = 1 iff points[i] is the point at infinity (all-zero x, y)
 template <class C>
 int infinity_flags(pm_ctx *ctx, const Affine<C> *d_points, size_t count, unsigned char *d_flags);

@@ -292,13 +292,14 @@ __global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, cons
 }
 
 // ---------------------------------------------------------------------------- accumulate
-// One lane per task (taken in order[]).  The accumulator lives in reduced-radix registers (fq28.cuh): 10 carry-free
+// One lane per task (taken in order[]); TABLE selects the point record (TablePoint of a window table, or the
+// dense affine array of the per-window pipeline).  The accumulator lives in reduced-radix registers (fq28.cuh): 10 carry-free
 // Montgomery products and 7 lazy add/sub per mixed add.  `bases` are in INTERNAL Montgomery form.
 // The exceptional case acc == +-point (doubling / cancellation) is resolved on the dense path.
-template <class C>
+template <class C, bool TABLE>
 __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, const uint32_t *counts,
                                                     const uint32_t *bucket_off, const uint32_t *task_off,
-                                                    const uint32_t *order, const Affine<C> *bases, XYZZ<C> *partials, size_t G,
+                                                    const uint32_t *order, const void *points, XYZZ<C> *partials, size_t G,
                                                     unsigned seg) {
     typedef typename C::FqRR RR;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,8 +321,17 @@ __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, cons
     acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
     for (uint32_t e = start; e < end; ++e) {
         const uint32_t v = sorted[e];
-        const Affine<C> p = bases[v >> 1];
-        if (!xyzz28_madd<C>(acc, p, (v & 1u) != 0)) acc = xyzz28_madd_exceptional<C>(acc, p, (v & 1u) != 0);
+        const bool neg = (v & 1u) != 0;
+        if (TABLE) {   // window tables: one aligned 128-byte record, already on 28-bit limbs
+            const TablePoint<C> tp = ((const TablePoint<C> *)points)[v >> 1];
+            F28<RR> x2, y2;
+#pragma unroll
+            for (int i = 0; i < RR::N; ++i) { x2.l[i] = tp.x[i]; y2.l[i] = tp.y[i]; }
+            if (!xyzz28_madd_limbs<C>(acc, x2, y2, neg)) acc = xyzz28_madd_exceptional<C>(acc, table_point_to_affine<C>(tp), neg);
+        } else {
+            const Affine<C> p = ((const Affine<C> *)points)[v >> 1];
+            if (!xyzz28_madd<C>(acc, p, neg)) acc = xyzz28_madd_exceptional<C>(acc, p, neg);
+        }
     }
     partials[t] = xyzz28_store<C>(acc);   // INTERNAL form: the bucket reduction stays on reduced-radix arithmetic
 }
@@ -948,8 +958,8 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
     {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
         size_t blocks = (p.max_tasks + 127) / 128;
-        hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(),
-                           counts, ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), d_bases,
+        hipLaunchKernelGGL((k_accumulate<C, false>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(),
+                           counts, ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), (const void *)d_bases,
                            ws.partials.as<XYZZ<C>>(), G, p.seg);
         PM_HIP(ctx, hipGetLastError());
     }
@@ -971,7 +981,7 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
 
 // ------------------------------------------------------------------------- table-mode driver
 template <class C>
-static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTables &tb, const Fp<typename C::FrP> *d_scalars,
+static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename C::FrP> *d_scalars,
                             size_t len, Affine<C> *h_out, int *h_inf) {
     typedef typename C::FrP FrP;
     typedef Fp<FrP> Fr;
@@ -1111,8 +1121,8 @@ static int msm_piece_tables(pm_ctx *ctx, const Affine<C> *d_table, const MsmTabl
     {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
         size_t blocks = (max_tasks + 127) / 128;
-        hipLaunchKernelGGL(k_accumulate<C>, dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
-                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), d_table,
+        hipLaunchKernelGGL((k_accumulate<C, true>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
+                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), tb.table,
                            ws.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
         PM_HIP(ctx, hipGetLastError());
     }
@@ -1154,7 +1164,7 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
     }
     const bool tbl = tables && tables->c;
     if (len <= MSM_MAX_PIECE)
-        return tbl ? msm_piece_tables<C>(ctx, d_bases, *tables, d_scalars, len, h_out, h_inf)
+        return tbl ? msm_piece_tables<C>(ctx, *tables, d_scalars, len, h_out, h_inf)
                    : msm_piece<C>(ctx, d_bases, d_scalars, len, h_out, h_inf);
     // very long MSMs (the 10n-pair quotient commitment at n >= 2^24 on one GPU): pieces, summed on the host
     XYZZ<C> acc = XYZZ<C>::identity();
@@ -1165,7 +1175,7 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
         if (tbl) {
             MsmTables tb = *tables;
             tb.base_index += off;
-            PM_TRY(msm_piece_tables<C>(ctx, d_bases, tb, d_scalars + off, cnt, &part, &inf));
+            PM_TRY(msm_piece_tables<C>(ctx, tb, d_scalars + off, cnt, &part, &inf));
         } else {
             PM_TRY(msm_piece<C>(ctx, d_bases + off, d_scalars + off, cnt, &part, &inf));
         }

@@ -339,7 +339,7 @@ static int msm_shard(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename 
     if (pk->tables[which].c) {   // this MSM's own window tables (window 0 = its resident slice)
         MsmTables tb = pk->tables[which];
         tb.base_index = 0;
-        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)pk->d_tab[which], d_scalars + lo, (size_t)(hi - lo), &r, &inf, &tb));
+        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)nullptr, d_scalars + lo, (size_t)(hi - lo), &r, &inf, &tb));
     } else {
         PM_TRY(msm_run<C>(ctx, bases, d_scalars + lo, (size_t)(hi - lo), &r, &inf));
     }

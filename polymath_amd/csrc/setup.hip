@@ -197,14 +197,22 @@ int bases_convert(pm_ctx *ctx, Affine<C> *d_points, size_t len, bool to_internal
 }
 
 // ------------------------------------------------------------------------------ window tables
-// T_w[i] = 2^c T_{w-1}[i]: c doublings on F28 registers, then back to affine with a per-lane Montgomery
-// batch inversion over TB_BATCH points (all in the internal radix).
+// Window 0 = the resident (internal-form, dense) points re-limbed into 128-byte TablePoint records;
+// T_w[i] = 2^(width of window w-1) T_{w-1}[i]: doublings on F28 registers, then back to affine with a
+// per-lane Montgomery batch inversion over TB_BATCH points (all in the internal radix).
 constexpr int TB_BATCH = 8;
 
 template <class C>
-__global__ __launch_bounds__(128) void k_table_next(const Affine<C> *prev, Affine<C> *next, size_t count, unsigned c) {
+__global__ void k_table_window0(const Affine<C> *src, TablePoint<C> *dst, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = table_point_from_affine<C>(src[i]);   // infinity (all-zero) stays all-zero
+}
+
+template <class C>
+__global__ __launch_bounds__(128) void k_table_next(const TablePoint<C> *prev, TablePoint<C> *next, size_t count, unsigned c) {
     typedef typename C::FqRR RR;
     typedef F28<RR> F;
+    constexpr int N = RR::N;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t lo = t * TB_BATCH;
     if (lo >= count) return;
@@ -213,39 +221,49 @@ __global__ __launch_bounds__(128) void k_table_next(const Affine<C> *prev, Affin
     bool live[TB_BATCH];
     F run = f28_one<RR>();
     for (size_t i = 0; i < cnt; ++i) {
-        Affine<C> p = prev[lo + i];
-        live[i] = !p.is_inf();
+        const TablePoint<C> p = prev[lo + i];
+        uint32_t any = 0;
+        XYZZ28<C> a;
+        for (int k = 0; k < N; ++k) { a.X.l[k] = p.x[k]; a.Y.l[k] = p.y[k]; any |= p.x[k] | p.y[k]; }
+        live[i] = any != 0;
         pre[i] = run;
         if (!live[i]) continue;
-        XYZZ28<C> a;
-        a.X = f28_unpack<RR>(p.x.l);
-        a.Y = f28_unpack<RR>(p.y.l);
         a.ZZ = f28_one<RR>();
         a.ZZZ = f28_one<RR>();
         for (unsigned k = 0; k < c; ++k) xyzz28_dbl<C>(a);
-        XYZZ<C> rec = xyzz28_store<C>(a);          // canonical internal words
-        next[lo + i].x = rec.X;                     // parked until the inverses are known
-        next[lo + i].y = rec.Y;
+        TablePoint<C> park;                          // X, Y (tight limbs) parked until the inverses are known
+        for (int k = 0; k < N; ++k) { park.x[k] = a.X.l[k]; park.y[k] = a.Y.l[k]; }
+        next[lo + i] = park;
         zz[i] = a.ZZ;
         zzz[i] = a.ZZZ;
         run = f28_mul<RR>(run, a.ZZZ);
     }
     F inv = f28_inverse<RR>(run);
     for (size_t ii = cnt; ii-- > 0;) {
-        if (!live[ii]) { next[lo + ii] = Affine<C>::infinity(); continue; }
+        TablePoint<C> out;
+        if (!live[ii]) {
+            for (int k = 0; k < N; ++k) out.x[k] = out.y[k] = 0;
+            next[lo + ii] = out;
+            continue;
+        }
         F i3 = f28_mul<RR>(inv, pre[ii]);           // 1 / ZZZ
         inv = f28_mul<RR>(inv, zzz[ii]);
         F i2 = f28_sqr<RR>(f28_mul<RR>(i3, zz[ii]));  // 1 / ZZ
-        Affine<C> out;
-        f28_pack_reduced<RR>(f28_mul<RR>(f28_unpack<RR>(next[lo + ii].x.l), i2), out.x.l);
-        f28_pack_reduced<RR>(f28_mul<RR>(f28_unpack<RR>(next[lo + ii].y.l), i3), out.y.l);
+        const TablePoint<C> park = next[lo + ii];
+        F X, Y;
+        for (int k = 0; k < N; ++k) { X.l[k] = park.x[k]; Y.l[k] = park.y[k]; }
+        X = f28_canonical<RR>(f28_mul<RR>(X, i2));
+        Y = f28_canonical<RR>(f28_mul<RR>(Y, i3));
+        for (int k = 0; k < N; ++k) { out.x[k] = X.l[k]; out.y[k] = Y.l[k]; }
         next[lo + ii] = out;
     }
 }
 
 template <class C>
-int tables_build(pm_ctx *ctx, Affine<C> *d_table, size_t count, const MsmTables &t) {
+int tables_build(pm_ctx *ctx, const Affine<C> *d_points, TablePoint<C> *d_table, size_t count, const MsmTables &t) {
     if (!t.c || !count) return PM_OK;
+    hipLaunchKernelGGL(k_table_window0<C>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_points, d_table, count);
+    PM_HIP(ctx, hipGetLastError());
     size_t lanes = (count + TB_BATCH - 1) / TB_BATCH;
     for (unsigned w = 1; w < t.nwin; ++w) {   // T_w = 2^(width of window w-1) * T_{w-1}
         hipLaunchKernelGGL(k_table_next<C>, dim3((unsigned)((lanes + 127) / 128)), dim3(128), 0, ctx->stream,
@@ -323,7 +341,7 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
     template int fixed_base_batch<C>(pm_ctx *, const Fp<typename C::FrP> *, size_t, Affine<C> *);               \
     template int bases_generate_multiples<C>(pm_ctx *, size_t, Affine<C> *);                                    \
     template int bases_convert<C>(pm_ctx *, Affine<C> *, size_t, bool);                                          \
-    template int tables_build<C>(pm_ctx *, Affine<C> *, size_t, const MsmTables &);                             \
+    template int tables_build<C>(pm_ctx *, const Affine<C> *, TablePoint<C> *, size_t, const MsmTables &);                             \
     template int infinity_flags<C>(pm_ctx *, const Affine<C> *, size_t, unsigned char *);
 PM_INST(BlsCurve)
 PM_INST(BnCurve)
