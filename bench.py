@@ -160,7 +160,7 @@ def main():
     assert proof_host.to_bytes() == proof.to_bytes()
     n = pk.n
     d_pairs_total = 10 * n + 22                     # quotient MSM M8 (prover.rs:229)
-    d_pairs_rank = d_pairs_total * (rank + 1) // world - d_pairs_total * rank // world
+    d_pairs_rank = d_pairs_total * (shard_rank + 1) // shard_count - d_pairs_total * shard_rank // shard_count
     pairs_per_proof = (n + 3) + (2 * r1cs.m0 + r1cs.mw + nr + (n - 1) + (n + 1) + 5) + d_pairs_total
     avg = lambda v: sum(v) / max(len(v), 1)
     if rank == 0:
@@ -174,7 +174,7 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                key = "k_accumulate/%s/2^%d/%dgpu" % (curve, args.log_constraints, world)
+                key = "k_accumulate/%s/2^%d/%dgpu" % (curve, args.log_constraints, shard_count)
                 traffic = tj.get(key)
             except Exception:
                 traffic = None
