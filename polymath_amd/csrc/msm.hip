@@ -357,9 +357,70 @@ __device__ __forceinline__ void lds_tree_sum(XYZZ28<C> *sh) {
     }
 }
 
+// ------------------------------------------------------------------------------- hot buckets
+// Skewed scalars (the reference's own bench circuit repeats one witness value 2^20 times, benches/bench.rs:
+// 49-51) put ~len entries into one bucket per window: the task split keeps k_accumulate balanced, but the
+// bucket then owns thousands of task partials, and the reduction's lane would add them one after the other
+// (measured: 268 ms).  k_task_counts lists the buckets with many tasks; k_task_fold sums such a bucket's
+// partials in parallel into its first slot and sets its effective task count to 1.
+//   tier A: more than FOLD_BLOCK_MIN tasks -> one workgroup per bucket;  tier B: more than FOLD_MIN -> one wave.
+constexpr uint32_t FOLD_MIN = 8, FOLD_BLOCK_MIN = 1024;
+
+__global__ void k_task_counts(const uint32_t *task_off, size_t G, uint32_t *task_cnt, uint32_t *hot_a, uint32_t *hot_b,
+                              uint32_t *hot_counts /*[2], zeroed*/, uint32_t cap) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t n = task_off[g + 1] - task_off[g];
+    task_cnt[g] = n;
+    if (n > FOLD_BLOCK_MIN) {
+        const uint32_t i = atomicAdd(&hot_counts[0], 1u);
+        if (i < cap) hot_a[i] = (uint32_t)g;   // an unlisted bucket keeps its sequential sum
+    } else if (n > FOLD_MIN) {
+        const uint32_t i = atomicAdd(&hot_counts[1], 1u);
+        if (i < cap) hot_b[i] = (uint32_t)g;
+    }
+}
+
+// LANES = 256: one workgroup per listed bucket (tier A);  LANES = 64: one wave per listed bucket (tier B)
+template <class C, unsigned LANES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_task_fold(XYZZ<C> *partials, const uint32_t *task_off, uint32_t *task_cnt,
+                                                   const uint32_t *hot, const uint32_t *hot_count, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    uint32_t listed = *hot_count;
+    if (listed > cap) listed = cap;
+    constexpr unsigned GROUPS = 256 / LANES;                       // buckets per workgroup per round
+    const unsigned group = threadIdx.x / LANES, lane = threadIdx.x % LANES;
+    for (uint32_t h0 = blockIdx.x * GROUPS; h0 < listed; h0 += gridDim.x * GROUPS) {   // uniform trip count per workgroup
+        const uint32_t h = h0 + group;
+        XYZZ28<C> *acc = &sh[threadIdx.x];
+        acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
+        uint32_t first = 0, n = 0;
+        if (h < listed) {
+            first = task_off[hot[h]];
+            n = task_off[hot[h] + 1] - first;
+            for (uint32_t i = lane; i < n; i += LANES) xyzz28_add_into_full<C>(acc, xyzz28_load<C>(partials[first + i]));
+        }
+        __syncthreads();
+        for (unsigned off = LANES >> 1; off > 0; off >>= 1) {
+            if (lane < off) {
+                const XYZZ28<C> b = sh[threadIdx.x + off];
+                xyzz28_add_into_full<C>(&sh[threadIdx.x], b);
+            }
+            __syncthreads();
+        }
+        if (h < listed && lane == 0) {
+            partials[first] = xyzz28_store<C>(sh[threadIdx.x]);
+            task_cnt[hot[h]] = 1;
+        }
+        __syncthreads();
+    }
+}
+
 // Input bucket b = sum of its task partials, weight b + 1 (a Pippenger window).
 template <class C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, unsigned nbuckets,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bucket_reduce(const XYZZ<C> *partials, const uint32_t *task_off, const uint32_t *task_cnt, unsigned nbuckets,
                                                        unsigned lanes_per_window, unsigned bpw, XYZZ<C> *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
@@ -374,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const size_t gbase = (size_t)w * nbuckets + (size_t)j * RED_K;
         for (int i = (int)RED_K - 1; i >= 0; --i) {
             if ((size_t)j * RED_K + i >= nbuckets) continue;
-            for (uint32_t q = task_off[gbase + i]; q < task_off[gbase + i + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
+            for (uint32_t q = task_off[gbase + i], qe = q + task_cnt[gbase + i]; q < qe; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
             xyzz28_add_into_full<C>(acc, run);                 // weight i + 1
         }
         const uint32_t s = j * RED_K;          // acc += s * run
@@ -796,7 +857,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t *cnt, uint32
 //   final    one workgroup sums the level-1 partials.
 //   S = sum_t acc_t + sum_t (t K0) A_t.
 template <class C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, size_t nbuckets, size_t lanes,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, const uint32_t *task_cnt, size_t nbuckets, size_t lanes,
                                                        unsigned K0, XYZZ<C> *outA, XYZZ<C> *outAcc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
@@ -810,7 +871,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = (int)K0 - 1; j >= 0; --j) {
         const size_t g = t * K0 + (size_t)j;
         if (g >= nbuckets) continue;
-        for (uint32_t q = task_off[g]; q < task_off[g + 1]; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
+        for (uint32_t q = task_off[g], qe = q + task_cnt[g]; q < qe; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
         xyzz28_add_into_full<C>(acc, run);
     }
     outA[t] = xyzz28_store<C>(run);
@@ -877,6 +938,29 @@ static void host_finish(const XYZZ<C> *S /*[nwin], internal form*/, unsigned nwi
     }
     *inf = acc.is_identity() ? 1 : 0;
     *out = xyzz_to_affine<C>(acc);
+}
+
+// effective task counts for the reduction + parallel fold of hot buckets (k_task_counts / k_task_fold);
+// enqueued after k_accumulate, before the bucket reduction
+template <class C>
+static int fold_hot_buckets(pm_ctx *ctx, size_t G, size_t max_tasks) {
+    MsmWorkspace &ws = ctx->msm;
+    size_t cap = max_tasks > G ? max_tasks - G + 1 : 1;          // a listed bucket has > FOLD_MIN tasks
+    cap = cap / FOLD_MIN + 1;
+    PM_HIP(ctx, ws.task_cnt.reserve(G * 4));
+    PM_HIP(ctx, ws.hot.reserve((2 * cap + 2) * 4));
+    uint32_t *hot_counts = ws.hot.as<uint32_t>(), *hot_a = hot_counts + 2, *hot_b = hot_a + cap;
+    PM_HIP(ctx, hipMemsetAsync(hot_counts, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_task_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx->stream, ws.task_off.as<uint32_t>(), G,
+                       ws.task_cnt.as<uint32_t>(), hot_a, hot_b, hot_counts, (uint32_t)cap);
+    PM_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL((k_task_fold<C, 256>), dim3(256), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, ws.partials.as<XYZZ<C>>(),
+                       ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), hot_a, hot_counts, (uint32_t)cap);
+    PM_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL((k_task_fold<C, 64>), dim3(1024), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, ws.partials.as<XYZZ<C>>(),
+                       ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), hot_b, hot_counts + 1, (uint32_t)cap);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
 }
 
 // order[] for k_accumulate (see k_task_bins); enqueued on the context's stream after the bucket scan.
@@ -966,9 +1050,10 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
     std::vector<XYZZ<C>> hS(p.nwin);
     {
         StageTimer t(ctx, T_MSM_REDUCE);
+        PM_TRY(fold_hot_buckets<C>(ctx, G, p.max_tasks));
         XYZZ<C> *parts = ws.wsum.as<XYZZ<C>>(), *dS = parts + (size_t)p.nwin * bpw;
         hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
-                           ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), p.nbuckets, red_lanes, bpw, parts);
+                           ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), p.nbuckets, red_lanes, bpw, parts);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_sum_parts<C>, dim3(p.nwin), dim3(64), 0, ctx->stream, parts, bpw, dS);
         PM_HIP(ctx, hipGetLastError());
@@ -1129,10 +1214,11 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     XYZZ<C> hres;
     {
         StageTimer t(ctx, T_MSM_REDUCE);
+        PM_TRY(fold_hot_buckets<C>(ctx, NB, max_tasks));
         XYZZ<C> *A = ws.wsum.as<XYZZ<C>>(), *Acc = A + lanes0, *parts = Acc + lanes0, *dres = parts + (blocks0 > bpw ? blocks0 : bpw);
         if (two_level) {
             hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
-                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), NB, lanes0, K0, A, Acc);
+                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), NB, lanes0, K0, A, Acc);
             PM_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(k_reduce_level1<C>, dim3((unsigned)blocks1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, A, Acc, lanes0,
                                K0, R1, parts);
@@ -1140,7 +1226,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             hipLaunchKernelGGL(k_sum_final<C>, dim3(1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
         } else {
             hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
-                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), (unsigned)NB, red_lanes, bpw, parts);
+                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), (unsigned)NB, red_lanes, bpw, parts);
             PM_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(k_sum_final<C>, dim3(1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, bpw, dres);
         }

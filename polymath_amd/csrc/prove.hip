@@ -187,11 +187,17 @@ __global__ __launch_bounds__(256) void k_horner_partial(const Fp<P> *u, uint64_t
 }
 
 template <class P>
-__global__ void k_sum_small(const Fp<P> *in, unsigned count, Fp<P> *out) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ __launch_bounds__(256) void k_sum_small(const Fp<P> *in, unsigned count, Fp<P> *out) {   // one workgroup
+    __shared__ Fp<P> sh[256];
     Fp<P> acc = Fp<P>::zero();
-    for (unsigned i = 0; i < count; ++i) acc = add<P>(acc, in[i]);
-    out[0] = acc;
+    for (unsigned i = threadIdx.x; i < count; i += 256) acc = add<P>(acc, in[i]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = add<P>(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
 }
 
 // ------------------------------------------------------------- numerator + division (phase 3)
@@ -481,7 +487,7 @@ int prove_phase2_impl(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) {
     Fr *part = ctx->scratch.as<Fr>();
     hipLaunchKernelGGL(k_horner_partial<P>, dim3(blocks), dim3(256), 0, st, ctx->u.as<Fr>(), n, x1, L, part);
     PM_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_sum_small<P>, dim3(1), dim3(64), 0, st, part, blocks, part + blocks);
+    hipLaunchKernelGGL(k_sum_small<P>, dim3(1), dim3(256), 0, st, part, blocks, part + blocks);
     PM_HIP(ctx, hipGetLastError());
     PM_HIP(ctx, hipMemcpyAsync(u_at_x1, part + blocks, sizeof(Fr), hipMemcpyDeviceToHost, st));
     PM_HIP(ctx, hipStreamSynchronize(st));

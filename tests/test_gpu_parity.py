@@ -144,6 +144,26 @@ def test_msm_skewed_scalars_hot_buckets(gpu_ctx, oracle, api):
     assert np.array_equal(out, ref)
 
 
+def test_msm_hot_bucket_fold_tiers(gpu_ctx, oracle, api):
+    """One repeated scalar over 2^18 pairs: a hot bucket per window owns thousands of task partials, which the
+    reduction folds in parallel (msm.hip: k_task_fold, one workgroup per bucket above 1024 tasks, one wave above
+    8) instead of adding them on one lane (268 ms at 2^20 before).  Per-window pipeline and window tables; a
+    second, smaller repeated value lands in the wave tier."""
+    curve, n = "bls12_381", 1 << 18
+    bases = api.Bases.multiples(gpu_ctx, curve, n)
+    hb = bases.download()
+    vals = rand_fr_limbs(curve, 2, 21)
+    sc = np.repeat(vals[:1], n, axis=0)
+    sc[1::5] = vals[1]                                   # ~52 K copies of a second value
+    sc[::1013] = rand_fr_limbs(curve, len(sc[::1013]), 22)
+    ref, _ = oracle.msm(curve, hb, sc, 8)
+    out, _ = bases.msm(sc)
+    assert np.array_equal(out, ref)
+    bases.precompute()
+    out, _ = bases.msm(sc)
+    assert np.array_equal(out, ref)
+
+
 def test_msm_full_size_linearity(gpu_ctx, oracle, api):
     """2^20 pairs (too slow for the CPU restatement in a unit test): MSM(s) + MSM(t) == MSM(s + t),
     and a sub-range agrees with the CPU on its own."""

@@ -1,0 +1,26 @@
+import sys, time
+sys.path.insert(0, '.')
+from polymath_amd import circuits as PC
+from polymath_amd.polymath import Polymath, FIELDS
+r = FIELDS["bls12_381"]["r"]
+nc = (1 << 20) - 100
+g = PC.SplitMix64(7)
+circ = PC.BenchCircuit(g.fr(r), g.fr(r), nc, nc)      # benches/bench.rs:16-17: num_variables = num_constraints
+pm = Polymath("bls12_381", "merlin", device=0)
+t0 = time.time()
+r1cs, inst, wit = pm._synthesize(circ)
+print("synth", time.time() - t0, r1cs.m0, r1cs.mw, r1cs.nr)
+x, z, r_a = g.fr(r), g.fr(r), [g.fr(r), g.fr(r)]
+t0 = time.time(); pk = pm.setup((r1cs, inst, wit), x, z); print("setup", time.time() - t0, pk.n)
+f = pm.field
+xl, wl = f.fr_limbs(inst), f.fr_limbs(wit)
+pm.prove_limbs(pk, inst, xl, wl, r_a)
+pm.collect_timings = True
+t0 = time.perf_counter(); p = pm.prove_limbs(pk, inst, xl, wl, r_a); dt = time.perf_counter() - t0
+print("prove ms", dt * 1e3)
+for i, tm in enumerate(pm.phase_timings): print(i + 1, {k: round(v, 2) for k, v in tm.items() if v})
+# acceptance: pairing verifier (oracle)
+from oracle.pyref import pairing as PA, protocol as PR, transcripts as T
+from oracle.pyref.fields import BLS12_381 as c, BLS12_381_G2
+vk = dict(n=pk.n, m0=r1cs.m0, sigma=pk.sigma, omega=pk.omega, one_g1=c.g1, one_g2=BLS12_381_G2, x_g2=PA.g2_mul(BLS12_381_G2, x), z_g2=PA.g2_mul(BLS12_381_G2, z))
+print("verify", PR.verify_proof(c, vk, p.as_dict(), inst[1:], T.make_transcripts(c)["merlin"], PA.pairing_check))
