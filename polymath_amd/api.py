@@ -284,6 +284,14 @@ class ProvingKey:
                                    ct.byref(c.struct), BA, shard_rank, shard_count, ct.byref(h)))
         return cls(ctx, curve, h, (a, b, c))
 
+    def view(self, ctx):
+        """The same resident key used from another context (a pm_pk is immutable and shareable; each context runs
+        one proof at a time).  The view does not own the handle: free the original."""
+        v = ProvingKey.__new__(ProvingKey)
+        v.__dict__.update(self.__dict__)
+        v.ctx, v._view = ctx, True
+        return v
+
     def msm_plan(self, which):
         """(pairs, windows = bucket additions per pair, window bits, has tables) of merged MSM 0 = a, 1 = c, 2 = d."""
         pairs, win, bits, tb = ct.c_uint64(), ct.c_uint(), ct.c_uint(), ct.c_int()
@@ -336,9 +344,9 @@ class ProvingKey:
         return out[:min(n.value, max_elems)]
 
     def free(self):
-        if self.h:
+        if self.h and not getattr(self, "_view", False):
             self.ctx.L.pm_pk_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
