@@ -417,6 +417,34 @@ def test_full_size_2p20_proof_passes_pairing_verifier(oracle):
     pk.free()
 
 
+def test_reference_bench_circuit_skew(oracle):
+    """benches/bench.rs:38-61 at 2^18 - 100 constraints: every padding witness carries the same value, so one
+    bucket per window of the [c] MSM owns ~2^18 entries (SURVEY.md §8d "skewed worst case").  The pairing
+    verifier accepts the proof; the hot buckets go through k_task_fold (a sequential sum took 268 ms at 2^20)."""
+    import time
+    from oracle.pyref import pairing as PA, protocol as PR
+    from oracle.pyref.fields import BLS12_381 as c, BLS12_381_G2
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    nc = (1 << 18) - 100
+    g = PC.SplitMix64(0xBEAC4)
+    pm = Polymath("bls12_381", "merlin", device=0)
+    r1cs, inst, wit = pm._synthesize(PC.BenchCircuit(g.fr(c.r), g.fr(c.r), nc, nc))
+    assert len(set(wit[2:])) == 1                                    # the skew itself
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    pk = pm.setup((r1cs, inst, wit), x, z)
+    xl, wl = pm.field.fr_limbs(inst), pm.field.fr_limbs(wit)
+    pm.prove_limbs(pk, inst, xl, wl, r_a)
+    t0 = time.perf_counter()
+    proof = pm.prove_limbs(pk, inst, xl, wl, r_a)
+    dt = time.perf_counter() - t0
+    vk = dict(n=pk.n, m0=r1cs.m0, sigma=pk.sigma, omega=pk.omega, one_g1=c.g1, one_g2=BLS12_381_G2,
+              x_g2=PA.g2_mul(BLS12_381_G2, x), z_g2=PA.g2_mul(BLS12_381_G2, z))
+    assert PR.verify_proof(c, vk, proof.as_dict(), inst[1:], T.make_transcripts(c)["merlin"], PA.pairing_check)
+    assert dt < 0.2, "skewed proof took %.0f ms: hot buckets are being reduced sequentially again" % (dt * 1e3)
+    pk.free()
+
+
 def test_phase1_device_resident_assignment_equals_host(gpu_ctx, oracle, api):
     """pm_prove_phase1_device (assignment already in HBM) == pm_prove_phase1 (host buffers).  Device buffers
     come straight from the HIP runtime the library itself uses (no torch in this process)."""
