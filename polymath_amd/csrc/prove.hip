@@ -95,6 +95,23 @@ __global__ void k_copy_zero_head(const Fp<P> *src, Fp<P> *dst, uint64_t n, uint6
     if (i < n) dst[i] = i < zero_rows ? Fp<P>::zero() : src[i];
 }
 
+// Coefficients of the witness-only part of u (N5, prover.rs:160-162) without a transform: its evaluations are
+// u's with the first `head` rows zeroed, so  wit_u = u - iNTT(head rows)  and the iNTT of a `head`-sparse
+// vector is a direct sum:  wit_u[k] = u[k] - n^-1 sum_{j < head} ue[j] w^(-jk)   (head = 2 m0, Horner in w^-k).
+// winv[k] = w^-k for k < n/2 (the inverse twiddle table); w^-(k + n/2) = -w^-k.
+template <class P>
+__global__ void k_wit_u_sparse(const Fp<P> *u, const Fp<P> *ue, const Fp<P> *winv, Fp<P> ninv, uint64_t n, unsigned head,
+                               Fp<P> *wit_u) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t half = n >> 1;
+    Fp<P> wk = winv[k < half ? k : k - half];
+    if (k >= half) wk = neg<P>(wk);
+    Fp<P> s = ue[head - 1];
+    for (int j = (int)head - 2; j >= 0; --j) s = add<P>(mul<P>(s, wk), ue[j]);
+    wit_u[k] = sub<P>(u[k], mul<P>(s, ninv));
+}
+
 template <class P>
 __global__ void k_pad_copy(const Fp<P> *src, Fp<P> *dst, uint64_t n_src, uint64_t n_dst) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -408,11 +425,20 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     // N1, N2, N5 (prover.rs:94,96,160-162): coefficients of u, w and of the witness-only U part
     PM_HIP(ctx, hipMemcpyAsync(u, ue, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     PM_HIP(ctx, hipMemcpyAsync(wv, we, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_copy_zero_head<P>, dim3(nblk(n)), dim3(256), 0, st, ue, wit_u, n, 2 * m0);
-    PM_HIP(ctx, hipGetLastError());
     PM_TRY(ntt_run<C>(ctx, u, pk->log_n, true));
     PM_TRY(ntt_run<C>(ctx, wv, pk->log_n, true));
-    PM_TRY(ntt_run<C>(ctx, wit_u, pk->log_n, true));
+    if (2 * m0 <= 16 && pk->log_n >= 1) {   // few public inputs: the sparse sum beats a fifth transform
+        const Fr *winv = nullptr;
+        PM_TRY(twiddles_get<C>(ctx, pk->log_n, true, &winv));
+        StageTimer t(ctx, T_NTT);
+        hipLaunchKernelGGL(k_wit_u_sparse<P>, dim3(nblk(n)), dim3(256), 0, st, u, ue, winv, inverse<P>(from_u64<P>(n)), n,
+                           (unsigned)(2 * m0), wit_u);
+        PM_HIP(ctx, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_copy_zero_head<P>, dim3(nblk(n)), dim3(256), 0, st, ue, wit_u, n, 2 * m0);
+        PM_HIP(ctx, hipGetLastError());
+        PM_TRY(ntt_run<C>(ctx, wit_u, pk->log_n, true));
+    }
     // square_polynomial (prover.rs:315-328) via the negacyclic half (see k_twist); the 2n-point domain of
     // the reference must still exist (checked above), its root psi = omega_2n is the twist.
     {
