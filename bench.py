@@ -128,7 +128,8 @@ def main():
     proof = None
     for _ in range(args.warmup):
         proof = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs)
-    acc_ms, msm_ms, sort_ms, red_ms, ntt_ms, phase_ms = [], [], [], [], [], []
+    acc_ms, msm_ms, sort_ms, red_ms, ntt_ms, phase_ms, acc1_ms = [], [], [], [], [], [], []
+    pm.collect_timings = True                       # keeps the stage slots of all three phases (3 tiny ctypes calls per proof)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -136,7 +137,9 @@ def main():
         tm = pm.ctx.timings()                       # phase-3 slots (the 10n+22-pair quotient MSM)
         acc_ms.append(tm["msm_accumulate"]); msm_ms.append(tm["msm_total"]); sort_ms.append(tm["msm_sort"])
         red_ms.append(tm["msm_reduce"]); phase_ms.append(tm["phase"])
+        acc1_ms.append(pm.phase_timings[0]["msm_accumulate"])   # [a]_1 and [c]_1 launches (phase 1)
     barrier()
+    pm.collect_timings = False
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -165,16 +168,22 @@ def main():
     avg = lambda v: sum(v) / max(len(v), 1)
     if rank == 0:
         bpp = MSM_BYTES_PER_PAIR[curve]
-        acc_s = avg(acc_ms) * 1e-3
-        msm_windows = pk.msm_windows(2)                # mixed adds per pair of the quotient MSM (table windows, or ceil(bits/c))
-        mads_rank = float(MADS_PER_MIXED_ADD[curve]) * msm_windows * d_pairs_rank
-        achieved = (bpp * d_pairs_rank / acc_s / 1e9) if acc_s > 0 else 0.0
+        # Dominant kernel: k_accumulate, launched once per merged MSM = 3 launches per proof ([a], [c], [d]).  Roofline
+        # over ALL of them: algorithmic bytes per launch = 128 B x (this rank's pairs of the three MSMs) / 3, average
+        # launch duration = (HIP-event time of the three launches) / 3 -- the same average rocprofv3 --stats prints.
+        plans = [pk.msm_plan(k) for k in range(3)]              # (resident pairs, windows, bits, tables)
+        launches = 3
+        acc_s = (avg(acc_ms) + avg(acc1_ms)) * 1e-3            # per proof, all three launches
+        pairs_rank = sum(p[0] for p in plans)
+        achieved = (bpp * pairs_rank / acc_s / 1e9) if acc_s > 0 else 0.0
+        mads_rank = float(MADS_PER_MIXED_ADD[curve]) * sum(p[0] * p[1] for p in plans)
+        msm_windows = plans[2][1]
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                key = "k_accumulate/%s/2^%d/%dgpu" % (curve, args.log_constraints, shard_count)
+                key = "k_accumulate/%s/2^%d/%dgpu/avg_launch" % (curve, args.log_constraints, shard_count)
                 traffic = tj.get(key)
             except Exception:
                 traffic = None
@@ -192,14 +201,17 @@ def main():
             "msm_d_pairs_per_sec_kernel_time": d_pairs_rank / (avg(msm_ms) * 1e-3) if avg(msm_ms) > 0 else None,
             "stage_ms_phase3": {"msm_sort": avg(sort_ms), "msm_accumulate": avg(acc_ms), "msm_reduce": avg(red_ms),
                                 "msm_total": avg(msm_ms), "phase3_total": avg(phase_ms)},
-            "roofline": {"bound": "hbm", "kernel": "k_accumulate (MSM bucket accumulation, quotient MSM M8)",
+            "roofline": {"bound": "hbm", "kernel": "k_accumulate (MSM bucket accumulation; %d launches per proof: [a], [c], [d])" % launches,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "note": "algorithmic bytes = %d B/pair x %d pairs per launch; the kernel is integer-ALU-bound "
+                         "traffic": traffic, "launches_per_step": launches, "avg_launch_ms": acc_s * 1e3 / launches,
+                         "algorithmic_bytes_per_launch": bpp * pairs_rank / launches,
+                         "largest_launch": {"pairs": d_pairs_rank, "ms": avg(acc_ms),
+                                            "achieved": (bpp * d_pairs_rank / (avg(acc_ms) * 1e-3) / 1e9) if avg(acc_ms) > 0 else None},
+                         "note": "algorithmic bytes = %d B/pair x %d pairs over %d launches; the kernel is integer-ALU-bound "
                                  "(%d mixed adds x %d v_mad_u64_u32 per pair: see `valu` and DESIGN.md §4.2)" %
-                                 (bpp, d_pairs_rank, msm_windows, MADS_PER_MIXED_ADD[curve])},
+                                 (bpp, pairs_rank, launches, msm_windows, MADS_PER_MIXED_ADD[curve])},
             "valu": {"kernel": "k_accumulate", "unit": "lane-mads/s (v_mad_u64_u32)", "mads_per_mixed_add": MADS_PER_MIXED_ADD[curve],
-                     "mixed_adds_per_pair": msm_windows, "achieved": mads_rank / acc_s if acc_s > 0 else None, "peak": VALU_MAD_PEAK,
+                     "mixed_adds_per_pair": [p[1] for p in plans], "achieved": mads_rank / acc_s if acc_s > 0 else None, "peak": VALU_MAD_PEAK,
                      "frac": (mads_rank / acc_s / VALU_MAD_PEAK) if acc_s > 0 else None,
                      "note": "the real bound of this kernel: mads are 76 % of its instruction stream (3 542 of 4 635 per mixed add)"},
             "proof_bytes": proof.to_bytes().hex(),
