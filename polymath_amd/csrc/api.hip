@@ -71,7 +71,7 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     timing_flush(ctx);
     MsmWorkspace &m = ctx->msm;
     for (DevBuf *b : {&m.digits, &m.sorted, &m.counts, &m.bucket_off, &m.task_off, &m.cursor, &m.partials, &m.wsum,
-                      &m.result, &m.canon, &m.region, &m.sub, &m.digits2, &m.order, &m.len_bins, &m.block_cnt, &m.task_cnt, &m.hot, &ctx->scratch, &ctx->flags, &ctx->xw, &ctx->ue, &ctx->we, &ctx->u, &ctx->w,
+                      &m.region, &m.sub, &m.digits2, &m.order, &m.len_bins, &m.block_cnt, &m.task_cnt, &m.hot, &ctx->scratch, &ctx->flags, &ctx->xw, &ctx->ue, &ctx->we, &ctx->u, &ctx->w,
                       &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra})
         b->release();
     for (auto &b : ctx->lvl) b.release();

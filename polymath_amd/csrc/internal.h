@@ -75,7 +75,7 @@ enum TimingSlot {
 };
 
 struct MsmWorkspace {
-    DevBuf digits, sorted, counts, bucket_off, task_off, cursor, partials, wsum, result, canon, region, sub, digits2, order, len_bins, block_cnt, task_cnt, hot;
+    DevBuf digits, sorted, counts, bucket_off, task_off, cursor, partials, wsum, region, sub, digits2, order, len_bins, block_cnt, task_cnt, hot;
 };
 
 // Window tables of a resident base vector (setup.hip: tables_build): point (w, i) = 2^(c w) P_i lives at

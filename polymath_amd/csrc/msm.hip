@@ -4,7 +4,10 @@
 // call sites :118,:121,:229,:335-354): result = sum_i scalar_i * base_i.  The result is a canonical
 // group element, so the schedule below is free to differ from ark-ec's.
 //
-// Pipeline, all on one HIP stream, no host round trip until the final point:
+// Two pipelines share the task / accumulate / reduce kernels: (A) below, per-window Pippenger
+// over a plain base array (one-shot pm_msm_g1, keys whose tables do not fit); (B) "Table mode" further down,
+// the path every resident key takes.
+// Pipeline (A), all on one HIP stream, no host round trip until the final point:
 //   k_digits      scalar (Montgomery) -> canonical -> W signed c-bit digits, one u32 per
 //                 (window, scalar): (bucket << 1 | negate), NONE for zero digits / infinity bases.
 //   k_hist        LDS-staged histogram: a workgroup owns one (chunk, window) and counts into a
@@ -14,8 +17,10 @@
 //                 longer than SEG entries into SEG-sized tasks (skewed scalars -> hot buckets).
 //   k_scatter     same LDS staging: claim a range per (workgroup, bucket) with one global atomic,
 //                 then place entries with LDS atomics -> base indices grouped by bucket.
+//   k_task_bins   tasks ordered by descending length, so the lanes of a wave carry equal loads.
 //   k_accumulate  one lane per task: XYZZ mixed adds (8M+2S each) over its <= SEG entries;
-//                 bases are gathered from HBM by index (96 B affine points).
+//                 bases are gathered from HBM by index (96 B affine points, or 128 B TablePoint records).
+//   k_task_fold   buckets that own many tasks (skewed scalars) have their partials summed in parallel.
 //   k_bucket_reduce  per window sum_b (b+1) * B_b by per-lane running sums over K buckets, a
 //                 small scalar multiple, and an LDS tree reduction per workgroup.
 //   host_finish   Horner over the W window sums (c doublings each) and one inversion to affine, on the
@@ -468,9 +473,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // Table mode: the base vector is resident together with its window tables T_w[i] = 2^(c w) P_i
 // (setup.hip: tables_build), so every window's digits share ONE set of 2^(c-1) buckets: c = 22 gives
 // 12 mixed adds per pair instead of 16, no per-window reduction and no doublings.  2^21 buckets do not
-// fit the LDS histogram, so the counting sort has two levels: entries are first partitioned by the high
-// bucket bits into regions of 2^15 buckets (k_tbl_*), then each region is sorted by the LDS-staged
-// kernels (k_hist2 / k_scatter2) exactly like a Pippenger window.
+// fit an LDS histogram, so the sort is a three-level MSD radix over (u16 key, u32 table index) entries:
+// k_tbl_count / k_block_scan / k_tbl_partition (64 regions of 2^15 buckets, atomic-free offsets),
+// k_region_pass<HIST> + k_region_pass_staged<MID> (128 sub-regions of 256 buckets), <HIST> + the bucket
+// scan + k_region_pass_staged<FINAL>; every scatter is staged through LDS and written out coalesced.
+// Reduction: k_reduce_level0 / k_reduce_level1 / k_sum_final (chains of dependent point additions).
 // =====================================================================================================
 constexpr unsigned LO_BITS = 15;
 
