@@ -134,8 +134,33 @@ static int run(const char *name, int iters) {
     return fails;
 }
 
+// The dense product the kernels use (field.cuh: mul, 28-bit limbs, radix 2^(32 N)) against the textbook
+// 32-bit CIOS (mul_cios) on random and extreme operands: identical canonical words.
+template <class P>
+static int dense_mul_check(const char *name, int iters) {
+    int bad = 0;
+    uint64_t s = 88172645463325252ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 16); };
+    const int topbits = P::BITS - 32 * (P::N - 1);
+    for (int it = 0; it < iters; ++it) {
+        Fp<P> a, b;
+        for (int i = 0; i < P::N; ++i) { a.l[i] = rnd(); b.l[i] = rnd(); }
+        a.l[P::N - 1] &= (1u << (topbits - 1)) - 1;     // < p
+        b.l[P::N - 1] &= (1u << (topbits - 1)) - 1;
+        if (it == 0) { for (int i = 0; i < P::N; ++i) a.l[i] = P::MOD[i]; a.l[0] -= 1; b = a; }   // (p - 1)^2
+        if (it == 1) a = Fp<P>::zero();
+        if (it == 2) a = Fp<P>::one();
+        if (it == 3) { for (int i = 0; i < P::N; ++i) a.l[i] = P::MOD[i]; a.l[0] -= 1; b = Fp<P>::one(); }
+        if (!mul<P>(a, b).eq(mul_cios<P>(a, b))) bad++;
+    }
+    printf("%s dense mul vs CIOS: %d mismatches of %d\n", name, bad, iters);
+    return bad;
+}
+
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 2000;
     int f = run<BlsCurve>("bls12_381", iters) + run<BnCurve>("bn254", iters);
+    f += dense_mul_check<BlsFrP>("BlsFr", 50 * iters) + dense_mul_check<BnFrP>("BnFr", 50 * iters) + dense_mul_check<BlsFqP>("BlsFq", 50 * iters) +
+         dense_mul_check<BnFqP>("BnFq", 50 * iters);
     return f ? 1 : 0;
 }
