@@ -176,7 +176,7 @@ PM_HD Fp<P> mul_cios(const Fp<P> &a, const Fp<P> &b) {
 // limbs; L - 1 full Montgomery steps of 28 bits and one partial step of TAIL = 32 N - 28 (L - 1) bits (4 for the
 // 256-bit fields, 20 for BLS12-381 Fq), then a TAIL-bit right shift.  8 limbs: ~385 instructions instead of ~600.
 template <class P>
-PM_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
+PM_HD Fp<P> mul_r28(const Fp<P> &a, const Fp<P> &b) {
     typedef typename Radix28<P>::RR RR;
     constexpr int N = P::N, L = RR::N, W = 28, TAIL = 32 * N - W * (L - 1);
     static_assert(TAIL > 0 && TAIL <= W && RR::W == W, "28-bit limb layout");
@@ -252,6 +252,17 @@ PM_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
         r.l[w] = (uint32_t)v;
     }
     return r;
+}
+
+// Device code takes the 28-bit-limb product (fewer instructions on gfx950); host code (key generation glue,
+// transcripts, verifier) the 32-bit CIOS, which a CPU's carry flags run faster.  Identical results.
+template <class P>
+PM_HD Fp<P> mul(const Fp<P> &a, const Fp<P> &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return mul_r28<P>(a, b);
+#else
+    return mul_cios<P>(a, b);
+#endif
 }
 
 template <class P>

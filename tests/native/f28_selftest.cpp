@@ -134,7 +134,7 @@ static int run(const char *name, int iters) {
     return fails;
 }
 
-// The dense product the kernels use (field.cuh: mul, 28-bit limbs, radix 2^(32 N)) against the textbook
+// The dense product the kernels use (field.cuh: mul_r28, 28-bit limbs, radix 2^(32 N)) against the textbook
 // 32-bit CIOS (mul_cios) on random and extreme operands: identical canonical words.
 template <class P>
 static int dense_mul_check(const char *name, int iters) {
@@ -151,7 +151,7 @@ static int dense_mul_check(const char *name, int iters) {
         if (it == 1) a = Fp<P>::zero();
         if (it == 2) a = Fp<P>::one();
         if (it == 3) { for (int i = 0; i < P::N; ++i) a.l[i] = P::MOD[i]; a.l[0] -= 1; b = Fp<P>::one(); }
-        if (!mul<P>(a, b).eq(mul_cios<P>(a, b))) bad++;
+        if (!mul_r28<P>(a, b).eq(mul_cios<P>(a, b))) bad++;
     }
     printf("%s dense mul vs CIOS: %d mismatches of %d\n", name, bad, iters);
     return bad;
