@@ -180,11 +180,14 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     PM_TRY(twiddles_get<C>(ctx, log_n, inv_dir, &tw, true));
     hipLaunchKernelGGL(k_bitrev<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, log_n);
     PM_HIP(ctx, hipGetLastError());
+    // passes of LOG_TILE = 8 stages on 256-row x 8-column tiles; domains above 2^24 take 9 stages per pass
+    // (512 rows x 4 columns, the same 64 KiB of LDS) so that 2^25..2^27 points still need only three passes
+    const unsigned tile_log = log_n > 24 ? (unsigned)LOG_TILE + 1 : (unsigned)LOG_TILE;
     unsigned s0 = 0;
     while (s0 < log_n) {
-        unsigned ns = log_n - s0 < (unsigned)LOG_TILE ? log_n - s0 : (unsigned)LOG_TILE;
-        // columns: consecutive `lo` values (contiguous in memory); needs s0 >= log_cols
-        unsigned log_cols = 3;
+        unsigned ns = log_n - s0 < tile_log ? log_n - s0 : tile_log;
+        // columns: consecutive `lo` values (contiguous in memory); needs s0 >= log_cols; tile <= 2^11 elements
+        unsigned log_cols = 11 - ns < 3 ? 11 - ns : 3;
         if (s0 < log_cols) log_cols = s0;
         size_t tiles = n >> (ns + log_cols);
         size_t lds = ((size_t)1 << (ns + log_cols)) * sizeof(Fr);

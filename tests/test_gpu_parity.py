@@ -49,6 +49,28 @@ def test_ntt_full_size_roundtrip_and_domain_limit(gpu_ctx, api):
     assert e.value.status == 3
 
 
+def test_ntt_2p25_nine_stage_passes(gpu_ctx, oracle):
+    """Domains above 2^24 run 9-stage passes (512 x 4 tiles): the n = 2^25 domain of the 2^24-constraint config.
+    Random round trip, and the transform of a unit vector e_j is the geometric sequence w^(jk) (checked at random
+    k against big-integer powers): every butterfly's twiddle takes part."""
+    curve, log_n = "bls12_381", 25
+    c = CURVES[curve]
+    n = 1 << log_n
+    a = rand_fr_limbs(curve, n, 31)
+    f = gpu_ctx.ntt(curve, a, log_n, False)
+    assert np.array_equal(gpu_ctx.ntt(curve, f, log_n, True), a)
+    del f
+    j = 12345677
+    e = np.zeros((n, 4), dtype=np.uint64)
+    e[j] = oracle.fr_to_mont_limbs(curve, [1])[0]
+    f = gpu_ctx.ntt(curve, e, log_n, False)
+    w = pow(c.two_adic_root, 1 << (c.two_adicity - log_n), c.r)
+    rng = np.random.default_rng(5)
+    ks = [0, 1, n - 1, n // 2] + [int(v) for v in rng.integers(0, n, size=60)]
+    want = oracle.fr_to_mont_limbs(curve, [pow(w, j * k % n, c.r) for k in ks])
+    assert np.array_equal(f[ks], want)
+
+
 # ------------------------------------------------------------------------------------ MSM
 @pytest.mark.parametrize("curve", CURVE_LIST)
 def test_msm_golden_edge_cases(gpu_ctx, oracle, curve):
