@@ -496,7 +496,6 @@ static int pk_load_impl(pm_ctx *ctx, uint64_t n, uint64_t m0, uint64_t mw, uint6
                         const pm_csr *b, const pm_csr *c, const pm_base_array *bases, int shard_rank, int shard_count,
                         pm_pk **out) {
     pm_pk *pk = new pm_pk();
-    memset(pk, 0, sizeof(*pk));
     auto guard = [&](int st) { if (st != PM_OK) pk_release(pk); return st; };
     int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count);
     if (st) return guard(st);
@@ -543,7 +542,6 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
     pm_pk *pk = new pm_pk();
-    memset(pk, 0, sizeof(*pk));
     auto guard = [&](int st) { if (st != PM_OK) pk_release(pk); return st; };
     int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count);
     if (st) return guard(st);

@@ -358,6 +358,60 @@ def test_sharded_pk_partials_sum_to_whole(gpu_ctx, oracle, api):
     ctx2.close()
 
 
+@pytest.mark.parametrize("shards", [4, 8])
+def test_sharded_whole_proof_in_lockstep(gpu_ctx, oracle, api, shards):
+    """The N-GPU data flow on one GPU: N shard keys (one context each, as N ranks would hold them) step through
+    the three phases in lockstep, partial points are summed with pm_g1_sum exactly as PointCombiner does after
+    the all-gather, and the proof bytes equal the unsharded key's."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    curve = "bls12_381"
+    r = CURVES[curve].r
+    r1cs, inst, wit = PC.synthetic_r1cs(r, 5000)
+    g = PC.SplitMix64(0x5AAD)
+    x_t, z_t, r_a = g.fr(r), g.fr(r), [g.fr(r), g.fr(r)]
+    whole = Polymath(curve, "keccak256", ctx=gpu_ctx)
+    pk = whole.setup((r1cs, inst, wit), x_t, z_t)
+    f = whole.field
+    xl, wl = f.fr_limbs(inst), f.fr_limbs(wit)
+    ref = whole.prove_limbs(pk, inst, xl, wl, r_a).to_bytes()
+    pk.free()
+    ranks = [Polymath(curve, "keccak256", device=0) for _ in range(shards)]
+    pks = [pm.setup((r1cs, inst, wit), x_t, z_t, shard_rank=i, shard_count=shards) for i, pm in enumerate(ranks)]
+    results = [None] * shards
+    pending = {}          # round -> {rank: (partial point, infinity flag)}
+
+    class _Yield(Exception):
+        pass
+
+    # cooperative lockstep without threads: replay each rank's prove_limbs until its next combine point
+    def run_rank(i, answers):
+        calls = {"n": 0}
+
+        def combine(xy, inf):
+            k = calls["n"]
+            calls["n"] += 1
+            if k < len(answers):
+                return answers[k]
+            pending.setdefault(k, {})[i] = (np.array(xy, dtype=np.uint64), inf)
+            raise _Yield()
+        return ranks[i].prove_limbs(pks[i], inst, xl, wl, r_a, combine)
+
+    answers = []
+    for rnd in range(3):                                    # [a], [c], [d]
+        for i in range(shards):
+            with pytest.raises(_Yield):
+                run_rank(i, answers)
+        pts = np.stack([pending[rnd][i][0] for i in range(shards)])
+        infs = np.array([pending[rnd][i][1] for i in range(shards)], dtype=np.int32)
+        answers.append(api.g1_sum(curve, pts, infs))
+    for i in range(shards):
+        results[i] = run_rank(i, answers).to_bytes()
+    assert all(b == ref for b in results)
+    for p in pks:
+        p.free()
+
+
 def test_error_codes(gpu_ctx, oracle, api):
     curve = "bls12_381"
     c = CURVES[curve]
