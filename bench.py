@@ -125,42 +125,64 @@ def main():
     d_x = torch.from_numpy(x_l.view("int64")).cuda()
     d_w = torch.from_numpy(w_l.view("int64")).cuda()
     dev_ptrs = (d_x.data_ptr(), d_w.data_ptr())
-    proof = None
+    # One GPU: the whole create_proof_with_assignment is ONE native call (pm_host_prove: the library's C++ host mirror
+    # runs the transcript and challenge arithmetic between the phases).  Several ranks: the phases are driven from
+    # here, because the partial points are exchanged between them (PointCombiner).
+    native = world == 1 and shard_count == 1 and not os.environ.get("BENCH_PYTHON_GLUE")
+
+    def prove_once():
+        if native:
+            return pm.prove_native(pk, x_l, w_l, r_a, dev_ptrs)
+        return pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs).to_bytes()
+
+    proof_b = None
     for _ in range(args.warmup):
-        proof = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs)
-    acc_ms, msm_ms, sort_ms, red_ms, ntt_ms, phase_ms, acc1_ms = [], [], [], [], [], [], []
-    pm.collect_timings = True                       # keeps the stage slots of all three phases (3 tiny ctypes calls per proof)
+        proof_b = prove_once()
+    acc_all_ms, sort_all_ms, red_all_ms, ntt_all_ms, poly_all_ms = [], [], [], [], []
+    acc_ms, msm_ms, sort_ms, red_ms, phase_ms, acc1_ms = [], [], [], [], [], []
+    pm.collect_timings = not native                 # phase-by-phase path: keep the stage slots of every phase
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        proof = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs)
-        tm = pm.ctx.timings()                       # phase-3 slots (the 10n+22-pair quotient MSM)
-        acc_ms.append(tm["msm_accumulate"]); msm_ms.append(tm["msm_total"]); sort_ms.append(tm["msm_sort"])
-        red_ms.append(tm["msm_reduce"]); phase_ms.append(tm["phase"])
-        acc1_ms.append(pm.phase_timings[0]["msm_accumulate"])   # [a]_1 and [c]_1 launches (phase 1)
+        proof_b = prove_once()
+        tm = pm.ctx.timings()
+        if native:                                  # slots accumulated over the three phases of the proof
+            acc_all_ms.append(tm["msm_accumulate"]); sort_all_ms.append(tm["msm_sort"]); red_all_ms.append(tm["msm_reduce"])
+            ntt_all_ms.append(tm["ntt"]); poly_all_ms.append(tm["poly"])
+        else:                                       # phase-3 slots here, phase-1 slots from collect_timings
+            acc_ms.append(tm["msm_accumulate"]); msm_ms.append(tm["msm_total"]); sort_ms.append(tm["msm_sort"])
+            red_ms.append(tm["msm_reduce"]); phase_ms.append(tm["phase"])
+            acc1_ms.append(pm.phase_timings[0]["msm_accumulate"])
     barrier()
-    pm.collect_timings = False
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
+    pm.collect_timings = False
     # PCIe-inclusive variant (host x, w buffers through pm_prove_phase1): reported, never `value`
     barrier()
     t1 = time.perf_counter()
-    proof_host = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine)
+    proof_host_b = pm.prove_native(pk, x_l, w_l, r_a) if native else pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine).to_bytes()
     barrier()
     ms_host_inputs = (time.perf_counter() - t1) * 1e3
+    assert proof_host_b == proof_b
+    # one phase-by-phase proof outside the timed region: per-phase stage breakdown, and the two host paths agree
+    pm.collect_timings = True
+    t1 = time.perf_counter()
+    proof_py = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs).to_bytes()
+    ms_python_glue = (time.perf_counter() - t1) * 1e3
+    pm.collect_timings = False
+    assert proof_py == proof_b
+    tm3, tm1 = pm.phase_timings[2], pm.phase_timings[0]
+    if native:
+        acc_ms, msm_ms, sort_ms, red_ms, phase_ms = [tm3["msm_accumulate"]], [tm3["msm_total"]], [tm3["msm_sort"]], [tm3["msm_reduce"]], [tm3["phase"]]
+        acc1_ms = [tm1["msm_accumulate"]]
     if os.environ.get("BENCH_PHASES"):             # dev hook: stage timings of all three phases (stderr)
-        pm.collect_timings = True
-        t1 = time.perf_counter()
-        pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs)
-        log(rank, "wall %.2f ms; phases:" % ((time.perf_counter() - t1) * 1e3))
+        log(rank, "phase-by-phase proof %.2f ms; phases:" % ms_python_glue)
         for i, tm in enumerate(pm.phase_timings):
             log(rank, " phase %d:" % (i + 1), {k: round(v, 2) for k, v in tm.items() if v})
-        pm.collect_timings = False
-    assert proof_host.to_bytes() == proof.to_bytes()
     n = pk.n
     d_pairs_total = 10 * n + 22                     # quotient MSM M8 (prover.rs:229)
     d_pairs_rank = d_pairs_total * (shard_rank + 1) // shard_count - d_pairs_total * shard_rank // shard_count
@@ -173,7 +195,7 @@ def main():
         # launch duration = (HIP-event time of the three launches) / 3 -- the same average rocprofv3 --stats prints.
         plans = [pk.msm_plan(k) for k in range(3)]              # (resident pairs, windows, bits, tables)
         launches = 3
-        acc_s = (avg(acc_ms) + avg(acc1_ms)) * 1e-3            # per proof, all three launches
+        acc_s = (avg(acc_all_ms) if native else avg(acc_ms) + avg(acc1_ms)) * 1e-3   # per proof, all three launches
         pairs_rank = sum(p[0] for p in plans)
         achieved = (bpp * pairs_rank / acc_s / 1e9) if acc_s > 0 else 0.0
         mads_rank = float(MADS_PER_MIXED_ADD[curve]) * sum(p[0] * p[1] for p in plans)
@@ -197,6 +219,9 @@ def main():
                        "msm_pairs_per_proof": pairs_per_proof, "parallelism": "msm-pairs-sharded x%d" % world},
             "msm_pairs_per_sec": pairs_per_proof / (dt / args.steps),
             "ms_per_step_pcie_inclusive": ms_host_inputs,
+            "host_glue": "native (pm_host_prove: C++ transcript + challenge arithmetic inside the library)" if native else
+                         "python (phases driven from bench.py; partial points exchanged between them)",
+            "ms_per_step_python_glue": ms_python_glue,
             "arithmetic": "integer, 28/32-bit limbs in u32 registers (255-bit Fr, 381-bit Fq Montgomery)",
             "msm_d_pairs_per_sec_kernel_time": d_pairs_rank / (avg(msm_ms) * 1e-3) if avg(msm_ms) > 0 else None,
             "stage_ms_phase3": {"msm_sort": avg(sort_ms), "msm_accumulate": avg(acc_ms), "msm_reduce": avg(red_ms),
@@ -214,7 +239,7 @@ def main():
                      "mixed_adds_per_pair": [p[1] for p in plans], "achieved": mads_rank / acc_s if acc_s > 0 else None, "peak": VALU_MAD_PEAK,
                      "frac": (mads_rank / acc_s / VALU_MAD_PEAK) if acc_s > 0 else None,
                      "note": "the real bound of this kernel: mads are 76 % of its instruction stream (3 542 of 4 635 per mixed add)"},
-            "proof_bytes": proof.to_bytes().hex(),
+            "proof_bytes": proof_b.hex(),
         }
         if not args.no_cpu_baseline:
             log(rank, "timing the CPU restatement (bounded sample) ...")

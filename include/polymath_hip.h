@@ -141,6 +141,8 @@ int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_t offset, s
 void pm_pk_free(pm_pk *pk);
 
 /* ---- prove: create_proof_with_assignment split at its two transcript calls ---------------- */
+/* Fiat-Shamir choices of the reference (src/transcript/{merlin,keccak256,blake3}.rs) for pm_host_prove. */
+typedef enum pm_transcript { PM_TRANSCRIPT_MERLIN = 0, PM_TRANSCRIPT_KECCAK256 = 1, PM_TRANSCRIPT_BLAKE3 = 2 } pm_transcript;
 /* Phase 1 (prover.rs:75-123): witness map, iNTTs, u^2, h, then [a]_1 and [c]_1.
  *   x   : m0 Fr, instance assignment INCLUDING the leading one (prover.rs:56)
  *   w   : mw Fr, witness assignment
@@ -159,6 +161,18 @@ int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
  * commit the dense quotient: [d]_1.  Returns PM_ERR_REMAINDER_NONZERO like prover.rs:221. */
 int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
                     const uint64_t *c_at_x1, uint64_t *d_g1_xy, int *d_inf);
+
+/* Whole create_proof_with_assignment (prover.rs:66-237) for an UNSHARDED key, transcript included: the three
+ * phases above plus the host glue between them (compute_x1 / compute_x2, common.rs:21-71; pi and c at x1,
+ * :73-98; transcript = pm_transcript), run by the library's own C++ mirror of that glue.  For hosts without a
+ * Transcript implementation of their own; a Rust host keeps calling the phases and owns T.
+ * instance_host: the m0 public inputs (leading one included) as host Montgomery limbs -- they are hashed;
+ * x, w: the assignment, host pointers or (assignment_on_device != 0) device pointers as in
+ * pm_prove_phase1_device.  proof_bytes receives Proof::serialize_compressed (data_structures.rs:10-19):
+ * 176 bytes on BLS12-381, 128 on BN254.  Status codes as for the phases. */
+int pm_host_prove(pm_ctx *ctx, const pm_pk *pk, int transcript, const uint64_t *instance_host, const uint64_t *x,
+                  const uint64_t *w, int assignment_on_device, const uint64_t *r_a, uint8_t *proof_bytes, size_t capacity,
+                  size_t *proof_len);
 
 /* Host helper: Keccak-f[1600] on 25 little-endian lanes, shared by the host mirrors' Merlin / Keccak256
  * transcripts (the reference's transcripts are host code too: src/transcript/*.rs). */

@@ -46,7 +46,7 @@ EXPORTS = [
     "pm_device_count", "pm_ctx_create", "pm_ctx_destroy", "pm_last_error", "pm_last_timings", "pm_ntt",
     "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
     "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
-    "pm_pk_info", "pm_pk_msm_plan", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3",
+    "pm_pk_info", "pm_pk_msm_plan", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3", "pm_host_prove",
     "pm_prove_tap", "pm_host_keccak_f1600",
 ]
 
@@ -88,6 +88,7 @@ def load_library():
     L.pm_pk_generate.argtypes = [vp, i, u64, u64, u64, ct.POINTER(PmCsr), ct.POINTER(PmCsr), ct.POINTER(PmCsr), u64p,
                                  u64p, i, i, ct.POINTER(vp)]
     L.pm_pk_info.argtypes = [vp, u64p, u64p, u64p, u64p, u64p]
+    L.pm_host_prove.argtypes = [vp, vp, ct.c_int, u64p, ct.c_void_p, ct.c_void_p, ct.c_int, u64p, ct.c_char_p, ct.c_size_t, ct.POINTER(ct.c_size_t)]
     L.pm_pk_msm_plan.argtypes = [vp, ct.c_int, u64p, ct.POINTER(ct.c_uint), ct.POINTER(ct.c_uint), intp]
     L.pm_pk_export_bases.argtypes = [vp, vp, i, sz, sz, u64p]
     L.pm_pk_free.argtypes = [vp]
@@ -325,6 +326,23 @@ class ProvingKey:
         rc = self.ctx.L.pm_prove_phase1_device(self.ctx.h, self.h, ct.c_void_p(d_x), ct.c_void_p(d_w), _p(_c(r_a)), _p(a), ct.byref(ai),
                                                _p(c), ct.byref(ci))
         return rc, a, ai.value, c, ci.value
+
+    TRANSCRIPT_IDS = {"merlin": 0, "keccak256": 1, "blake3": 2}
+
+    def host_prove(self, transcript, instance_limbs, x, w, r_a, on_device=False):
+        """pm_host_prove: all three phases and the Fiat-Shamir glue in one native call (unsharded keys).
+        x, w: numpy limb arrays, or device pointers (ints) with on_device=True.  -> (status, proof bytes)."""
+        buf = ct.create_string_buffer(256)
+        n = ct.c_size_t(0)
+        if on_device:
+            px, pw = ct.c_void_p(x), ct.c_void_p(w)
+        else:
+            x = _c(x)
+            w = _c(w) if len(w) else np.zeros((1, 4), dtype=np.uint64)
+            px, pw = x.ctypes.data_as(ct.c_void_p), w.ctypes.data_as(ct.c_void_p)
+        rc = self.ctx.L.pm_host_prove(self.ctx.h, self.h, self.TRANSCRIPT_IDS[transcript], _p(_c(instance_limbs)), px, pw, int(on_device),
+                                      _p(_c(r_a)), buf, len(buf), ct.byref(n))
+        return rc, buf.raw[:n.value]
 
     def phase2(self, x1):
         out = np.zeros(4, dtype=np.uint64)

@@ -54,6 +54,7 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     ctx->pk = nullptr;
     ctx->phase = 0;
     ctx->aux = nullptr;
+    ctx->keep_timings = false;
     timing_reset(ctx);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;

@@ -1,0 +1,66 @@
+// pm_host_prove: the reference's create_proof_with_assignment glue (prover.rs:66-237) inside the library,
+// for hosts that do not bring their own Transcript: the C++ host mirror (polymath_amd/host/polymath.hpp --
+// transcripts of src/transcript/*.rs, challenge arithmetic of common.rs:21-98, ark wire format) driven on the
+// caller's context.  The three phases stay the boundary; this is their caller, compiled once.
+#include "internal.h"
+#include "../host/polymath.hpp"
+
+namespace {
+
+template <class C, class T>
+int host_prove_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *instance_host, const uint64_t *x, const uint64_t *w, int on_device,
+                    const uint64_t *r_a, uint8_t *proof_bytes, size_t cap, size_t *proof_len) {
+    typedef pmhost::FrOps<C> F;
+    typedef typename F::Fr Fr;
+    pmhost::Context view(ctx, pmhost::Context::Borrow{});
+    pmhost::ProvingKey<C> key;
+    key.h = const_cast<pm_pk *>(pk);
+    key.n = pk->n; key.m0 = pk->m0; key.sigma = pk->sigma;
+    memcpy(key.omega.l, pk->omega, 32);
+    std::vector<Fr> instance(pk->m0);
+    memcpy((void *)instance.data(), instance_host, pk->m0 * sizeof(Fr));
+    Fr ra[2];
+    memcpy(ra, r_a, sizeof(ra));
+    int status = PM_OK;
+    pm::timing_reset(ctx);
+    ctx->keep_timings = true;      // pm_last_timings then covers the whole proof
+    try {
+        pmhost::Polymath<C, T> pm(view);
+        pmhost::Proof<C> proof = pm.prove_raw(key, instance, x, w, on_device != 0, ra);
+        pmhost::Bytes b = proof.to_bytes();
+        if (proof_len) *proof_len = b.size();
+        if (b.size() > cap) status = PM_ERR_INVALID_ARG;
+        else memcpy(proof_bytes, b.data(), b.size());
+    } catch (const pmhost::PolymathError &e) {
+        status = e.status ? e.status : PM_ERR_STATE;
+    } catch (const std::exception &e) {
+        ctx->err = e.what();
+        status = PM_ERR_STATE;
+    }
+    ctx->keep_timings = false;
+    key.h = nullptr;   // borrowed: the destructor must not free the caller's key
+    return status;
+}
+
+template <class C>
+int host_prove_curve(pm_ctx *ctx, const pm_pk *pk, int transcript, const uint64_t *ih, const uint64_t *x, const uint64_t *w, int dev,
+                     const uint64_t *r_a, uint8_t *out, size_t cap, size_t *len) {
+    switch (transcript) {
+        case PM_TRANSCRIPT_MERLIN: return host_prove_impl<C, pmhost::MerlinFieldTranscript<C>>(ctx, pk, ih, x, w, dev, r_a, out, cap, len);
+        case PM_TRANSCRIPT_KECCAK256: return host_prove_impl<C, pmhost::Keccak256Transcript<C>>(ctx, pk, ih, x, w, dev, r_a, out, cap, len);
+        case PM_TRANSCRIPT_BLAKE3: return host_prove_impl<C, pmhost::Blake3Transcript<C>>(ctx, pk, ih, x, w, dev, r_a, out, cap, len);
+        default: return PM_ERR_INVALID_ARG;
+    }
+}
+
+}  // namespace
+
+extern "C" int pm_host_prove(pm_ctx *ctx, const pm_pk *pk, int transcript, const uint64_t *instance_host, const uint64_t *x,
+                             const uint64_t *w, int assignment_on_device, const uint64_t *r_a, uint8_t *proof_bytes, size_t capacity,
+                             size_t *proof_len) {
+    if (!ctx || !pk || !instance_host || !x || !r_a || !proof_bytes || (pk->mw && !w)) return PM_ERR_INVALID_ARG;
+    if (pk->device != ctx->device || pk->shard_count != 1) return PM_ERR_INVALID_ARG;   // sharded keys: the host exchanges partial points between phases
+    if (hipSetDevice(ctx->device) != hipSuccess) return PM_ERR_HIP;
+    return pk->curve == PM_BLS12_381 ? host_prove_curve<pm::BlsCurve>(ctx, pk, transcript, instance_host, x, w, assignment_on_device, r_a, proof_bytes, capacity, proof_len)
+                                     : host_prove_curve<pm::BnCurve>(ctx, pk, transcript, instance_host, x, w, assignment_on_device, r_a, proof_bytes, capacity, proof_len);
+}

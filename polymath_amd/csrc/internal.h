@@ -160,6 +160,7 @@ struct pm_ctx {
     // proof in flight
     const pm_pk *pk;
     int phase;
+    bool keep_timings;   // pm_host_prove: the stage slots accumulate over the three phases of one proof
     pm::DevBuf xw, ue, we, u, w, wit_u, u2, sc_a, sc_c, quotient, ztail, lvl[6], ra;
 };
 

@@ -380,7 +380,7 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     const uint64_t Lz = 2 * m0 + mw + nr;  // |z_tail| = M - m0
     if (pk->log_n + 1 > (unsigned)C::TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;  // prover.rs:317
     hipStream_t st = ctx->stream;
-    timing_reset(ctx);
+    if (!ctx->keep_timings) timing_reset(ctx);
     ctx->pk = pk;
     ctx->phase = 0;
     StageTimer t_phase(ctx, T_PHASE);
@@ -530,7 +530,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     if (ctx->phase < 1 || !ctx->pk) return PM_ERR_STATE;
     const pm_pk *pk = ctx->pk;
     hipStream_t st = ctx->stream;
-    timing_reset(ctx);
+    if (!ctx->keep_timings) timing_reset(ctx);
     StageTimer t_phase(ctx, T_PHASE);
     const uint64_t n = pk->n, sigma = pk->sigma;
     Fr x1 = load_fr<P>(x1_in), x2 = load_fr<P>(x2_in), a_at = load_fr<P>(a_in), c_at = load_fr<P>(c_in);

@@ -201,13 +201,16 @@ inline std::string to_hex(const Bytes &b) {
 }
 
 // ------------------------------------------------------------------------------------ facade
-struct Context {   // pm_ctx RAII
+struct Context {   // pm_ctx RAII (or a borrowed handle: pm_host_prove runs the mirror on the caller's context)
     pm_ctx *h = nullptr;
+    bool owned = true;
     explicit Context(int device = 0) {
         int st = pm_ctx_create(device, &h);
         if (st) throw PolymathError(0, st, "pm_ctx_create failed (no GPU? status " + std::to_string(st) + ")");
     }
-    ~Context() { pm_ctx_destroy(h); }
+    struct Borrow {};
+    Context(pm_ctx *borrowed, Borrow) : h(borrowed), owned(false) {}
+    ~Context() { if (owned) pm_ctx_destroy(h); }
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
 };
@@ -266,11 +269,19 @@ public:
     }
 
     Proof<C> prove_with_assignment(const ProvingKey<C> &pk, const std::vector<Fr> &instance, const std::vector<Fr> &witness, const Fr r_a[2]) {
+        Fr dummy = Fr::zero();
+        return prove_raw(pk, instance, (const uint64_t *)instance.data(), witness.empty() ? (const uint64_t *)&dummy : (const uint64_t *)witness.data(),
+                         false, r_a);
+    }
+
+    // The same with the assignment given as raw Montgomery limbs, on the host or already resident in HBM
+    // (pm_prove_phase1_device); `instance` is the host copy of the public inputs the transcript hashes.
+    Proof<C> prove_raw(const ProvingKey<C> &pk, const std::vector<Fr> &instance, const uint64_t *x, const uint64_t *w, bool on_device,
+                       const Fr r_a[2]) {
         Proof<C> proof;
         int ai = 0, ci = 0, di = 0;
-        Fr dummy = Fr::zero();
-        int st = pm_prove_phase1(ctx_.h, pk.h, (const uint64_t *)instance.data(), witness.empty() ? (const uint64_t *)&dummy : (const uint64_t *)witness.data(),
-                                 (const uint64_t *)r_a, (uint64_t *)&proof.a_g1.p, &ai, (uint64_t *)&proof.c_g1.p, &ci);
+        int st = on_device ? pm_prove_phase1_device(ctx_.h, pk.h, x, w, (const uint64_t *)r_a, (uint64_t *)&proof.a_g1.p, &ai, (uint64_t *)&proof.c_g1.p, &ci)
+                           : pm_prove_phase1(ctx_.h, pk.h, x, w, (const uint64_t *)r_a, (uint64_t *)&proof.a_g1.p, &ai, (uint64_t *)&proof.c_g1.p, &ci);
         if (st) throw PolymathError(1, st, "prove phase 1 failed: status " + std::to_string(st));   // == the asserts of prover.rs:107,108
         proof.a_g1.inf = ai != 0;
         proof.c_g1.inf = ci != 0;

@@ -300,6 +300,7 @@ class Polymath:
     def __init__(self, curve="bls12_381", transcript="merlin", device=0, ctx=None):
         self.curve, self.field = curve, Field(curve)
         self.transcript_cls = TRANSCRIPTS[transcript] if isinstance(transcript, str) else transcript
+        self.transcript_name = transcript if isinstance(transcript, str) else None
         self.ctx = ctx if ctx is not None else api.Context(device)
         self.collect_timings, self.phase_timings = False, []    # per-phase stage timings (pm_last_timings), opt-in
 
@@ -329,6 +330,21 @@ class Polymath:
         x = f.fr_limbs(instance)
         w = f.fr_limbs(witness)
         return self.prove_limbs(pk, instance, x, w, r_a, combine)
+
+    def prove_native(self, pk, x_limbs, w_limbs, r_a, device_ptrs=None):
+        """create_proof_with_assignment in ONE native call (pm_host_prove: the C++ host mirror inside the library
+        runs the transcript and the challenge arithmetic between the phases).  Unsharded keys, the three
+        transcripts of the reference.  -> Proof::serialize_compressed bytes."""
+        if self.transcript_name is None:
+            raise ValueError("prove_native needs one of the reference's transcripts: " + ", ".join(TRANSCRIPTS))
+        f = self.field
+        if device_ptrs is not None:
+            rc, data = pk.host_prove(self.transcript_name, x_limbs, device_ptrs[0], device_ptrs[1], f.fr_limbs(r_a), on_device=True)
+        else:
+            rc, data = pk.host_prove(self.transcript_name, x_limbs, x_limbs, w_limbs, f.fr_limbs(r_a))
+        if rc:
+            raise PolymathProverError(0, rc)
+        return data
 
     def prove_limbs(self, pk, instance, x_limbs, w_limbs, r_a, combine=None, device_ptrs=None):
         """device_ptrs = (d_x, d_w): the assignment is already resident in HBM (pm_prove_phase1_device)."""

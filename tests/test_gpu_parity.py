@@ -412,6 +412,42 @@ def test_sharded_whole_proof_in_lockstep(gpu_ctx, oracle, api, shards):
         p.free()
 
 
+def test_native_whole_prove_equals_phase_by_phase(gpu_ctx):
+    """pm_host_prove (C++ host glue inside the library: transcripts, challenge arithmetic, wire format) returns
+    the fixture proofs byte for byte, for the three transcripts, host and device-resident assignment; an
+    unsatisfied witness surfaces the phase status."""
+    import ctypes as ct
+    from polymath_amd import polymath as PM
+    hip = ct.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ct.POINTER(ct.c_void_p), ct.c_size_t]
+    hip.hipMemcpy.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int]
+    hip.hipFree.argtypes = [ct.c_void_p]
+    for fx in load_golden("proofs.json"):
+        q = r1cs_from_json(fx["r1cs"])
+        inst, wit, r_a = [I(v) for v in fx["instance"]], [I(v) for v in fx["witness"]], [I(v) for v in fx["r_a"]]
+        for tname, ref in fx["proofs"].items():
+            pm = PM.Polymath("bls12_381", tname, ctx=gpu_ctx)
+            pk = pm.setup((PM.R1CS(q.m0, q.mw, q.a, q.b, q.c), inst, wit), I(fx["x_trapdoor"]), I(fx["z_trapdoor"]))
+            xl, wl = pm.field.fr_limbs(inst), pm.field.fr_limbs(wit)
+            assert pm.prove_native(pk, xl, wl, r_a).hex() == ref["bytes"], (fx["name"], tname)
+            if tname == "merlin":
+                bufs = []
+                for arr in (xl, wl):
+                    p = ct.c_void_p()
+                    assert hip.hipMalloc(ct.byref(p), max(arr.nbytes, 32)) == 0
+                    assert hip.hipMemcpy(p, arr.ctypes.data_as(ct.c_void_p), arr.nbytes, 1) == 0
+                    bufs.append(p)
+                assert pm.prove_native(pk, xl, wl, r_a, device_ptrs=(bufs[0].value, bufs[1].value)).hex() == ref["bytes"]
+                for p in bufs:
+                    hip.hipFree(p)
+                bad = list(wit)
+                bad[0] = (bad[0] + 1) % pm.field.r
+                with pytest.raises(PM.PolymathProverError) as e:
+                    pm.prove_native(pk, xl, pm.field.fr_limbs(bad), r_a)
+                assert e.value.status == 4                                    # PM_ERR_REMAINDER_NONZERO, prover.rs:108
+            pk.free()
+
+
 def test_error_codes(gpu_ctx, oracle, api):
     curve = "bls12_381"
     c = CURVES[curve]
