@@ -175,7 +175,7 @@ int pm_host_prove(pm_ctx *ctx, const pm_pk *pk, int transcript, const uint64_t *
                   size_t *proof_len);
 
 /* Host helper: Keccak-f[1600] on 25 little-endian lanes, shared by the host mirrors' Merlin / Keccak256
- * transcripts (the reference's transcripts are host code too: src/transcript/*.rs). */
+ * transcripts (the reference's transcripts are host code too: src/transcript/ *.rs). */
 void pm_host_keccak_f1600(uint64_t state[25]);
 
 /* Debug / parity taps: copy an intermediate vector of the proof in flight back to the host.

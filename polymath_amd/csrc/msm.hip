@@ -1076,7 +1076,6 @@ template <class C>
 static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename C::FrP> *d_scalars,
                             size_t len, Affine<C> *h_out, int *h_inf) {
     typedef typename C::FrP FrP;
-    typedef Fp<FrP> Fr;
     StageTimer t_total(ctx, T_MSM_TOTAL);
     MsmWorkspace &ws = ctx->msm;
     const unsigned c = tb.c, nwin = tb.nwin;

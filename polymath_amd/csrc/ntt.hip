@@ -54,9 +54,8 @@ __global__ void k_bitrev(Fp<P> *a, unsigned log_n) {
 // One pass = stages [s0, s0+ns) of the DIT network on bit-reversed input.  Stage s (1-based)
 // pairs indices differing in bit s-1; the twiddle of butterfly (blk, j) is tw[j << (log_n - s)].
 // Decompose index i = (hi, mid, lo): lo = s0 bits (already-processed strides), mid = ns bits
-// (this pass), hi = the rest.  A workgroup takes one `hi`, COLS consecutive `lo`, all 2^ns `mid`.
+// (this pass), hi = the rest.  A workgroup takes one `hi`, 2^log_cols consecutive `lo`, all 2^ns `mid`.
 constexpr int LOG_TILE = 8;
-constexpr int COLS = 8;
 
 // The butterfly product runs on 28-bit limbs (fq28.cuh: 200 carry-free mads + 70 instead of the dense
 // 32-bit-limb Montgomery product the compiler lowers to ~700 instructions, half of them register moves);
