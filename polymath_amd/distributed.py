@@ -20,17 +20,27 @@ class PointCombiner:
         self.words = 2 * nq + 1
 
     def __call__(self, xy, inf):
+        return self.many([(xy, inf)])[0]
+
+    def many(self, points):
+        """[(xy, inf), ...] partial points of this rank -> the same list summed over all ranks, with ONE all-gather
+        (phase 1 returns two points: [a]_1 and [c]_1)."""
         if self.world == 1:
-            return xy, inf
+            return list(points)
         torch, dist = self.torch, self.dist
-        mine = np.zeros(self.words, dtype=np.int64)
-        mine[:2 * self.nq] = np.asarray(xy, dtype=np.uint64).view(np.int64)
-        mine[-1] = int(inf)
+        k, words = len(points), self.words
+        mine = np.zeros(k * words, dtype=np.int64)
+        for j, (xy, inf) in enumerate(points):
+            mine[j * words:j * words + 2 * self.nq] = np.asarray(xy, dtype=np.uint64).view(np.int64)
+            mine[(j + 1) * words - 1] = int(inf)
         t = torch.from_numpy(mine).to(self.dev)
-        out = torch.empty(self.world * self.words, dtype=torch.int64, device=self.dev)
+        out = torch.empty(self.world * k * words, dtype=torch.int64, device=self.dev)
         dist.all_gather_into_tensor(out, t)
-        allp = out.cpu().numpy().reshape(self.world, self.words)
-        pts = np.ascontiguousarray(allp[:, :2 * self.nq]).view(np.uint64)
-        infs = allp[:, -1].astype(np.int32)
+        allp = out.cpu().numpy().reshape(self.world, k, words)
         from . import api
-        return api.g1_sum(self.curve, pts, infs)
+        res = []
+        for j in range(k):
+            pts = np.ascontiguousarray(allp[:, j, :2 * self.nq]).view(np.uint64)
+            infs = np.ascontiguousarray(allp[:, j, -1]).astype(np.int32)
+            res.append(api.g1_sum(self.curve, pts, infs))
+        return res

@@ -358,8 +358,11 @@ class Polymath:
         if self.collect_timings:
             self.phase_timings = [self.ctx.timings()]
         if combine:
-            a_xy, a_inf = combine(a_xy, a_inf)
-            c_xy, c_inf = combine(c_xy, c_inf)
+            if hasattr(combine, "many"):                       # one exchange for both phase-1 points
+                (a_xy, a_inf), (c_xy, c_inf) = combine.many([(a_xy, a_inf), (c_xy, c_inf)])
+            else:
+                a_xy, a_inf = combine(a_xy, a_inf)
+                c_xy, c_inf = combine(c_xy, c_inf)
         a_g1, c_g1 = f.g1_affine(a_xy, a_inf), f.g1_affine(c_xy, c_inf)
         t = self.transcript_cls(B_POLYMATH, r)                                   # prover.rs:125
         x1 = self.compute_x1(t, instance, [a_g1, c_g1])                          # :126
