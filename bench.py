@@ -125,14 +125,14 @@ def main():
     d_x = torch.from_numpy(x_l.view("int64")).cuda()
     d_w = torch.from_numpy(w_l.view("int64")).cuda()
     dev_ptrs = (d_x.data_ptr(), d_w.data_ptr())
-    # One GPU: the whole create_proof_with_assignment is ONE native call (pm_host_prove: the library's C++ host mirror
-    # runs the transcript and challenge arithmetic between the phases).  Several ranks: the phases are driven from
-    # here, because the partial points are exchanged between them (PointCombiner).
-    native = world == 1 and shard_count == 1 and not os.environ.get("BENCH_PYTHON_GLUE")
+    # The whole create_proof_with_assignment is ONE native call (pm_host_prove[_sharded]: the library's C++ host mirror
+    # runs the transcript and challenge arithmetic between the phases); with several ranks it calls back into
+    # PointCombiner.many between the phases to exchange the partial points (RCCL all-gather + pm_g1_sum).
+    native = (world == shard_count) and not os.environ.get("BENCH_PYTHON_GLUE")
 
     def prove_once():
         if native:
-            return pm.prove_native(pk, x_l, w_l, r_a, dev_ptrs)
+            return pm.prove_native(pk, x_l, w_l, r_a, dev_ptrs, combine)
         return pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs).to_bytes()
 
     proof_b = None
@@ -164,7 +164,7 @@ def main():
     # PCIe-inclusive variant (host x, w buffers through pm_prove_phase1): reported, never `value`
     barrier()
     t1 = time.perf_counter()
-    proof_host_b = pm.prove_native(pk, x_l, w_l, r_a) if native else pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine).to_bytes()
+    proof_host_b = pm.prove_native(pk, x_l, w_l, r_a, None, combine) if native else pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine).to_bytes()
     barrier()
     ms_host_inputs = (time.perf_counter() - t1) * 1e3
     assert proof_host_b == proof_b
@@ -219,8 +219,8 @@ def main():
                        "msm_pairs_per_proof": pairs_per_proof, "parallelism": "msm-pairs-sharded x%d" % world},
             "msm_pairs_per_sec": pairs_per_proof / (dt / args.steps),
             "ms_per_step_pcie_inclusive": ms_host_inputs,
-            "host_glue": "native (pm_host_prove: C++ transcript + challenge arithmetic inside the library)" if native else
-                         "python (phases driven from bench.py; partial points exchanged between them)",
+            "host_glue": "native (pm_host_prove%s: C++ transcript + challenge arithmetic inside the library)" % ("_sharded" if world > 1 else "")
+                         if native else "python (phases driven from bench.py)",
             "ms_per_step_python_glue": ms_python_glue,
             "arithmetic": "integer, 28/32-bit limbs in u32 registers (255-bit Fr, 381-bit Fq Montgomery)",
             "msm_d_pairs_per_sec_kernel_time": d_pairs_rank / (avg(msm_ms) * 1e-3) if avg(msm_ms) > 0 else None,

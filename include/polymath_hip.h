@@ -174,6 +174,16 @@ int pm_host_prove(pm_ctx *ctx, const pm_pk *pk, int transcript, const uint64_t *
                   const uint64_t *w, int assignment_on_device, const uint64_t *r_a, uint8_t *proof_bytes, size_t capacity,
                   size_t *proof_len);
 
+/* The same on a SHARDED key (one rank of a multi-GPU proof): `combine` is called between the phases with this
+ * rank's partial points -- count = 2 ([a]_1, [c]_1) after phase 1, count = 1 ([d]_1) after phase 3 -- and must
+ * replace them, in place, by the sums over all ranks (all-gather over RCCL + pm_g1_sum: SURVEY.md §8e; RCCL has
+ * no elliptic-curve reduction).  xy: count x (x||y Montgomery, 16*fq_limbs bytes); inf: count flags.  A non-zero
+ * return aborts the proof with that status.  Every rank then hashes the same points and returns the same proof. */
+typedef int (*pm_combine_fn)(void *user, int count, uint64_t *xy, int *inf);
+int pm_host_prove_sharded(pm_ctx *ctx, const pm_pk *pk, int transcript, const uint64_t *instance_host, const uint64_t *x,
+                          const uint64_t *w, int assignment_on_device, const uint64_t *r_a, pm_combine_fn combine, void *user,
+                          uint8_t *proof_bytes, size_t capacity, size_t *proof_len);
+
 /* Host helper: Keccak-f[1600] on 25 little-endian lanes, shared by the host mirrors' Merlin / Keccak256
  * transcripts (the reference's transcripts are host code too: src/transcript/ *.rs). */
 void pm_host_keccak_f1600(uint64_t state[25]);

@@ -28,6 +28,10 @@ u32p = ct.POINTER(ct.c_uint32)
 intp = ct.POINTER(ct.c_int)
 
 
+# pm_combine_fn: int (*)(void *user, int count, uint64_t *xy, int *inf)
+COMBINE_FN = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_int, ct.POINTER(ct.c_uint64), ct.POINTER(ct.c_int))
+
+
 class PmCsr(ct.Structure):
     _fields_ = [("nrows", ct.c_uint64), ("rowptr", u64p), ("col", u32p), ("val", u64p)]
 
@@ -46,7 +50,7 @@ EXPORTS = [
     "pm_device_count", "pm_ctx_create", "pm_ctx_destroy", "pm_last_error", "pm_last_timings", "pm_ntt",
     "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
     "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
-    "pm_pk_info", "pm_pk_msm_plan", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3", "pm_host_prove",
+    "pm_pk_info", "pm_pk_msm_plan", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3", "pm_host_prove", "pm_host_prove_sharded",
     "pm_prove_tap", "pm_host_keccak_f1600",
 ]
 
@@ -89,6 +93,8 @@ def load_library():
                                  u64p, i, i, ct.POINTER(vp)]
     L.pm_pk_info.argtypes = [vp, u64p, u64p, u64p, u64p, u64p]
     L.pm_host_prove.argtypes = [vp, vp, ct.c_int, u64p, ct.c_void_p, ct.c_void_p, ct.c_int, u64p, ct.c_char_p, ct.c_size_t, ct.POINTER(ct.c_size_t)]
+    L.pm_host_prove_sharded.argtypes = [vp, vp, ct.c_int, u64p, ct.c_void_p, ct.c_void_p, ct.c_int, u64p, COMBINE_FN, ct.c_void_p, ct.c_char_p,
+                                        ct.c_size_t, ct.POINTER(ct.c_size_t)]
     L.pm_pk_msm_plan.argtypes = [vp, ct.c_int, u64p, ct.POINTER(ct.c_uint), ct.POINTER(ct.c_uint), intp]
     L.pm_pk_export_bases.argtypes = [vp, vp, i, sz, sz, u64p]
     L.pm_pk_free.argtypes = [vp]
@@ -329,19 +335,38 @@ class ProvingKey:
 
     TRANSCRIPT_IDS = {"merlin": 0, "keccak256": 1, "blake3": 2}
 
-    def host_prove(self, transcript, instance_limbs, x, w, r_a, on_device=False):
-        """pm_host_prove: all three phases and the Fiat-Shamir glue in one native call (unsharded keys).
-        x, w: numpy limb arrays, or device pointers (ints) with on_device=True.  -> (status, proof bytes)."""
+    def host_prove(self, transcript, instance_limbs, x, w, r_a, on_device=False, combine_many=None):
+        """pm_host_prove / pm_host_prove_sharded: all three phases and the Fiat-Shamir glue in one native call.
+        x, w: numpy limb arrays, or device pointers (ints) with on_device=True.  combine_many (sharded keys):
+        [(xy, inf), ...] -> the same list summed over all ranks (polymath_amd.distributed.PointCombiner.many).
+        -> (status, proof bytes)."""
         buf = ct.create_string_buffer(256)
         n = ct.c_size_t(0)
+        words = 2 * self.nq
+        failure = []
+
+        def _cb(_user, count, xy, inf):
+            try:
+                pts = [(np.ctypeslib.as_array(xy, shape=(count * words,))[j * words:(j + 1) * words].copy(), int(inf[j])) for j in range(count)]
+                for j, (sxy, sinf) in enumerate(combine_many(pts)):
+                    for k, v in enumerate(np.asarray(sxy, dtype=np.uint64).tolist()):
+                        xy[j * words + k] = v
+                    inf[j] = int(sinf)
+                return 0
+            except Exception as e:          # never unwind through the C frames
+                failure.append(e)
+                return 8                    # PM_ERR_STATE
+        cb = COMBINE_FN(_cb) if combine_many is not None else ct.cast(None, COMBINE_FN)
         if on_device:
             px, pw = ct.c_void_p(x), ct.c_void_p(w)
         else:
             x = _c(x)
             w = _c(w) if len(w) else np.zeros((1, 4), dtype=np.uint64)
             px, pw = x.ctypes.data_as(ct.c_void_p), w.ctypes.data_as(ct.c_void_p)
-        rc = self.ctx.L.pm_host_prove(self.ctx.h, self.h, self.TRANSCRIPT_IDS[transcript], _p(_c(instance_limbs)), px, pw, int(on_device),
-                                      _p(_c(r_a)), buf, len(buf), ct.byref(n))
+        rc = self.ctx.L.pm_host_prove_sharded(self.ctx.h, self.h, self.TRANSCRIPT_IDS[transcript], _p(_c(instance_limbs)), px, pw, int(on_device),
+                                              _p(_c(r_a)), cb, None, buf, len(buf), ct.byref(n))
+        if failure:
+            raise failure[0]
         return rc, buf.raw[:n.value]
 
     def phase2(self, x1):

@@ -11,6 +11,7 @@
 // O(m0) scalar glue of common.rs:21-98 and the two Fiat-Shamir calls with the same field templates the
 // kernels use (csrc/field.cuh compiles as plain C++).  Header-only; link with -lpolymath_hip.
 #pragma once
+#include <functional>
 #include <stdexcept>
 #include <type_traits>
 #include <string>
@@ -276,8 +277,12 @@ public:
 
     // The same with the assignment given as raw Montgomery limbs, on the host or already resident in HBM
     // (pm_prove_phase1_device); `instance` is the host copy of the public inputs the transcript hashes.
+    // combine(points, count): replace this rank's PARTIAL points (sharded key) by their sums over all ranks -- the
+    // all-gather + pm_g1_sum of SURVEY.md §8e; null for an unsharded key.  Non-zero return aborts the proof.
+    typedef std::function<int(G1Point<C> *points, int count)> Combine;
+
     Proof<C> prove_raw(const ProvingKey<C> &pk, const std::vector<Fr> &instance, const uint64_t *x, const uint64_t *w, bool on_device,
-                       const Fr r_a[2]) {
+                       const Fr r_a[2], const Combine &combine = nullptr) {
         Proof<C> proof;
         int ai = 0, ci = 0, di = 0;
         int st = on_device ? pm_prove_phase1_device(ctx_.h, pk.h, x, w, (const uint64_t *)r_a, (uint64_t *)&proof.a_g1.p, &ai, (uint64_t *)&proof.c_g1.p, &ci)
@@ -285,6 +290,12 @@ public:
         if (st) throw PolymathError(1, st, "prove phase 1 failed: status " + std::to_string(st));   // == the asserts of prover.rs:107,108
         proof.a_g1.inf = ai != 0;
         proof.c_g1.inf = ci != 0;
+        if (combine) {
+            G1Point<C> ac[2] = {proof.a_g1, proof.c_g1};
+            if (int rc = combine(ac, 2)) throw PolymathError(1, rc, "combining the phase-1 partial points failed");
+            proof.a_g1 = ac[0];
+            proof.c_g1 = ac[1];
+        }
         T t("polymath");                                                                    // prover.rs:125, B_POLYMATH
         Fr x1 = compute_x1(t, instance, proof.a_g1, proof.c_g1);                            // :126
         Fr y1 = F::pow(x1, pk.sigma), y1_inv = F::inv(y1);                                  // :128
@@ -302,6 +313,8 @@ public:
                              (const uint64_t *)c_at_x1.l, (uint64_t *)&proof.d_g1.p, &di);
         if (st) throw PolymathError(3, st, "prove phase 3 failed: status " + std::to_string(st));   // prover.rs:221,222
         proof.d_g1.inf = di != 0;
+        if (combine)
+            if (int rc = combine(&proof.d_g1, 1)) throw PolymathError(3, rc, "combining the phase-3 partial point failed");
         return proof;                                                                       // :231-236
     }
 

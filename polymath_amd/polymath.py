@@ -331,17 +331,19 @@ class Polymath:
         w = f.fr_limbs(witness)
         return self.prove_limbs(pk, instance, x, w, r_a, combine)
 
-    def prove_native(self, pk, x_limbs, w_limbs, r_a, device_ptrs=None):
+    def prove_native(self, pk, x_limbs, w_limbs, r_a, device_ptrs=None, combine=None):
         """create_proof_with_assignment in ONE native call (pm_host_prove: the C++ host mirror inside the library
-        runs the transcript and the challenge arithmetic between the phases).  Unsharded keys, the three
-        transcripts of the reference.  -> Proof::serialize_compressed bytes."""
+        runs the transcript and the challenge arithmetic between the phases), the three transcripts of the
+        reference.  A sharded key needs `combine` with a .many([(xy, inf), ...]) method (PointCombiner): it is called
+        back between the phases with this rank's partial points.  -> Proof::serialize_compressed bytes."""
         if self.transcript_name is None:
             raise ValueError("prove_native needs one of the reference's transcripts: " + ", ".join(TRANSCRIPTS))
         f = self.field
+        many = combine.many if combine is not None else None
         if device_ptrs is not None:
-            rc, data = pk.host_prove(self.transcript_name, x_limbs, device_ptrs[0], device_ptrs[1], f.fr_limbs(r_a), on_device=True)
+            rc, data = pk.host_prove(self.transcript_name, x_limbs, device_ptrs[0], device_ptrs[1], f.fr_limbs(r_a), on_device=True, combine_many=many)
         else:
-            rc, data = pk.host_prove(self.transcript_name, x_limbs, x_limbs, w_limbs, f.fr_limbs(r_a))
+            rc, data = pk.host_prove(self.transcript_name, x_limbs, x_limbs, w_limbs, f.fr_limbs(r_a), combine_many=many)
         if rc:
             raise PolymathProverError(0, rc)
         return data
