@@ -219,7 +219,7 @@ def _gpu_pk(api, ctx, curve, q, x, z, oracle, **kw):
 def test_golden_setup_prove_bytes(gpu_ctx, oracle, api):
     """Every committed fixture: GPU setup bases, every intermediate vector, and the 176-byte proofs for
     the three transcripts (tests/dummy.rs:75-80 shape) equal the big-integer restatement's."""
-    for fx in load_golden("proofs.json"):
+    for fx in load_golden("proofs.json") + load_golden("proofs_bn254.json"):
         curve = fx["curve"]
         c = CURVES[curve]
         TR = T.make_transcripts(c)

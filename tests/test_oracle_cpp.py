@@ -79,7 +79,7 @@ def test_setup_and_proofs_match_pyref_golden(oracle):
     """Sparse setup + three-phase prove of the C++ restatement == dense literal transcription
     (bases, every intermediate vector, and the proof bytes for all three transcripts)."""
     CO = oracle
-    for fx in load_golden("proofs.json"):
+    for fx in load_golden("proofs.json") + load_golden("proofs_bn254.json"):
         curve = fx["curve"]
         c = CURVES[curve]
         TR = T.make_transcripts(c)

@@ -110,6 +110,39 @@ def proof_fixtures():
     return out
 
 
+def proof_fixtures_bn254():
+    """BN254 (BASELINE configs[4]: second curve, 254-bit limb path): same shape as proofs.json.  pyref has no BN254
+    pairing, so these are pinned by the prover's own asserts (rem == 0 twice, degree bounds) and by the two
+    independent restatements agreeing (tests/test_oracle_cpp.py), not by a verifier."""
+    c = CURVES["bn254"]
+    TR = T.make_transcripts(c)
+    g = CI.SplitMix64(0xB254)
+    cases = [("dummy", ) + CI.dummy_circuit(c, g.fr(c.r), g.fr(c.r)),
+             ("synthetic6", ) + CI.synthetic_r1cs(c, 6),
+             ("bench_shape", ) + CI.bench_circuit(c, g.fr(c.r), g.fr(c.r), 7, 6)]
+    out = []
+    for name, q, inst, wit in cases:
+        x, z = g.fr(c.r), g.fr(c.r)
+        pk = PR.generate_proving_key(c, q, x, z)
+        r_a = [g.fr(c.r), g.fr(c.r)]
+        entry = dict(name=name, curve="bn254", r1cs=r1cs_json(q), instance=[H(v) for v in inst], witness=[H(v) for v in wit],
+                     x_trapdoor=H(x), z_trapdoor=H(z), r_a=[H(v) for v in r_a], n=pk.n, sigma=pk.sigma, omega=H(pk.omega),
+                     bases={nm: [PT(p) for p in getattr(pk, nm)] for nm in
+                            ["x_powers_g1", "x_powers_y_alpha_g1", "x_powers_y_gamma_g1", "x_powers_y_gamma_z_g1",
+                             "x_powers_zh_by_y_alpha_g1", "uj_wj_lcs_by_y_alpha_g1"]}, proofs={})
+        for tname in ["merlin", "keccak256", "blake3"]:
+            tr = {}
+            proof = PR.create_proof_with_assignment(c, pk, inst, wit, r_a, TR[tname], tr)
+            entry["proofs"][tname] = dict(a_g1=PT(proof["a_g1"]), c_g1=PT(proof["c_g1"]), a_at_x1=H(proof["a_at_x1"]),
+                                          d_g1=PT(proof["d_g1"]), x1=H(tr["x1"]), x2=H(tr["x2"]),
+                                          bytes=SE.ser_proof(c, proof).hex())
+            if tname == "keccak256":
+                entry["trace"] = {k: [H(v) for v in tr[k]] for k in ["u_evals", "w_evals", "u", "w", "h", "wit_u", "z_tail", "quotient"]}
+        print("bn254 fixture", name, "n =", pk.n)
+        out.append(entry)
+    return out
+
+
 def pk_wire_fixtures():
     """ProvingKey / VerifyingKey wire bytes of the small proof fixtures: same circuits and
     trapdoors as proofs.json (which must exist), so a key loaded from these bytes reproduces those proofs."""
@@ -139,7 +172,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
     for fname, fn in [("field_curve_kats.json", field_and_curve_kats), ("ntt_msm.json", ntt_msm_vectors),
-                      ("proofs.json", proof_fixtures), ("pk_wire.json", pk_wire_fixtures)]:
+                      ("proofs.json", proof_fixtures), ("proofs_bn254.json", proof_fixtures_bn254), ("pk_wire.json", pk_wire_fixtures)]:
         if only and fname not in only:
             continue
         with open(os.path.join(OUT, fname), "w") as f:
