@@ -674,6 +674,7 @@ __global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, con
 // With 64 regions -> 128 sub-regions -> 256 buckets every pass writes runs of ~100+ entries per bin instead
 // of single scattered words (the two-level version spent most of its time on 4-byte scattered stores).
 enum { RS_HIST = 0, RS_MID = 1, RS_FINAL = 2 };
+constexpr unsigned ST_MAX_BINS_HIST = 256;   // k_hist_small: bins per segment
 constexpr unsigned RS_CHUNK_LOG = 15, RS_PER_LANE = (1u << RS_CHUNK_LOG) / 1024;   // entries per lane of a 1024-lane workgroup
 
 template <int MODE>
@@ -741,6 +742,58 @@ __global__ __launch_bounds__(1024) void k_region_pass(const uint16_t *keys, cons
                     }
                 }
             }
+        }
+        __syncthreads();
+    }
+}
+
+// Histogram for SMALL bin counts (<= 256): counts[segment * nbins + (key >> bin_shift)] += 1.  Every wave counts
+// into its own LDS copy: with one shared copy the 1024 lanes of a workgroup pile onto 128-256 addresses and the
+// LDS serialises them (0.30 ms per pass over 252 M keys; the data is only 0.5 GB).
+__global__ __launch_bounds__(1024) void k_hist_small(const uint16_t *keys, const uint32_t *seg_off, unsigned nseg, unsigned bin_shift,
+                                                     unsigned nbins, unsigned chunk, uint32_t *counts) {
+    __shared__ uint32_t h[16][ST_MAX_BINS_HIST];
+    const uint32_t total = seg_off[nseg];
+    const uint32_t lo = blockIdx.x * chunk;
+    if (lo >= total) return;
+    uint32_t hi = lo + chunk;
+    if (hi > total) hi = total;
+    unsigned ra = 0, rb = nseg;
+    while (rb - ra > 1) {
+        unsigned mid = (ra + rb) >> 1;
+        if (seg_off[mid] <= lo) ra = mid; else rb = mid;
+    }
+    const unsigned wave = threadIdx.x >> 6;
+    for (unsigned r = ra; r < nseg; ++r) {
+        const uint32_t s0 = seg_off[r] > lo ? seg_off[r] : lo;
+        const uint32_t s1 = seg_off[r + 1] < hi ? seg_off[r + 1] : hi;
+        if (s0 >= hi) break;
+        if (s0 >= s1) continue;
+        for (unsigned b = threadIdx.x; b < 16 * ST_MAX_BINS_HIST; b += blockDim.x) (&h[0][0])[b] = 0;
+        __syncthreads();
+        // 8 keys per 16-byte load over the aligned body of the piece; scalar head and tail
+        const uint32_t b0 = (s0 + 7u) & ~7u, b1 = s1 & ~7u;
+        if (b0 < b1) {
+            for (uint32_t e = s0 + threadIdx.x; e < b0; e += blockDim.x) atomicAdd(&h[wave][keys[e] >> bin_shift], 1u);
+            for (uint32_t e = b0 + threadIdx.x * 8u; e < b1; e += blockDim.x * 8u) {
+                const uint4 v = *(const uint4 *)(keys + e);
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    atomicAdd(&h[wave][(w4[q] & 0xffffu) >> bin_shift], 1u);
+                    atomicAdd(&h[wave][(w4[q] >> 16) >> bin_shift], 1u);
+                }
+            }
+            for (uint32_t e = b1 + threadIdx.x; e < s1; e += blockDim.x) atomicAdd(&h[wave][keys[e] >> bin_shift], 1u);
+        } else {
+            for (uint32_t e = s0 + threadIdx.x; e < s1; e += blockDim.x) atomicAdd(&h[wave][keys[e] >> bin_shift], 1u);
+        }
+        __syncthreads();
+        for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {
+            uint32_t v = 0;
+#pragma unroll
+            for (unsigned w = 0; w < 16; ++w) v += h[w][b];
+            if (v) atomicAdd(&counts[(size_t)r * nbins + b], v);
         }
         __syncthreads();
     }
@@ -1175,9 +1228,8 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             uint16_t *keys2 = (uint16_t *)ws.digits2.p;
             uint32_t *vals2 = (uint32_t *)((uint8_t *)ws.digits2.p + keys_bytes);
             PM_HIP(ctx, hipMemsetAsync(sub_count, 0, (size_t)nsub * 4, ctx->stream));
-            hipLaunchKernelGGL(k_region_pass<RS_HIST>, dim3(sblocks), dim3(1024), SUB_BINS * 4, ctx->stream, keys, vals, region_off, regions,
-                               FIN_BITS, SUB_BINS, chunk, sub_count, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                               (uint16_t *)nullptr, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(k_hist_small, dim3(sblocks), dim3(1024), 0, ctx->stream, keys, region_off, regions, FIN_BITS, SUB_BINS, chunk,
+                               sub_count);
             PM_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, sub_count, sub_off, sub_cursor, nsub);
             PM_HIP(ctx, hipGetLastError());
@@ -1185,9 +1237,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             hipLaunchKernelGGL(k_region_pass_staged<RS_MID>, dim3(stblocks), dim3(1024), 0, ctx->stream, keys, vals, region_off, regions,
                                FIN_BITS, SUB_BINS, sub_off, sub_cursor, (uint32_t *)nullptr, keys2, vals2);
             PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_region_pass<RS_HIST>, dim3(sblocks), dim3(1024), FIN_BINS * 4, ctx->stream, keys2, vals2, sub_off, nsub, 0u,
-                               FIN_BINS, chunk, counts, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                               (uint16_t *)nullptr, (uint32_t *)nullptr);
+            hipLaunchKernelGGL(k_hist_small, dim3(sblocks), dim3(1024), 0, ctx->stream, keys2, sub_off, nsub, 0u, FIN_BINS, chunk, counts);
             PM_HIP(ctx, hipGetLastError());
             PM_TRY(bucket_scan());
             hipLaunchKernelGGL(k_region_pass_staged<RS_FINAL>, dim3(stblocks), dim3(1024), 0, ctx->stream, keys2, vals2, sub_off, nsub, 0u,
