@@ -84,7 +84,7 @@ inline void compress(const uint32_t cv[8], const uint32_t block[16], uint64_t co
 }
 inline void words(const uint8_t *p, size_t len, uint32_t w[16]) {
     uint8_t buf[64] = {0};
-    memcpy(buf, p, len);
+    if (len) memcpy(buf, p, len);   // p may be null for the empty message
     memcpy(w, buf, 64);
 }
 struct CV { uint32_t v[8]; };
