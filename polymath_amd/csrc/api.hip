@@ -60,6 +60,11 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
         delete ctx;
         return PM_ERR_HIP;
     }
+    if (hipEventCreateWithFlags(&ctx->ev_sc_a, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return PM_ERR_HIP;
+    }
     *out = ctx;
     return PM_OK;
 }
@@ -78,6 +83,7 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     for (auto &b : ctx->lvl) b.release();
     for (auto &b : ctx->fb_table) b.release();
     for (auto &t : ctx->tw) { t.fwd.release(); t.inv.release(); t.fwd_int.release(); t.inv_int.release(); }
+    (void)hipEventDestroy(ctx->ev_sc_a);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -151,7 +151,7 @@ struct pm_ctx {
     hipStream_t stream;
     std::string err;
     double timing_ms[pm::T_NUM_SLOTS];
-    hipEvent_t ev[4];
+    hipEvent_t ev_sc_a;       // recorded when the [a]_1 scalars are ready (prove.hip: the helper stream waits on it)
     pm::MsmWorkspace msm;
     pm::TwiddleCache tw[4];
     pm::DevBuf scratch, flags;

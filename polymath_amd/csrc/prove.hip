@@ -159,7 +159,7 @@ __global__ void k_phase1_scalars(const Fp<P> *u, const Fp<P> *u2, const Fp<P> *r
         } else if (!hi.is_zero()) {
             atomicOr(flags, 2u);
         }
-        sc_a[i] = u[i];
+        if (sc_a) sc_a[i] = u[i];
     }
     if (i <= n) {  // coefficient i of 2 r_a(X) u(X) = 2 (r0 u_i + r1 u_{i-1})
         Fp<P> t = Fp<P>::zero();
@@ -174,9 +174,23 @@ __global__ void k_phase1_scalars(const Fp<P> *u, const Fp<P> *u2, const Fp<P> *r
         tail[2] = sqr<P>(r1);
         tail[3] = r0;
         tail[4] = r1;
+        if (sc_a) {
+            sc_a[n] = Fp<P>::zero();
+            sc_a[n + 1] = r0;
+            sc_a[n + 2] = r1;
+        }
+    }
+}
+
+// sc_a alone, as soon as u is known: lets the [a]_1 MSM start while the rest of phase 1 still runs
+template <class P>
+__global__ void k_sc_a(const Fp<P> *u, const Fp<P> *ra, Fp<P> *sc_a, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sc_a[i] = u[i];
+    if (i == 0) {
         sc_a[n] = Fp<P>::zero();
-        sc_a[n + 1] = r0;
-        sc_a[n + 2] = r1;
+        sc_a[n + 1] = ra[0];
+        sc_a[n + 2] = ra[1];
     }
 }
 
@@ -426,6 +440,35 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     PM_HIP(ctx, hipMemcpyAsync(u, ue, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     PM_HIP(ctx, hipMemcpyAsync(wv, we, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     PM_TRY(ntt_run<C>(ctx, u, pk->log_n, true));
+    // [a]_1 = M1 + M2 needs only u and r_a, and is independent of [c]_1 = M7 + M6 + M3 + M4 + M5: it runs on a helper
+    // context (own stream and workspace) from a second host thread, started HERE -- its sort, bucket reduction and
+    // host finish are dependent chains that leave the chip mostly idle, and hide under the remaining transforms and
+    // the larger MSM's accumulation.  The helper stream waits on an event, the host does not.  PM_MSM_OVERLAP=0
+    // runs the two MSMs back to back after the checks.
+    static const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
+    int st_a = PM_OK;   // written by the helper thread: declared before the joiner so that it outlives the join
+    struct Joiner {     // an early error return must not leave a joinable thread behind
+        std::thread t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } helper;
+    const bool a_early = overlap && ctx->aux;
+    if (a_early) {
+        pm_ctx *aux = ctx->aux;
+        hipLaunchKernelGGL(k_sc_a<P>, dim3(nblk(n)), dim3(256), 0, st, u, ra, sc_a, n);
+        PM_HIP(ctx, hipGetLastError());
+        PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
+        timing_reset(aux);
+        helper.t = std::thread([&, aux] {
+            if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0) != hipSuccess) {
+                st_a = PM_ERR_HIP;
+                aux->err = "helper stream setup failed";
+                return;
+            }
+            st_a = msm_shard<C>(aux, pk, 0, sc_a, a_xy, a_inf);
+            timing_flush(aux);
+        });
+    }
     PM_TRY(ntt_run<C>(ctx, wv, pk->log_n, true));
     if (2 * m0 <= 16 && pk->log_n >= 1) {   // few public inputs: the sparse sum beats a fifth transform
         const Fr *winv = nullptr;
@@ -459,7 +502,8 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     }
     {
         StageTimer t(ctx, T_POLY);
-        hipLaunchKernelGGL(k_phase1_scalars<P>, dim3(nblk(n + 1)), dim3(256), 0, st, u, u2, ra, sc_c + Lz, sc_a, n, flags);
+        hipLaunchKernelGGL(k_phase1_scalars<P>, dim3(nblk(n + 1)), dim3(256), 0, st, u, u2, ra, sc_c + Lz, a_early ? (Fr *)nullptr : sc_a, n,
+                           flags);
         PM_HIP(ctx, hipGetLastError());
     }
     unsigned hflags = 0;
@@ -467,25 +511,11 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     PM_HIP(ctx, hipStreamSynchronize(st));
     if (hflags & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
     if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
-    // [a]_1 = M1 + M2 and [c]_1 = M7 + M6 + M3 + M4 + M5 are independent: the smaller one runs on a helper
-    // context (own stream and workspace) from a second host thread, so its sort, bucket reduction and host
-    // finish -- dependent chains that leave the chip mostly idle -- hide under the larger one's accumulation.
-    // PM_MSM_OVERLAP=0 runs them back to back.
-    static const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
-    if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
-    if (overlap && ctx->aux) {
-        pm_ctx *aux = ctx->aux;
-        timing_reset(aux);
-        int st_a = PM_OK;
-        std::thread helper([&] {
-            if (hipSetDevice(aux->device) != hipSuccess) { st_a = PM_ERR_HIP; aux->err = "hipSetDevice (helper thread)"; return; }
-            st_a = msm_shard<C>(aux, pk, 0, sc_a, a_xy, a_inf);
-            timing_flush(aux);
-        });
+    if (a_early) {
         const int st_c = msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
-        helper.join();
-        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += aux->timing_ms[s];
-        if (st_a != PM_OK) { ctx->err = aux->err; return st_a; }
+        helper.t.join();
+        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];
+        if (st_a != PM_OK) { ctx->err = ctx->aux->err; return st_a; }
         PM_TRY(st_c);
     } else {
         PM_TRY(msm_shard<C>(ctx, pk, 0, sc_a, a_xy, a_inf));
