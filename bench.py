@@ -11,8 +11,9 @@ resident in HBM before the timed region.  With N > 1 ONE proof is spread over th
 ranges sharded, partial points all-gathered over RCCL), so scaling is "strong".
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the MSM bucket accumulation,
-HIP-event timed on the library's stream) and `cpu_baseline` (the CPU restatement oracle/cpp timed on
-this box's host cores over a bounded sample; "CPU restatement -- not arkworks").
+HIP-event timed on the library's stream), `cpu_baseline` (the CPU restatement oracle/cpp proving the SAME
+2^20-100-gate circuit on this box's host cores, once; "CPU restatement -- not arkworks") and
+`msm_micro` (the metric's second half: standalone resident G1 MSM pairs/s at 2^20 ... 2^26 pairs).
 """
 import argparse
 import json
@@ -37,28 +38,69 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(curve, log_nr, seconds_hint=20):
-    """ORACLE leg (the only place bench.py touches oracle/): time the CPU restatement's whole prove
-    on a smaller circuit of the same family and report constraints/s."""
+def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
+    """ORACLE leg (the only place bench.py touches oracle/): time the CPU restatement's whole prove of THE SAME
+    circuit, key and r_a the GPU just proved (the headline workload when log_nr == --log-constraints) on this box's host
+    cores.  The oracle's key is seeded with the bases exported from HBM (its own CPU setup would take many minutes and
+    is not the metric); the two proofs must be byte-identical."""
     from oracle import cpp_oracle as CO, driver as DR
-    from oracle.pyref import circuits as OC, protocol as PR, transcripts as OT
+    from oracle.pyref import serialize as SE, transcripts as OT
     from oracle.pyref.fields import CURVES
     c = CURVES[curve]
     cores = os.cpu_count() or 1
-    nr = (1 << log_nr) - 100
-    q, inst, wit = OC.synthetic_r1cs(c, nr)
+
+    class Shape:
+        pass
+    q = Shape()
+    q.m0, q.mw, q.nr = lc.m0, lc.mw, lc.nr
+    q.csr_arrays = [(a.rowptr, a.col, a.val) for a in lc.csrs]
     t0 = time.time()
-    opk = CO.OraclePk(curve, q, 0x1234567, 0x7654321, cores)
+    opk = CO.OraclePk(curve, q, None, None, cores)
+    for i in range(6):
+        opk.import_bases(i, gpk.export_bases(i))
     t_setup = time.time() - t0
     omega = CO.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+    inst = lc.instance
     t0 = time.time()
-    DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, [3, 5], OT.make_transcripts(c)["merlin"])
+    ref = DR.prove(opk, opk.n, opk.sigma, omega, inst, None, r_a, OT.make_transcripts(c)[transcript], w_limbs=lc.wit_limbs)
     dt = time.time() - t0
+    same = gpu_proof is None or SE.ser_proof(c, ref) == gpu_proof
     pairs = 14 * opk.n + 30
-    return {"value": nr / dt, "unit": "constraints/s", "cores": cores, "kind": "port",
-            "sample": "oracle/cpp CPU restatement (not arkworks): whole prove of the 2^%d-100-gate synthetic R1CS "
-                      "(n=%d, %d MSM pairs) in %.2f s on %d threads; setup %.1f s untimed" % (log_nr, opk.n, pairs, dt, cores, t_setup),
-            "msm_pairs_per_sec": pairs / dt}
+    return {"value": lc.nr / dt, "unit": "constraints/s", "cores": cores, "kind": "port",
+            "sample": "oracle/cpp CPU restatement (not arkworks; 64-bit-limb C++, %d threads): ONE whole prove of the 2^%d-100-gate "
+                      "synthetic R1CS (n=%d, %d MSM pairs) in %.2f s, on the key exported from HBM (import %.1f s untimed); "
+                      "proof bytes %s the GPU's" % (cores, log_nr, opk.n, pairs, dt, t_setup, "==" if same else "!="),
+            "seconds": dt, "proof_identical_to_gpu": same, "msm_pairs_per_sec": pairs / dt}
+
+
+def msm_micro(ctx, curve, logs, reps=3):
+    """The second half of the metric (SURVEY.md §8d: "G1 MSM pairs/s = L / time of pm_msm_g1, bases resident";
+    benches/bench.rs:82-91 is the reference's only analogue): standalone resident MSM, bases P_i = (i+1) G built on the
+    device with their window tables, uniform scalars already in HBM."""
+    import torch
+    from polymath_amd import api
+    out = []
+    for lg in logs:
+        n = 1 << lg
+        bases = api.Bases.multiples(ctx, curve, n).precompute()
+        g = torch.Generator(device="cuda").manual_seed(1234 + lg)
+        sc = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device="cuda", generator=g) * 4 + torch.randint(0, 4, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        sc[:, 3] &= (1 << 61) - 1      # < 2^253: canonical residues of both scalar fields, taken as Montgomery forms of uniform elements
+        torch.cuda.synchronize()
+        best, tm = None, None
+        for rep in range(reps + 1):
+            t0 = time.perf_counter()
+            bases.msm(None, 0, n, device_ptr=sc.data_ptr())
+            dt = time.perf_counter() - t0
+            if rep and (best is None or dt < best):
+                best, tm = dt, ctx.timings()
+        out.append({"len": n, "ms": best * 1e3, "pairs_per_sec": n / best,
+                    "hbm_frac_algorithmic": MSM_BYTES_PER_PAIR[curve] * n / best / 1e9 / HBM_PEAK_GBS,
+                    "stage_ms": {k: round(v, 3) for k, v in tm.items() if k.startswith("msm")}})
+        bases.free()
+        del sc
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -69,8 +111,9 @@ def main():
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--curve", default="bls12_381")
     ap.add_argument("--transcript", default="merlin")
-    ap.add_argument("--cpu-baseline-log", type=int, default=16)
+    ap.add_argument("--cpu-baseline-log", type=int, default=0, help="0 = the headline workload itself when this box has >= 32 host threads, else 2^16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msm-micro", default="20,22,24,26", help="log2 lengths of the standalone resident MSM legs ('' = none)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,7 +143,8 @@ def main():
     r = FIELDS[curve]["r"]
     nr = (1 << args.log_constraints) - 100          # benches/bench.rs:16 convention: n = 2^(k+1)
     t0 = time.time()
-    r1cs, inst, wit = PC.synthetic_r1cs(r, nr)
+    r1cs = PC.synthetic_r1cs_native(curve, nr)      # pm_synth_r1cs: the same draws as circuits.synthetic_r1cs, no Python big ints
+    inst = r1cs.instance
     log(rank, "synthetic R1CS: nr=%d m0=%d mw=%d (%.1f s)" % (nr, r1cs.m0, r1cs.mw, time.time() - t0))
     pm = Polymath(curve, args.transcript, device=local)
     g = PC.SplitMix64(0xBE7C4)
@@ -111,9 +155,9 @@ def main():
     shard_rank, shard_count = rank, world
     if world == 1 and os.environ.get("BENCH_FAKE_SHARD"):
         shard_rank, shard_count = (int(v) for v in os.environ["BENCH_FAKE_SHARD"].split("/"))
-    pk = pm.setup((r1cs, inst, wit), x_trap, z_trap, shard_rank=shard_rank, shard_count=shard_count)
+    pk = pm.setup(r1cs, x_trap, z_trap, shard_rank=shard_rank, shard_count=shard_count)
     log(rank, "setup on device: n=%d, %d resident points (%.1f s)" % (pk.n, sum(pk.base_lens), time.time() - t0))
-    x_l, w_l = pm.field.fr_limbs(inst), pm.field.fr_limbs(wit)
+    x_l, w_l = r1cs.inst_limbs, r1cs.wit_limbs
     combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local, backend_gloo=(backend != "nccl")) if world > 1 else None
 
     def barrier():
@@ -179,6 +223,16 @@ def main():
     if native:
         acc_ms, msm_ms, sort_ms, red_ms, phase_ms = [tm3["msm_accumulate"]], [tm3["msm_total"]], [tm3["msm_sort"]], [tm3["msm_reduce"]], [tm3["phase"]]
         acc1_ms = [tm1["msm_accumulate"]]
+    # Roofline sample, outside the timed region: ONE proof with PM_MSM_OVERLAP=0, so that each k_accumulate launch runs
+    # alone on the chip (in the timed proofs the [a] launch shares it with the transforms and the [c] MSM, which
+    # inflates its HIP-event duration); these are the durations rocprofv3 --stats of the same configuration prints.
+    os.environ["PM_MSM_OVERLAP"] = "0"
+    pm.collect_timings = True
+    proof_serial = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs).to_bytes()
+    pm.collect_timings = False
+    del os.environ["PM_MSM_OVERLAP"]
+    assert proof_serial == proof_b
+    acc_serial_ms = pm.phase_timings[0]["msm_accumulate"] + pm.phase_timings[2]["msm_accumulate"]
     if os.environ.get("BENCH_PHASES"):             # dev hook: stage timings of all three phases (stderr)
         log(rank, "phase-by-phase proof %.2f ms; phases:" % ms_python_glue)
         for i, tm in enumerate(pm.phase_timings):
@@ -195,7 +249,8 @@ def main():
         # launch duration = (HIP-event time of the three launches) / 3 -- the same average rocprofv3 --stats prints.
         plans = [pk.msm_plan(k) for k in range(3)]              # (resident pairs, windows, bits, tables)
         launches = 3
-        acc_s = (avg(acc_all_ms) if native else avg(acc_ms) + avg(acc1_ms)) * 1e-3   # per proof, all three launches
+        acc_s = acc_serial_ms * 1e-3                             # per proof, all three launches, each running alone
+        acc_overlapped_s = (avg(acc_all_ms) if native else avg(acc_ms) + avg(acc1_ms)) * 1e-3   # as in the timed proofs
         pairs_rank = sum(p[0] for p in plans)
         achieved = (bpp * pairs_rank / acc_s / 1e9) if acc_s > 0 else 0.0
         mads_rank = float(MADS_PER_MIXED_ADD[curve]) * sum(p[0] * p[1] for p in plans)
@@ -228,7 +283,10 @@ def main():
                                 "msm_total": avg(msm_ms), "phase3_total": avg(phase_ms)},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (MSM bucket accumulation; %d launches per proof: [a], [c], [d])" % launches,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "launches_per_step": launches, "avg_launch_ms": acc_s * 1e3 / launches,
+                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured by this run)",
+                         "launches_per_step": launches, "avg_launch_ms": acc_s * 1e3 / launches,
+                         "timing": "HIP events on the library's stream around each launch of one PM_MSM_OVERLAP=0 proof outside the timed region "
+                                   "(launches run alone); in the timed proofs [a] overlaps other kernels: %.3f ms per proof there" % (acc_overlapped_s * 1e3),
                          "algorithmic_bytes_per_launch": bpp * pairs_rank / launches,
                          "largest_launch": {"pairs": d_pairs_rank, "ms": avg(acc_ms),
                                             "achieved": (bpp * d_pairs_rank / (avg(acc_ms) * 1e-3) / 1e9) if avg(acc_ms) > 0 else None},
@@ -241,9 +299,23 @@ def main():
                      "note": "the real bound of this kernel: mads are 76 % of its instruction stream (3 542 of 4 635 per mixed add)"},
             "proof_bytes": proof_b.hex(),
         }
-        if not args.no_cpu_baseline:
-            log(rank, "timing the CPU restatement (bounded sample) ...")
-            out["cpu_baseline"] = cpu_baseline(curve, args.cpu_baseline_log)
+        if world == 1 and shard_count == 1:
+            if not args.no_cpu_baseline:
+                cores = os.cpu_count() or 1
+                cb_log = args.cpu_baseline_log or (args.log_constraints if cores >= 32 and args.log_constraints <= 20 else 16)
+                log(rank, "timing the CPU restatement on the 2^%d-100-gate circuit (%d host threads) ..." % (cb_log, cores))
+                if cb_log == args.log_constraints:
+                    out["cpu_baseline"] = cpu_baseline(curve, cb_log, r1cs, pk, r_a, proof_b, args.transcript)
+                else:
+                    lc_s = PC.synthetic_r1cs_native(curve, (1 << cb_log) - 100)
+                    pk_s = pm.setup(lc_s, x_trap, z_trap)
+                    gp = pm.prove_native(pk_s, lc_s.inst_limbs, lc_s.wit_limbs, r_a)
+                    out["cpu_baseline"] = cpu_baseline(curve, cb_log, lc_s, pk_s, r_a, gp, args.transcript)
+                    pk_s.free()
+            if args.msm_micro:
+                pk.free()                                        # give the HBM back: the 2^26 leg holds 100 GB of window tables
+                log(rank, "standalone resident MSM legs: 2^{%s} pairs ..." % args.msm_micro)
+                out["msm_micro"] = msm_micro(pm.ctx, curve, [int(v) for v in args.msm_micro.split(",")])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -148,7 +148,9 @@ typedef enum pm_transcript { PM_TRANSCRIPT_MERLIN = 0, PM_TRANSCRIPT_KECCAK256 =
  *   w   : mw Fr, witness assignment
  *   r_a : 2 Fr, the two F::rand draws of prover.rs:110 (constant term first) -- an input so
  *         the RNG stays with the caller.
- * On a sharded pk the outputs are this shard's PARTIAL sums; combine with pm_g1_sum. */
+ * On a sharded pk the outputs are this shard's PARTIAL sums; combine with pm_g1_sum.
+ * On a non-zero status the output points are UNDEFINED (the [a]_1 MSM may already have run when the witness check
+ * fails: it overlaps the transforms). */
 int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
                     uint64_t *a_g1_xy, int *a_inf, uint64_t *c_g1_xy, int *c_inf);
 /* Same with the assignment ALREADY RESIDENT in HBM: d_x (m0 Fr) and d_w (mw Fr) are device pointers (e.g. the
@@ -187,6 +189,14 @@ int pm_host_prove_sharded(pm_ctx *ctx, const pm_pk *pk, int transcript, const ui
 /* Host helper: Keccak-f[1600] on 25 little-endian lanes, shared by the host mirrors' Merlin / Keccak256
  * transcripts (the reference's transcripts are host code too: src/transcript/ *.rs). */
 void pm_host_keccak_f1600(uint64_t state[25]);
+
+/* Harness workload (no reference counterpart in src/; benches/bench.rs:38-61 is the reference's own): the synthetic
+ * "random A*B=C gates" R1CS of BASELINE.json configs[1..4], generated natively with the same splitmix64
+ * draws as polymath_amd/circuits.py: synthetic_r1cs.  m0 = 2, mw = nr + 1, one entry per row in A, B and C, so
+ * rowptr = 0..nr is implied.  a_val/b_val/c_val: nr x 4 u64 Montgomery; *_col: nr u32; instance: 2 Fr (one, out);
+ * witness: (nr + 1) Fr.  Host code: needs no GPU. */
+int pm_synth_r1cs(int curve, uint64_t nr, uint64_t seed, uint64_t *a_val, uint32_t *a_col, uint64_t *b_val, uint32_t *b_col,
+                  uint64_t *c_val, uint32_t *c_col, uint64_t *instance, uint64_t *witness);
 
 /* Debug / parity taps: copy an intermediate vector of the proof in flight back to the host.
  * which: 0 u_evals(n) 1 w_evals(n) 2 u coeffs(n) 3 w coeffs(n) 4 h coeffs(n) 5 witness-u coeffs(n)

@@ -107,6 +107,16 @@ def _p(arr):
 class CsrBuf:
     """Keeps numpy buffers alive behind a PoCsr / pm_csr struct."""
 
+    @classmethod
+    def from_arrays(cls, rowptr, col, val, struct_cls=PoCsr):
+        """Ready CSR arrays (rowptr u64, col u32, val [nnz,4] Montgomery limbs) -- no Python integers involved."""
+        self = cls.__new__(cls)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        self.col = np.ascontiguousarray(col, dtype=np.uint32)
+        self.val = np.ascontiguousarray(val, dtype=np.uint64)
+        self.struct = struct_cls(len(self.rowptr) - 1, _p(self.rowptr), self.col.ctypes.data_as(u32p), _p(self.val))
+        return self
+
     def __init__(self, curve, rows, struct_cls=PoCsr):
         rowptr = [0]
         cols, vals = [], []
@@ -198,7 +208,10 @@ class OraclePk:
     def __init__(self, curve, r1cs, x_trapdoor=None, z_trapdoor=None, nthreads=1):
         self.curve, self.cid, self.nthreads = curve, CURVE_IDS[curve], nthreads
         self.nq = CURVES[curve].fq_limbs64
-        self._bufs = [CsrBuf(curve, r1cs.a), CsrBuf(curve, r1cs.b), CsrBuf(curve, r1cs.c)]
+        if hasattr(r1cs, "csr_arrays"):       # (rowptr, col, val limbs) x 3, e.g. from the library's native circuit generator
+            self._bufs = [CsrBuf.from_arrays(*t) for t in r1cs.csr_arrays]
+        else:
+            self._bufs = [CsrBuf(curve, r1cs.a), CsrBuf(curve, r1cs.b), CsrBuf(curve, r1cs.c)]
         st = ct.c_int(0)
         xt = fr_to_mont_limbs(curve, [x_trapdoor]) if x_trapdoor is not None else None
         zt = fr_to_mont_limbs(curve, [z_trapdoor]) if z_trapdoor is not None else None

@@ -18,12 +18,13 @@ class ProverError(Exception):
         self.phase, self.rc = phase, rc
 
 
-def prove(backend, n, sigma, omega, instance, witness, r_a, transcript_cls, trace=None):
+def prove(backend, n, sigma, omega, instance, witness, r_a, transcript_cls, trace=None, w_limbs=None):
+    """witness: list of integers, or None with w_limbs = the same as Montgomery limbs [mw, 4] (large circuits)."""
     cname = backend.curve
     c = CURVES[cname]
     r = c.r
     x = CO.fr_to_mont_limbs(cname, instance)
-    w = CO.fr_to_mont_limbs(cname, witness)
+    w = w_limbs if w_limbs is not None else CO.fr_to_mont_limbs(cname, witness)
     ra = CO.fr_to_mont_limbs(cname, r_a)
     rc, a_xy, a_inf, c_xy, c_inf = backend.phase1(x, w, ra)
     if rc:

@@ -36,6 +36,15 @@ BN254_P = 2188824287183927522224640574525727508869631115729782366268903789464522
 BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 BN254_B = 3
 BN254_G1 = (1, 2)
+# G2 generator of ark-bn254 / EIP-197 (x = x0 + x1*i, y = y0 + y1*i), Fq2 = Fq[i]/(i^2+1); twist b' = 3/(9+i).
+# Checked in tests/test_oracle_pyref.py: on the twist, r * G2 == O.
+BN254_G2 = (
+    (10857046999023057135944570762232829481370756359578518086990519993285655852781,
+     11559732032986387107991004021392285783925812861821192530917403151452391805634),
+    (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+     4082367875863433681332203403145435568316851327593401208105741076214120093531),
+)
+BN254_X = 4965661367192848881     # curve parameter: p = 36x^4 + 36x^3 + 24x^2 + 6x + 1, r = 36x^4 + 36x^3 + 18x^2 + 6x + 1
 BN254_FR_GENERATOR = 5
 BN254_FR_TWO_ADICITY = 28
 

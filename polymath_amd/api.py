@@ -51,7 +51,7 @@ EXPORTS = [
     "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
     "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
     "pm_pk_info", "pm_pk_msm_plan", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3", "pm_host_prove", "pm_host_prove_sharded",
-    "pm_prove_tap", "pm_host_keccak_f1600",
+    "pm_prove_tap", "pm_host_keccak_f1600", "pm_synth_r1cs",
 ]
 
 _lib = None
@@ -106,6 +106,7 @@ def load_library():
     L.pm_prove_tap.argtypes = [vp, i, u64p, sz, ct.POINTER(sz)]
     L.pm_host_keccak_f1600.argtypes = [u64p]
     L.pm_host_keccak_f1600.restype = None
+    L.pm_synth_r1cs.argtypes = [i, u64, u64, u64p, u32p, u64p, u32p, u64p, u32p, u64p, u64p]
     _lib = L
     return L
 
@@ -130,6 +131,20 @@ def g1_sum(curve, pts, infs=None):
     if st:
         raise PolymathError(st, "pm_g1_sum")
     return out, inf.value
+
+
+def synth_r1cs(curve, nr, seed):
+    """pm_synth_r1cs: the SURVEY §8d synthetic R1CS as limb arrays -> (CsrArrays A, B, C, instance [2,4], witness [nr+1,4])."""
+    L = load_library()
+    vals = [np.zeros((nr, 4), dtype=np.uint64) for _ in range(3)]
+    cols = [np.zeros(nr, dtype=np.uint32) for _ in range(3)]
+    inst, wit = np.zeros((2, 4), dtype=np.uint64), np.zeros((nr + 1, 4), dtype=np.uint64)
+    st = L.pm_synth_r1cs(CURVE_IDS[curve], nr, seed, _p(vals[0]), cols[0].ctypes.data_as(u32p), _p(vals[1]), cols[1].ctypes.data_as(u32p),
+                         _p(vals[2]), cols[2].ctypes.data_as(u32p), _p(inst), _p(wit))
+    if st:
+        raise PolymathError(st, "pm_synth_r1cs")
+    rowptr = np.arange(nr + 1, dtype=np.uint64)
+    return [CsrArrays(rowptr, cols[k], vals[k]) for k in range(3)], inst, wit
 
 
 class Context:

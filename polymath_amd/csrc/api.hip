@@ -471,10 +471,16 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     // an MSM without tables runs the per-window pipeline on the plain array.
     size_t free_b = 0, total_b = 0;
     PM_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    double budget = 0.9 * (double)free_b - 64.0 * 40.0 * (double)pk->n;
+    // PM_INFLIGHT_CONTEXTS: how many contexts will prove on this resident key at once (each owns the per-proof vectors
+    // and an MSM workspace; default 1).  The helper context of the overlapped [a]_1 MSM (prove.hip) has a workspace of
+    // its own as well.
+    int inflight = 1;
+    if (const char *e = getenv("PM_INFLIGHT_CONTEXTS")) inflight = atoi(e) > 1 ? atoi(e) : 1;
+    double budget = 0.9 * (double)free_b - (double)inflight * 64.0 * 40.0 * (double)pk->n;
     {
-        const uint64_t len_d = pk->res_hi[2] - pk->res_lo[2];
-        budget -= 48.0 * 16.0 * (double)(len_d < ((uint64_t)1 << 27) ? len_d : ((uint64_t)1 << 27));
+        const uint64_t len_d = pk->res_hi[2] - pk->res_lo[2], len_a = pk->res_hi[0] - pk->res_lo[0];
+        budget -= (double)inflight * 48.0 * 16.0 * (double)(len_d < (uint64_t)msm_max_piece() ? len_d : (uint64_t)msm_max_piece());
+        budget -= (double)inflight * 48.0 * 16.0 * (double)len_a;
     }
     int order[3] = {0, 1, 2};
     std::sort(order, order + 3, [&](int x, int y) { return pk->res_hi[x] - pk->res_lo[x] < pk->res_hi[y] - pk->res_lo[y]; });
@@ -667,7 +673,7 @@ extern "C" int pm_pk_msm_plan(const pm_pk *pk, int which, uint64_t *pairs, unsig
         nwin = pk->tables[which].nwin;
         c = pk->tables[which].c;
     } else {
-        const uint64_t piece = len < ((uint64_t)1 << 27) ? len : ((uint64_t)1 << 27);   // msm.hip: MSM_MAX_PIECE
+        const uint64_t piece = len < (uint64_t)msm_max_piece() ? len : (uint64_t)msm_max_piece();
         pm::msm_plan_query((size_t)piece, pk->curve == PM_BLS12_381 ? (unsigned)BlsFrP::BITS : (unsigned)BnFrP::BITS, &nwin, &c);
     }
     if (pairs) *pairs = len;
@@ -700,13 +706,30 @@ extern "C" int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_
 }
 
 // -------------------------------------------------------------------------------- prove
+// extern "C" entry points never let a C++ exception (bad_alloc in a host vector, system_error from a thread) unwind
+// into the embedding host (a Rust shim or ctypes): it becomes a status with the message in pm_last_error.
+template <class F>
+static int guarded(pm_ctx *ctx, F body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        ctx->err = "host allocation failed";
+        return PM_ERR_STATE;
+    } catch (const std::exception &e) {
+        ctx->err = e.what();
+        return PM_ERR_STATE;
+    }
+}
+
 extern "C" int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
                                uint64_t *a_g1_xy, int *a_inf, uint64_t *c_g1_xy, int *c_inf) {
     if (!ctx || !pk || !x || !r_a || !a_g1_xy || !a_inf || !c_g1_xy || !c_inf || (pk->mw && !w)) return PM_ERR_INVALID_ARG;
     if (pk->device != ctx->device) return PM_ERR_INVALID_ARG;
     PM_TRY(set_device(ctx));
-    return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false),
-                       prove_phase1_impl<BnCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false));
+    return guarded(ctx, [&] {
+        return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false),
+                           prove_phase1_impl<BnCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false));
+    });
 }
 
 extern "C" int pm_prove_phase1_device(pm_ctx *ctx, const pm_pk *pk, const uint64_t *d_x, const uint64_t *d_w, const uint64_t *r_a,
@@ -714,15 +737,17 @@ extern "C" int pm_prove_phase1_device(pm_ctx *ctx, const pm_pk *pk, const uint64
     if (!ctx || !pk || !d_x || !r_a || !a_g1_xy || !a_inf || !c_g1_xy || !c_inf || (pk->mw && !d_w)) return PM_ERR_INVALID_ARG;
     if (pk->device != ctx->device) return PM_ERR_INVALID_ARG;
     PM_TRY(set_device(ctx));
-    return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true),
-                       prove_phase1_impl<BnCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true));
+    return guarded(ctx, [&] {
+        return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true),
+                           prove_phase1_impl<BnCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true));
+    });
 }
 
 extern "C" int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1) {
     if (!ctx || !x1 || !u_at_x1) return PM_ERR_INVALID_ARG;
     if (!ctx->pk) return PM_ERR_STATE;
     PM_TRY(set_device(ctx));
-    return PM_DISPATCH(ctx->pk->curve, prove_phase2_impl<BlsCurve>(ctx, x1, u_at_x1), prove_phase2_impl<BnCurve>(ctx, x1, u_at_x1));
+    return guarded(ctx, [&] { return PM_DISPATCH(ctx->pk->curve, prove_phase2_impl<BlsCurve>(ctx, x1, u_at_x1), prove_phase2_impl<BnCurve>(ctx, x1, u_at_x1)); });
 }
 
 extern "C" int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
@@ -730,8 +755,10 @@ extern "C" int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *
     if (!ctx || !x1 || !x2 || !a_at_x1 || !c_at_x1 || !d_g1_xy || !d_inf) return PM_ERR_INVALID_ARG;
     if (!ctx->pk) return PM_ERR_STATE;
     PM_TRY(set_device(ctx));
-    return PM_DISPATCH(ctx->pk->curve, prove_phase3_impl<BlsCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf),
-                       prove_phase3_impl<BnCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf));
+    return guarded(ctx, [&] {
+        return PM_DISPATCH(ctx->pk->curve, prove_phase3_impl<BlsCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf),
+                           prove_phase3_impl<BnCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf));
+    });
 }
 
 extern "C" int pm_prove_tap(pm_ctx *ctx, int which, uint64_t *out, size_t max_elems, size_t *n_elems) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -179,6 +180,15 @@ template <class C>
 int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len,
             Affine<C> *h_out, int *h_inf, const MsmTables *tables = nullptr);
 
+// One bucket pipeline covers at most this many pairs (sorted-entry positions are u32: windows x pairs < 2^32); longer
+// MSMs run in pieces summed on the host.  2^27 in production; PM_MSM_MAX_PIECE_LOG (developer / test knob) lowers it
+// so that the piece-split path can be exercised at small sizes.
+inline size_t msm_max_piece() {
+    const char *e = getenv("PM_MSM_MAX_PIECE_LOG");   // read per call: tests toggle it inside one process
+    const int lg = e ? atoi(e) : 27;
+    return (size_t)1 << (lg < 4 ? 4 : lg > 27 ? 27 : lg);
+}
+
 // choose c and the number of windows for a key whose longest MSM has `max_len` pairs
 void msm_plan_query(size_t len, unsigned scalar_bits, unsigned *nwin, unsigned *c);
 MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits);
@@ -252,5 +262,13 @@ inline void timing_flush(pm_ctx *ctx) {
     }
     ctx->pending_timers.clear();
 }
+
+// Declared BEFORE a call's StageTimers: whatever path the call returns by (error statuses included), the stage timers
+// that were started are read and their events destroyed -- stale entries would otherwise be added to the next
+// proof's slots.
+struct TimingGuard {
+    pm_ctx *ctx;
+    ~TimingGuard() { timing_flush(ctx); if (ctx->aux) timing_flush(ctx->aux); }
+};
 
 }  // namespace pm

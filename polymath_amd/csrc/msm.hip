@@ -1046,8 +1046,7 @@ static int task_order(pm_ctx *ctx, const uint32_t *counts, size_t G, size_t seg,
 }
 
 // ------------------------------------------------------------------------------- driver
-// One bucket pipeline over at most MSM_MAX_PIECE pairs (sorted-entry positions are u32: W * len < 2^32).
-constexpr size_t MSM_MAX_PIECE = (size_t)1 << 27;
+// One bucket pipeline over at most msm_max_piece() pairs (internal.h; sorted-entry positions are u32: W * len < 2^32).
 
 template <class C>
 static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, Affine<C> *h_out,
@@ -1305,6 +1304,7 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
         return PM_OK;
     }
     const bool tbl = tables && tables->c;
+    const size_t MSM_MAX_PIECE = msm_max_piece();
     if (len <= MSM_MAX_PIECE)
         return tbl ? msm_piece_tables<C>(ctx, *tables, d_scalars, len, h_out, h_inf)
                    : msm_piece<C>(ctx, d_bases, d_scalars, len, h_out, h_inf);

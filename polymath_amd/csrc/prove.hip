@@ -397,6 +397,7 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     if (!ctx->keep_timings) timing_reset(ctx);
     ctx->pk = pk;
     ctx->phase = 0;
+    TimingGuard timing_guard{ctx};
     StageTimer t_phase(ctx, T_PHASE);
     const uint64_t len_c = Lz + (n - 1) + (n + 1) + 3 + 2, len_a = n + 3;
     PM_HIP(ctx, ctx->xw.reserve((m0 + mw) * sizeof(Fr)));
@@ -445,29 +446,38 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     // host finish are dependent chains that leave the chip mostly idle, and hide under the remaining transforms and
     // the larger MSM's accumulation.  The helper stream waits on an event, the host does not.  PM_MSM_OVERLAP=0
     // runs the two MSMs back to back after the checks.
-    static const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
+    const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();   // per call: bench.py toggles it
     if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
     int st_a = PM_OK;   // written by the helper thread: declared before the joiner so that it outlives the join
     struct Joiner {     // an early error return must not leave a joinable thread behind
         std::thread t;
         ~Joiner() { if (t.joinable()) t.join(); }
     } helper;
-    const bool a_early = overlap && ctx->aux;
+    bool a_early = overlap && ctx->aux;
     if (a_early) {
         pm_ctx *aux = ctx->aux;
         hipLaunchKernelGGL(k_sc_a<P>, dim3(nblk(n)), dim3(256), 0, st, u, ra, sc_a, n);
         PM_HIP(ctx, hipGetLastError());
         PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
         timing_reset(aux);
-        helper.t = std::thread([&, aux] {
-            if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0) != hipSuccess) {
-                st_a = PM_ERR_HIP;
-                aux->err = "helper stream setup failed";
-                return;
-            }
-            st_a = msm_shard<C>(aux, pk, 0, sc_a, a_xy, a_inf);
-            timing_flush(aux);
-        });
+        try {
+            helper.t = std::thread([&, aux] {
+                if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0) != hipSuccess) {
+                    st_a = PM_ERR_HIP;
+                    aux->err = "helper stream setup failed";
+                    return;
+                }
+                try {
+                    st_a = msm_shard<C>(aux, pk, 0, sc_a, a_xy, a_inf);
+                } catch (const std::exception &e) {   // bad_alloc in the MSM's host vectors: a status, never a terminate
+                    st_a = PM_ERR_STATE;
+                    aux->err = e.what();
+                }
+                timing_flush(aux);
+            });
+        } catch (const std::system_error &) {
+            a_early = false;   // no helper thread: the two MSMs run back to back below (sc_a is already filled)
+        }
     }
     PM_TRY(ntt_run<C>(ctx, wv, pk->log_n, true));
     if (2 * m0 <= 16 && pk->log_n >= 1) {   // few public inputs: the sparse sum beats a fifth transform
@@ -561,6 +571,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     const pm_pk *pk = ctx->pk;
     hipStream_t st = ctx->stream;
     if (!ctx->keep_timings) timing_reset(ctx);
+    TimingGuard timing_guard{ctx};
     StageTimer t_phase(ctx, T_PHASE);
     const uint64_t n = pk->n, sigma = pk->sigma;
     Fr x1 = load_fr<P>(x1_in), x2 = load_fr<P>(x2_in), a_at = load_fr<P>(a_in), c_at = load_fr<P>(c_in);

@@ -227,14 +227,17 @@ struct ProvingKey {   // device-resident ProvingKey (data_structures.rs:56-73) +
     ~ProvingKey() { if (h) pm_pk_free(h); }
 };
 
-// VerifyingKey (data_structures.rs:38-52) with PairingVK (:25-35).  BLS12-381 only: the reference
-// instantiates no other pairing engine (Cargo.toml:35).
-struct VerifyingKey {
-    G1Point<pm::BlsCurve> one_g1;
-    Bls12Pairing::G2 one_g2, x_g2, z_g2;
+// VerifyingKey (data_structures.rs:38-52) with PairingVK (:25-35), per pairing engine: BLS12-381 (the reference's,
+// Cargo.toml:35) and BN254 (BASELINE.json configs[4]).
+template <class C>
+struct VerifyingKeyT {
+    typedef typename PairingOf<C>::type Pairing;
+    G1Point<C> one_g1;
+    typename Pairing::G2 one_g2, x_g2, z_g2;
     uint64_t n = 0, m0 = 0, sigma = 0;
-    pm::Fp<pm::BlsFrP> omega;
+    pm::Fp<typename C::FrP> omega;
 };
+typedef VerifyingKeyT<pm::BlsCurve> VerifyingKey;   // the wire format (wire.hpp) is the BLS12-381 one
 
 template <class C, class T>
 class Polymath {
@@ -319,22 +322,21 @@ public:
     }
 
     // generator.rs:139-157: the verifying key of a proving key made from trapdoors (x, z)
-    template <class CC = C>
-    static typename std::enable_if<CC::ID == 0, VerifyingKey>::type make_vk(const ProvingKey<C> &pk, const Fr &x_trapdoor, const Fr &z_trapdoor) {
-        VerifyingKey vk;
+    typedef typename PairingOf<C>::type Pairing;
+    static VerifyingKeyT<C> make_vk(const ProvingKey<C> &pk, const Fr &x_trapdoor, const Fr &z_trapdoor) {
+        VerifyingKeyT<C> vk;
         for (int i = 0; i < C::FqP::N; ++i) { vk.one_g1.p.x.l[i] = C::GX_MONT[i]; vk.one_g1.p.y.l[i] = C::GY_MONT[i]; }
         vk.one_g1.inf = false;
-        vk.one_g2 = Bls12Pairing::g2_generator();
+        vk.one_g2 = Pairing::g2_generator();
         Fr xc = pm::from_mont<typename C::FrP>(x_trapdoor), zc = pm::from_mont<typename C::FrP>(z_trapdoor);
-        vk.x_g2 = Bls12Pairing::g2_mul(vk.one_g2, xc.l, 8);
-        vk.z_g2 = Bls12Pairing::g2_mul(vk.one_g2, zc.l, 8);
+        vk.x_g2 = Pairing::g2_mul(vk.one_g2, xc.l, 8);
+        vk.z_g2 = Pairing::g2_mul(vk.one_g2, zc.l, 8);
         vk.n = pk.n; vk.m0 = pk.m0; vk.sigma = pk.sigma; vk.omega = pk.omega;
         return vk;
     }
 
     // verify (lib.rs:80-90) -> verify_proof (verifier.rs:19-62).  `public_inputs` WITHOUT the leading one (:26).
-    template <class CC = C>
-    static typename std::enable_if<CC::ID == 0, bool>::type verify(const VerifyingKey &vk, const std::vector<Fr> &public_inputs, const Proof<C> &proof) {
+    static bool verify(const VerifyingKeyT<C> &vk, const std::vector<Fr> &public_inputs, const Proof<C> &proof) {
         typedef pm::XYZZ<C> J;
         T t("polymath");                                                                   // :24
         std::vector<Fr> pub{Fr::one()};
@@ -365,11 +367,11 @@ public:
         lhs = pm::xyzz_add<C>(lhs, smul(proof.c_g1, x2));
         lhs = pm::xyzz_add<C>(lhs, smul(vk.one_g1, F::neg(F::add(proof.a_at_x1, F::mul(x2, c_at_x1)))));
         Fr x1c = pm::from_mont<typename C::FrP>(x1);
-        Bls12Pairing::G2 x_minus_x1 = Bls12Pairing::g2_add(vk.x_g2, Bls12Pairing::g2_neg(Bls12Pairing::g2_mul(vk.one_g2, x1c.l, 8)));   // :48
+        typename Pairing::G2 x_minus_x1 = Pairing::g2_add(vk.x_g2, Pairing::g2_neg(Pairing::g2_mul(vk.one_g2, x1c.l, 8)));   // :48
         pm::Affine<C> lhs_aff = pm::xyzz_to_affine<C>(lhs), neg_d = proof.d_g1.p;
         neg_d.y = pm::neg<typename C::FqP>(neg_d.y);                                        // proof.d_g1 * (-1)  :53
-        std::vector<Bls12Pairing::Pair> pairs{{lhs_aff, lhs.is_identity(), vk.z_g2}, {neg_d, proof.d_g1.inf, x_minus_x1}};
-        return Bls12Pairing::product_is_one(pairs);                                        // :50-61
+        std::vector<typename Pairing::Pair> pairs{{lhs_aff, lhs.is_identity(), vk.z_g2}, {neg_d, proof.d_g1.inf, x_minus_x1}};
+        return Pairing::product_is_one(pairs);                                             // :50-61
     }
 
     // common.rs:21-30

@@ -307,6 +307,16 @@ ProvingKey<C> pk_load(Context &ctx, const WireKey<C> &k, int shard_rank = 0, int
     ProvingKey<C> pk;
     int st = pm_pk_load(ctx.h, C::ID, k.vk.n, k.m0, k.mw, k.nr, k.vk.sigma, &va, &vb, &vc, arr, shard_rank, shard_count, &pk.h);
     if (st) throw PolymathError(0, st, std::string("pm_pk_load: ") + pm_last_error(ctx.h));
+    // the host mirror hashes and evaluates pi(x1) with the vk's n / m0 / omega while the device derives its own from the
+    // SAP header: a file whose two halves disagree would silently produce invalid proofs -- reject it here
+    uint64_t dn = 0, dm0 = 0, dsigma = 0, lens[PM_NUM_BASE_VECS];
+    pm::Fp<typename C::FrP> domega;
+    pm_pk_info(pk.h, &dn, &dm0, &dsigma, (uint64_t *)domega.l, lens);
+    if (k.vk.m0 != k.m0 || dm0 != k.m0) throw WireError("vk.m0 disagrees with the SAP matrices' m0");
+    if (dn != k.vk.n || dsigma != k.vk.sigma) throw WireError("vk.n / vk.sigma disagree with the domain of the SAP matrices");
+    if (!domega.eq(k.vk.omega)) throw WireError("vk.omega is not the generator of the size-n domain");
+    for (int v = 0; v < PM_NUM_BASE_VECS; ++v)
+        if (k.vec[v].size() != lens[v]) throw WireError("a base vector's length does not match the key's shape");
     pk.n = k.vk.n; pk.m0 = k.vk.m0; pk.sigma = k.vk.sigma; pk.omega = k.vk.omega;
     return pk;
 }

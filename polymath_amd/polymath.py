@@ -110,6 +110,20 @@ class R1CS:
         self.m0, self.mw, self.nr, self.a, self.b, self.c = m0, mw, len(a), a, b, c
 
 
+class LimbCircuit:
+    """An R1CS plus assignment held as limb arrays (api.CsrArrays + Montgomery numpy arrays) instead of Python
+    integers: what circuits.synthetic_r1cs_native returns -- the 2^22 / 2^24-gate configurations never pass through
+    Python big integers.  Accepted by Polymath.setup / prove_native / prove_limbs wherever a circuit is."""
+
+    def __init__(self, field, m0, mw, nr, csrs, inst_limbs, wit_limbs):
+        self.field, self.m0, self.mw, self.nr, self.csrs = field, m0, mw, nr, csrs
+        self.inst_limbs, self.wit_limbs = inst_limbs, wit_limbs
+
+    @property
+    def instance(self):
+        return [self.field.fr_int(row) for row in self.inst_limbs]
+
+
 def _csr(field, rows):
     rowptr, cols, vals = [0], [], []
     for row in rows:
@@ -306,9 +320,12 @@ class Polymath:
 
     # circuit_specific_setup (lib.rs:63-70) -> generate_proving_key (generator.rs:24-167)
     def setup(self, circuit, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1):
-        r1cs = self._synthesize(circuit)[0]
         f = self.field
-        A, B, C = _csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)
+        if isinstance(circuit, LimbCircuit):
+            r1cs, (A, B, C) = circuit, circuit.csrs
+        else:
+            r1cs = self._synthesize(circuit)[0]
+            A, B, C = _csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)
         pk = api.ProvingKey.generate(self.ctx, self.curve, r1cs.m0, r1cs.mw, r1cs.nr, A, B, C,
                                      f.fr_limbs([x_trapdoor])[0], f.fr_limbs([z_trapdoor])[0], shard_rank, shard_count)
         pk.omega = f.fr_int(pk.omega_limbs)
@@ -325,6 +342,8 @@ class Polymath:
     def prove(self, pk, circuit, r_a, combine=None):
         """`combine(xy, inf) -> (xy, inf)` merges per-shard partial points across ranks (RCCL
         all-gather + pm_g1_sum, polymath_amd.distributed); None for a whole key."""
+        if isinstance(circuit, LimbCircuit):
+            return self.prove_limbs(pk, circuit.instance, circuit.inst_limbs, circuit.wit_limbs, r_a, combine)
         _, instance, witness = self._synthesize(circuit)
         f = self.field
         x = f.fr_limbs(instance)

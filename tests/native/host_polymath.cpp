@@ -20,25 +20,29 @@ struct SplitMix64 {
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         return z ^ (z >> 31);
     }
-    Fr fr() {   // 4 draws, limb 0 first, masked to 255 bits, rejection; canonical value -> Montgomery
+    template <class CC>
+    typename FrOps<CC>::Fr fr_of() {   // 4 draws, limb 0 first, masked to the field's bit length, rejection; canonical value -> Montgomery
         for (;;) {
             uint64_t l[4];
             for (int i = 0; i < 4; ++i) l[i] = next();
-            l[3] &= (1ull << 63) - 1;
+            l[3] &= (1ull << (CC::FrP::BITS - 192)) - 1;
             uint8_t buf[64] = {0};
             memcpy(buf, l, 32);
-            Fr out;
-            if (F::from_random_bytes(buf, &out)) return out;
+            typename FrOps<CC>::Fr out;
+            if (FrOps<CC>::from_random_bytes(buf, &out)) return out;
         }
     }
+    Fr fr() { return fr_of<Curve>(); }
 };
 
-struct DummyCircuit {   // tests/dummy.rs:20-35
-    Fr a, b;
-    void generate_constraints(ConstraintSystem<Curve> &cs) const {
+template <class CC>
+struct DummyCircuitT {   // tests/dummy.rs:20-35
+    typename FrOps<CC>::Fr a, b;
+    void generate_constraints(ConstraintSystem<CC> &cs) const {
+        typedef typename FrOps<CC>::Fr FrC;
         Variable va = cs.new_witness_variable(a), vb = cs.new_witness_variable(b);
-        Variable vc = cs.new_input_variable(F::mul(a, b));
-        cs.enforce_constraint({{Fr::one(), va}}, {{Fr::one(), vb}}, {{Fr::one(), vc}});
+        Variable vc = cs.new_input_variable(FrOps<CC>::mul(a, b));
+        cs.enforce_constraint({{FrC::one(), va}}, {{FrC::one(), vb}}, {{FrC::one(), vc}});
     }
 };
 
@@ -64,35 +68,38 @@ struct MiMCDemo {       // tests/mimc.rs:66-143
     }
 };
 
-template <class T>
-static void run_dummy(Context &ctx, const char *tname, uint64_t seed) {
+// CC = pairing engine: BLS12-381 (the reference's) or BN254 (BASELINE.json configs[4]); `tag` prefixes the printed lines
+template <class CC, class T>
+static void run_dummy(Context &ctx, const char *tag, const char *tname, uint64_t seed) {
+    typedef FrOps<CC> FC;
+    typedef typename FC::Fr FrC;
     SplitMix64 g{seed};
-    Fr a = g.fr(), b = g.fr(), x = g.fr(), z = g.fr();
-    Fr r_a[2] = {g.fr(), g.fr()};
-    Polymath<Curve, T> pm(ctx);
-    DummyCircuit c{a, b};
-    ProvingKey<Curve> pk = pm.setup(c, x, z);
-    Proof<Curve> proof = pm.prove(pk, c, r_a);
-    printf("dummy %s n=%llu %s\n", tname, (unsigned long long)pk.n, to_hex(proof.to_bytes()).c_str());
+    FrC a = g.fr_of<CC>(), b = g.fr_of<CC>(), x = g.fr_of<CC>(), z = g.fr_of<CC>();
+    FrC r_a[2] = {g.fr_of<CC>(), g.fr_of<CC>()};
+    Polymath<CC, T> pm(ctx);
+    DummyCircuitT<CC> c{a, b};
+    ProvingKey<CC> pk = pm.setup(c, x, z);
+    Proof<CC> proof = pm.prove(pk, c, r_a);
+    printf("dummy%s %s n=%llu %s\n", tag, tname, (unsigned long long)pk.n, to_hex(proof.to_bytes()).c_str());
     // tests/dummy.rs:69-72: assert!(Polymath::verify(&vk, &[product], &proof))
-    VerifyingKey vk = Polymath<Curve, T>::make_vk(pk, x, z);
-    std::vector<Fr> pub{F::mul(a, b)};
-    bool ok = Polymath<Curve, T>::verify(vk, pub, proof);
-    Proof<Curve> bad = proof;
-    bad.a_at_x1 = F::add(bad.a_at_x1, Fr::one());
-    bool ok_bad = Polymath<Curve, T>::verify(vk, pub, bad);
-    pub[0] = F::add(pub[0], Fr::one());
-    bool ok_wrong_input = Polymath<Curve, T>::verify(vk, pub, proof);
-    printf("verify %s accept=%d tampered=%d wrong_input=%d\n", tname, ok, ok_bad, ok_wrong_input);
+    VerifyingKeyT<CC> vk = Polymath<CC, T>::make_vk(pk, x, z);
+    std::vector<FrC> pub{FC::mul(a, b)};
+    bool ok = Polymath<CC, T>::verify(vk, pub, proof);
+    Proof<CC> bad = proof;
+    bad.a_at_x1 = FC::add(bad.a_at_x1, FrC::one());
+    bool ok_bad = Polymath<CC, T>::verify(vk, pub, bad);
+    pub[0] = FC::add(pub[0], FrC::one());
+    bool ok_wrong_input = Polymath<CC, T>::verify(vk, pub, proof);
+    printf("verify%s %s accept=%d tampered=%d wrong_input=%d\n", tag, tname, ok, ok_bad, ok_wrong_input);
 }
 
 int main(int argc, char **argv) {
     int rounds = argc > 1 ? atoi(argv[1]) : 322, samples = argc > 2 ? atoi(argv[2]) : 3;
     try {
         Context ctx(0);
-        run_dummy<MerlinFieldTranscript<Curve>>(ctx, "merlin", 101);
-        run_dummy<Keccak256Transcript<Curve>>(ctx, "keccak256", 102);
-        run_dummy<Blake3Transcript<Curve>>(ctx, "blake3", 103);
+        run_dummy<Curve, MerlinFieldTranscript<Curve>>(ctx, "", "merlin", 101);
+        run_dummy<Curve, Keccak256Transcript<Curve>>(ctx, "", "keccak256", 102);
+        run_dummy<Curve, Blake3Transcript<Curve>>(ctx, "", "blake3", 103);
         // tests/mimc.rs: constants, setup once, then SAMPLES x (random preimage, prove)
         SplitMix64 g{322};
         std::vector<Fr> constants(rounds);
@@ -126,6 +133,10 @@ int main(int argc, char **argv) {
         } catch (const PolymathError &e) {
             printf("bad-witness rejected phase=%d status=%d\n", e.phase, e.status);
         }
+        // the same dummy test on the second pairing engine (BN254: 254-bit limb path, its own optimal-ate verifier)
+        run_dummy<pm::BnCurve, MerlinFieldTranscript<pm::BnCurve>>(ctx, "_bn254", "merlin", 201);
+        run_dummy<pm::BnCurve, Keccak256Transcript<pm::BnCurve>>(ctx, "_bn254", "keccak256", 202);
+        run_dummy<pm::BnCurve, Blake3Transcript<pm::BnCurve>>(ctx, "_bn254", "blake3", 203);
     } catch (const std::exception &e) {
         printf("ERROR %s\n", e.what());
         return 1;

@@ -45,6 +45,35 @@ int main() {
         B::G2 wrong = B::g2_mul(g2, kab, 2);
         if (B::product_is_one({{aP, false, bQ}, {negP, false, wrong}})) { fails++; printf("pairing false accept\n"); }
     }
+    {   // the same on BN254 (optimal ate: 6x + 2 loop and the two Frobenius steps)
+        typedef Bn254Pairing B;
+        typedef pm::BnCurve CC;
+        B::G2 g2 = B::g2_generator();
+        if (!B::g2_on_curve(g2)) { fails++; printf("BN254 G2 generator off the twist\n"); }
+        uint32_t rm1[8];
+        for (int i = 0; i < 8; ++i) rm1[i] = pm::BnFrP::MOD[i];
+        rm1[0] -= 1;                                                     // r - 1 (r is odd)
+        B::G2 m = B::g2_mul(g2, rm1, 8), ng = B::g2_neg(g2);
+        if (m.inf || !m.x.eq(ng.x) || !m.y.eq(ng.y)) { fails++; printf("BN254 G2 generator order\n"); }
+        pm::Affine<CC> g1;
+        for (int i = 0; i < 8; ++i) { g1.x.l[i] = CC::GX_MONT[i]; g1.y.l[i] = CC::GY_MONT[i]; }
+        auto g1mul = [&](uint32_t k) {
+            pm::XYZZ<CC> acc = pm::XYZZ<CC>::identity();
+            for (int b = 31; b >= 0; --b) { acc = pm::xyzz_dbl<CC>(acc); if ((k >> b) & 1) pm::xyzz_madd<CC>(acc, g1, false); }
+            return pm::xyzz_to_affine<CC>(acc);
+        };
+        uint32_t a = 0x1234567u, b = 0x89abcdu;
+        uint64_t ab = (uint64_t)a * b;
+        uint32_t kb[2] = {b, 0}, kab[2] = {(uint32_t)ab, (uint32_t)(ab >> 32)};
+        pm::Affine<CC> aP = g1mul(a), negP = g1;
+        negP.y = pm::neg<pm::BnFqP>(negP.y);
+        B::G2 bQ = B::g2_mul(g2, kb, 1), abQ = B::g2_mul(g2, kab, 2);
+        if (!B::product_is_one({{aP, false, bQ}, {negP, false, abQ}})) { fails++; printf("BN254 pairing bilinearity\n"); }
+        kab[0] += 1;
+        B::G2 wrong = B::g2_mul(g2, kab, 2);
+        if (B::product_is_one({{aP, false, bQ}, {negP, false, wrong}})) { fails++; printf("BN254 pairing false accept\n"); }
+        if (B::product_is_one({{g1, false, g2}})) { fails++; printf("BN254 pairing degenerate\n"); }
+    }
     printf("host selftest: %d failures\n", fails);
     return fails ? 1 : 0;
 }

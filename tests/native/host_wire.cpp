@@ -51,6 +51,16 @@ int main(int argc, char **argv) {
         printf("proof %s\n", to_hex(proof.to_bytes()).c_str());
         WireKey<C> back = pk_export<C>(ctx, pk, key.vk, key.mw, key.nr, key.a, key.b, key.c);
         printf("export identical=%d\n", (int)(back.to_bytes() == data));
+        // a key file whose vk disagrees with its SAP header must be rejected, not silently produce invalid proofs
+        int rejected = 0;
+        for (int which = 0; which < 3; ++which) {
+            WireKey<C> bad = key;
+            if (which == 0) bad.vk.m0 += 1;
+            if (which == 1) bad.vk.omega = FrOps<C>::mul(bad.vk.omega, bad.vk.omega);
+            if (which == 2) bad.vec[PM_X_POWERS].push_back(bad.vec[PM_X_POWERS].back());
+            try { (void)pk_load<C>(ctx, bad); } catch (const WireError &) { ++rejected; }
+        }
+        printf("inconsistent keys rejected=%d\n", rejected);
     } catch (const std::exception &e) {
         printf("error %s\n", e.what());
         return 1;

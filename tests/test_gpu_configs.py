@@ -1,0 +1,202 @@
+"""GPU tests of the BASELINE.json configurations at their full sizes and of the code paths that only exist at size
+(VERDICT r1 items 1-2): whole-proof bit-exactness against oracle/cpp at 2^16 and 2^18 gates (3-pass NTT, 12/13-window
+tables, 3-level sort), 2^22 and 2^24 gates on one GPU, BN254 at 2^20, the piece-split MSM, BN254 NTT above 2^17.
+Everything goes through the C ABI; integer arithmetic, exact equality."""
+import numpy as np
+import pytest
+
+from helpers import rand_fr_limbs
+from oracle import driver as DR
+from oracle.pyref import circuits as CI, transcripts as T
+from oracle.pyref.fields import CURVES
+
+pytestmark = pytest.mark.gpu
+
+CURVE_LIST = ["bls12_381", "bn254"]
+
+
+@pytest.fixture(scope="module")
+def api():
+    from polymath_amd import api as _api
+    return _api
+
+
+def _vk(curve, pk, x, z):
+    from oracle.pyref import pairing as PA
+    return PA.ENGINES[curve].make_vk_from_trapdoors(pk.n, 2, pk.sigma, pk.omega, x, z)
+
+
+def _accepts(curve, vk, proof, public_inputs, tname="merlin"):
+    from oracle.pyref import pairing as PA, protocol as PR
+    c = CURVES[curve]
+    return PR.verify_proof(c, vk, proof, public_inputs, T.make_transcripts(c)[tname], PA.ENGINES[curve].pairing_check)
+
+
+# ------------------------------------------------- whole proofs, bit-exact against the CPU restatement, at size
+@pytest.mark.parametrize("curve", CURVE_LIST)
+@pytest.mark.parametrize("log_nr,tables", [(16, "1"), (16, "0"), (18, "1"), (18, "0")])
+def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, log_nr, tables, monkeypatch):
+    """2^16-100 and 2^18-100 synthetic gates (n = 2^17 / 2^19: three-pass NTT, per-MSM window tables with 12-13 windows,
+    three-level sort, two-level bucket reduction), both curves, with the key's tables and with PM_TABLES=0.
+    The CPU restatement's key is seeded with the GPU's exported bases (their parity is tested at mid size: the CPU
+    setup would take minutes here); proof, challenges and all 8 intermediate vectors must be identical."""
+    import os
+    monkeypatch.setenv("PM_TABLES", tables)
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    c = CURVES[curve]
+    nr = (1 << log_nr) - 100
+    q, inst, wit = CI.synthetic_r1cs(c, nr)
+    g = CI.SplitMix64(1600 + log_nr)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    lc = PC.synthetic_r1cs_native(curve, nr)                      # the library's generator draws the same circuit
+    assert np.array_equal(lc.wit_limbs, oracle.fr_to_mont_limbs(curve, wit))
+    pm = Polymath(curve, "merlin", ctx=gpu_ctx)
+    gpk = pm.setup(lc, x, z)
+    assert gpk.msm_plan(2)[3] == (tables == "1")
+    threads = os.cpu_count() or 8
+    opk = oracle.OraclePk(curve, q, None, None, threads)
+    for i in range(6):
+        opk.import_bases(i, gpk.export_bases(i))
+    omega = oracle.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+    assert omega == gpk.omega
+    TR = T.make_transcripts(c)
+    tr_o, tr_g = {}, {}
+    po = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_o)
+    pg = DR.prove(gpk, gpk.n, gpk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_g)
+    assert pg == po and tr_g == tr_o
+    cap = 10 * gpk.n + 64
+    for which in range(8):
+        a, b = gpk.tap(which, cap), opk.tap(which, cap)
+        k = min(len(a), len(b))
+        assert k > 0 and np.array_equal(a[:k], b[:k]) and not a[k:].any() and not b[k:].any(), which
+    # the one-call native path (C++ glue inside the library) returns the same bytes
+    from oracle.pyref import serialize as SE
+    native = pm.prove_native(gpk, lc.inst_limbs, lc.wit_limbs, r_a)
+    assert native == SE.ser_proof(c, po)
+    gpk.free()
+
+
+# ------------------------------------------------------------------ full-size configurations on one GPU
+def _full_size_config(curve, log_nr, seed):
+    """setup -> prove -> the pairing verifier accepts (tests/mimc.rs:214) and rejects a tampered proof; an unsatisfied
+    witness returns PM_ERR_REMAINDER_NONZERO (prover.rs:108); the native one-call path gives the same bytes."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath, PolymathProverError
+    c = CURVES[curve]
+    nr = (1 << log_nr) - 100
+    lc = PC.synthetic_r1cs_native(curve, nr)
+    g = PC.SplitMix64(seed)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    pm = Polymath(curve, "merlin", device=0)
+    pk = pm.setup(lc, x, z)
+    assert pk.n == 1 << (log_nr + 1)
+    inst = lc.instance
+    proof_obj = pm.prove(pk, lc, r_a)
+    proof = proof_obj.as_dict()
+    vk = _vk(curve, pk, x, z)
+    assert _accepts(curve, vk, proof, inst[1:])
+    assert not _accepts(curve, vk, dict(proof, a_at_x1=(proof["a_at_x1"] + 1) % c.r), inst[1:])
+    assert not _accepts(curve, vk, proof, [(inst[1] + 1) % c.r])
+    assert pm.prove_native(pk, lc.inst_limbs, lc.wit_limbs, r_a) == proof_obj.to_bytes()
+    bad = lc.wit_limbs.copy()
+    bad[12345, 0] ^= np.uint64(1)
+    with pytest.raises(PolymathProverError) as e:
+        pm.prove_limbs(pk, inst, lc.inst_limbs, bad, r_a)
+    assert (e.value.phase, e.value.status) == (1, 4)
+    plans = [pk.msm_plan(k) for k in range(3)]
+    pk.free()
+    pm.ctx.close()
+    return plans
+
+
+def test_config_2p22_one_gpu():
+    """BASELINE configs[2] circuit (2^22-100 gates, n = 2^23, 117 M MSM pairs) on ONE GPU."""
+    plans = _full_size_config("bls12_381", 22, 0x2222)
+    assert plans[2][0] == 10 * (1 << 23) + 22
+
+
+def test_config_2p24_one_gpu_piece_split():
+    """BASELINE configs[3] circuit (2^24-100 gates, n = 2^25, 470 M MSM pairs) on ONE GPU: nine-stage NTT passes, and the
+    335 M-pair quotient MSM runs in > 2^27-pair pieces (msm.hip: msm_run) on the per-window pipeline."""
+    plans = _full_size_config("bls12_381", 24, 0x2424)
+    assert plans[2][0] == 10 * (1 << 25) + 22 and plans[2][0] > (1 << 27)
+
+
+def test_config_bn254_2p20():
+    """BASELINE configs[4]: BN254 at 2^20-100 gates, accepted by the BN254 optimal-ate pairing verifier."""
+    plans = _full_size_config("bn254", 20, 0xB254)
+    assert all(p[3] for p in plans)                                  # all three MSMs on window tables
+
+
+# ---------------------------------------------------------------------------- piece-split MSM at small size
+@pytest.mark.parametrize("curve", CURVE_LIST)
+@pytest.mark.parametrize("tables", [False, True])
+def test_msm_piece_split_paths_vs_oracle(gpu_ctx, oracle, api, curve, tables, monkeypatch):
+    """PM_MSM_MAX_PIECE_LOG=18: a 2^20-pair (and a ragged 2^20 - 12345) MSM runs as 4 pieces summed on the host, on the
+    per-window pipeline and on the window-table pipeline (tb.base_index += off); equal to the one-piece result and to
+    the CPU restatement."""
+    n = 1 << 20
+    bases = api.Bases.multiples(gpu_ctx, curve, n)
+    if tables:
+        bases.precompute()
+    sc = rand_fr_limbs(curve, n, 4242)
+    whole, inf0 = bases.msm(sc)
+    ref, _ = oracle.msm(curve, bases.download(), sc, 16)
+    assert inf0 == 0 and np.array_equal(whole, ref)
+    monkeypatch.setenv("PM_MSM_MAX_PIECE_LOG", "18")
+    split, inf1 = bases.msm(sc)
+    assert inf1 == 0 and np.array_equal(split, whole)
+    m = n - 12345
+    ragged, _ = bases.msm(sc[:m], offset=777)
+    monkeypatch.delenv("PM_MSM_MAX_PIECE_LOG")
+    one, _ = bases.msm(sc[:m], offset=777)
+    assert np.array_equal(ragged, one)
+    bases.free()
+
+
+def test_prove_with_piece_split_msms_equals_whole(gpu_ctx, oracle, api, monkeypatch):
+    """A whole proof (5000 gates) whose three merged MSMs are forced through 2^12-pair pieces -- with tables for all
+    three, and with PM_TABLES=0 -- gives the same bytes as the unsplit run."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    curve = "bls12_381"
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, 5000)
+    pm = Polymath(curve, "keccak256", ctx=gpu_ctx)
+    for tables in ("1", "0"):
+        monkeypatch.setenv("PM_TABLES", tables)
+        pk = pm.setup(lc, 0xABCDEF, 0x123457)
+        ref = pm.prove_native(pk, lc.inst_limbs, lc.wit_limbs, [5, 7])
+        monkeypatch.setenv("PM_MSM_MAX_PIECE_LOG", "12")
+        assert pm.prove_native(pk, lc.inst_limbs, lc.wit_limbs, [5, 7]) == ref
+        monkeypatch.delenv("PM_MSM_MAX_PIECE_LOG")
+        pk.free()
+
+
+# ------------------------------------------------------------------------------------ BN254 NTT at size
+def test_ntt_bn254_2p21_vs_oracle_and_2p24_roundtrip(gpu_ctx, oracle):
+    """BN254 NTT above 2^17: 2^21 forward and inverse against the CPU restatement; 2^24 (three
+    8-stage passes) inverse(forward(x)) == x on canonical inputs, and the first 8 outputs against a direct DFT."""
+    import os
+    curve = "bn254"
+    threads = min(os.cpu_count() or 8, 64)
+    a = rand_fr_limbs(curve, 1 << 21, 2121)
+    fwd = gpu_ctx.ntt(curve, a, 21, False)
+    assert np.array_equal(fwd, oracle.ntt(curve, a, 21, False, threads))
+    inv = gpu_ctx.ntt(curve, a, 21, True)
+    assert np.array_equal(inv, oracle.ntt(curve, a, 21, True, threads))
+    b = rand_fr_limbs(curve, 1 << 24, 2424)
+    fb = gpu_ctx.ntt(curve, b, 24, False)
+    assert np.array_equal(gpu_ctx.ntt(curve, fb, 24, True), b)
+    # linearity spot check at 2^24: NTT(e_j) is the geometric sequence omega^(j k); compare 4 entries of fb with the
+    # direct sum over a sparse input instead of a full CPU transform
+    c = CURVES[curve]
+    sparse = np.zeros((1 << 24, 4), dtype=np.uint64)
+    idx = [0, 1, 12345, (1 << 24) - 1]
+    vals = [3, 5, 7, 11]
+    sparse[idx] = oracle.fr_to_mont_limbs(curve, vals)
+    fs = oracle.fr_from_mont_limbs(curve, gpu_ctx.ntt(curve, sparse, 24, False)[[0, 1, 2, 77777]])
+    omega = pow(c.two_adic_root, 1 << (c.two_adicity - 24), c.r)
+    for k, got in zip([0, 1, 2, 77777], fs):
+        assert got == sum(v * pow(omega, j * k, c.r) for j, v in zip(idx, vals)) % c.r

@@ -38,10 +38,26 @@ def test_cpp_dummy_and_mimc_match_oracle(tmp_path, oracle):
     assert out.returncode == 0, out.stdout + out.stderr
     all_lines = out.stdout.strip().splitlines()
     verdicts = [l for l in all_lines if l.startswith("verify")]
-    # Polymath::verify (verifier.rs:19-62) in C++ with its own pairing: accepts, rejects tampering / wrong inputs
+    # Polymath::verify (verifier.rs:19-62) in C++ with its own pairings (BLS12-381, then BN254): accepts, rejects tampering / wrong inputs
     assert verdicts == ["verify merlin accept=1 tampered=0 wrong_input=0", "verify keccak256 accept=1 tampered=0 wrong_input=0",
-                        "verify blake3 accept=1 tampered=0 wrong_input=0", "verify mimc accept=1"], verdicts
-    lines = [l for l in all_lines if not l.startswith("verify")]
+                        "verify blake3 accept=1 tampered=0 wrong_input=0", "verify mimc accept=1",
+                        "verify_bn254 merlin accept=1 tampered=0 wrong_input=0", "verify_bn254 keccak256 accept=1 tampered=0 wrong_input=0",
+                        "verify_bn254 blake3 accept=1 tampered=0 wrong_input=0"], verdicts
+    bn_lines = [l for l in all_lines if l.startswith("dummy_bn254")]
+    lines = [l for l in all_lines if not l.startswith("verify") and not l.startswith("dummy_bn254")]
+    # tests/dummy.rs on BN254: same proof bytes as the CPU oracle
+    from oracle.pyref.fields import BN254 as cb
+    TRB = T.make_transcripts(cb)
+    assert len(bn_lines) == 3
+    for line, (tname, seed) in zip(bn_lines, [("merlin", 201), ("keccak256", 202), ("blake3", 203)]):
+        g = CI.SplitMix64(seed)
+        a, b, x, z, r_a = g.fr(cb.r), g.fr(cb.r), g.fr(cb.r), g.fr(cb.r), [g.fr(cb.r), g.fr(cb.r)]
+        q, inst, wit = CI.dummy_circuit(cb, a, b)
+        opk = oracle.OraclePk("bn254", q, x, z, 1)
+        omega = oracle.fr_from_mont_limbs("bn254", opk.omega_limbs)[0]
+        ref = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, TRB[tname])
+        kind, name, n, hx = line.split()
+        assert (kind, name, n) == ("dummy_bn254", tname, "n=%d" % opk.n) and hx == SE.ser_proof(cb, ref).hex()
     TR = T.make_transcripts(c)
     # tests/dummy.rs
     for line, (tname, seed) in zip(lines[:3], [("merlin", 101), ("keccak256", 102), ("blake3", 103)]):

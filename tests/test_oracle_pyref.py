@@ -49,6 +49,40 @@ def test_pairing_bilinear():
     assert not PA.pairing_product_is_one([(P, Q), (g1_neg(c, g1_mul(c, c.g1, a * b + 1)), BLS12_381_G2)])
 
 
+def test_pairing_bilinear_bn254():
+    """BN254 optimal-ate pairing (BASELINE configs[4] acceptance oracle): curve parameters, G2 generator on the twist
+    and of order r, bilinear, non-degenerate."""
+    from oracle.pyref import fields as F
+    c, E, G2 = BN254, PA.ENGINES["bn254"], F.BN254_G2
+    x = F.BN254_X
+    assert 36 * x**4 + 36 * x**3 + 24 * x**2 + 6 * x + 1 == c.p and 36 * x**4 + 36 * x**3 + 18 * x**2 + 6 * x + 1 == c.r
+    assert E.g2_is_on_curve(G2) and E.g2_mul(G2, c.r - 1) == E.g2_neg(G2)
+    a, b = 0x1234567, 0x89ABCDEF01
+    P, Q = g1_mul(c, c.g1, a), E.g2_mul(G2, b)
+    assert E.pairing_product_is_one([(P, Q), (g1_neg(c, g1_mul(c, c.g1, a * b)), G2)])
+    assert not E.pairing_product_is_one([(P, Q), (g1_neg(c, g1_mul(c, c.g1, a * b + 1)), G2)])
+    assert not E.pairing_product_is_one([(c.g1, G2)])                      # e(G1, G2) != 1
+    assert E.pairing_product_is_one([(c.g1, G2), (g1_neg(c, c.g1), G2)])
+
+
+def test_bn254_golden_proofs_pass_the_pairing_verifier():
+    """Every committed BN254 fixture proof (tests/golden/proofs_bn254.json, 3 circuits x 3 transcripts) is accepted by
+    verify_proof (verifier.rs:19-62) over the BN254 pairing; tampering and a wrong public input are rejected."""
+    import json, os
+    c, E = BN254, PA.ENGINES["bn254"]
+    TR = T.make_transcripts(c)
+    I = lambda s: int(s, 16)
+    PT = lambda p: None if p is None else (I(p[0]), I(p[1]))
+    for fx in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "proofs_bn254.json"))):
+        vk = E.make_vk_from_trapdoors(fx["n"], fx["r1cs"]["m0"], fx["sigma"], I(fx["omega"]), I(fx["x_trapdoor"]), I(fx["z_trapdoor"]))
+        inst = [I(v) for v in fx["instance"]]
+        for tname, ref in fx["proofs"].items():
+            proof = dict(a_g1=PT(ref["a_g1"]), c_g1=PT(ref["c_g1"]), a_at_x1=I(ref["a_at_x1"]), d_g1=PT(ref["d_g1"]))
+            assert PR.verify_proof(c, vk, proof, inst[1:], TR[tname], E.pairing_check), (fx["name"], tname)
+        assert not PR.verify_proof(c, vk, dict(proof, a_at_x1=(proof["a_at_x1"] + 1) % c.r), inst[1:], TR[tname], E.pairing_check)
+        assert not PR.verify_proof(c, vk, proof, [(v + 1) % c.r for v in inst[1:]], TR[tname], E.pairing_check)
+
+
 def test_dummy_prove_verify_all_transcripts():
     """tests/dummy.rs:75-80 restated: setup -> prove -> verify accepts, for the three transcripts;
     plus the negative cases the reference lacks."""

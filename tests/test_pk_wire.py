@@ -153,3 +153,4 @@ def test_cpp_loaded_key_proves_and_exports(tmp_path):
         lines = out.stdout.strip().splitlines()
         assert lines[0] == "proof " + e["proofs"]["merlin"]["bytes"], name
         assert lines[1] == "export identical=1", name
+        assert lines[2] == "inconsistent keys rejected=3", name

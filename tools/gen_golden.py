@@ -111,9 +111,10 @@ def proof_fixtures():
 
 
 def proof_fixtures_bn254():
-    """BN254 (BASELINE configs[4]: second curve, 254-bit limb path): same shape as proofs.json.  pyref has no BN254
-    pairing, so these are pinned by the prover's own asserts (rem == 0 twice, degree bounds) and by the two
-    independent restatements agreeing (tests/test_oracle_cpp.py), not by a verifier."""
+    """BN254 (BASELINE configs[4]: second curve, 254-bit limb path): same shape as proofs.json; every proof is checked
+    by the verifier (verifier.rs:19-62) over the BN254 optimal-ate pairing of oracle/pyref/pairing.py before it is
+    written, and a tampered one must be rejected."""
+    E = PA.ENGINES["bn254"]
     c = CURVES["bn254"]
     TR = T.make_transcripts(c)
     g = CI.SplitMix64(0xB254)
@@ -136,9 +137,12 @@ def proof_fixtures_bn254():
             entry["proofs"][tname] = dict(a_g1=PT(proof["a_g1"]), c_g1=PT(proof["c_g1"]), a_at_x1=H(proof["a_at_x1"]),
                                           d_g1=PT(proof["d_g1"]), x1=H(tr["x1"]), x2=H(tr["x2"]),
                                           bytes=SE.ser_proof(c, proof).hex())
+            vk = E.make_vk(pk)
+            assert PR.verify_proof(c, vk, proof, inst[1:], TR[tname], E.pairing_check), (name, tname)
+            assert not PR.verify_proof(c, vk, dict(proof, a_at_x1=(proof["a_at_x1"] + 1) % c.r), inst[1:], TR[tname], E.pairing_check)
             if tname == "keccak256":
                 entry["trace"] = {k: [H(v) for v in tr[k]] for k in ["u_evals", "w_evals", "u", "w", "h", "wit_u", "z_tail", "quotient"]}
-        print("bn254 fixture", name, "n =", pk.n)
+        print("bn254 fixture", name, "n =", pk.n, "verified x3")
         out.append(entry)
     return out
 
