@@ -73,6 +73,15 @@ typedef enum pm_base_vec {
     PM_NUM_BASE_VECS = 6
 } pm_base_vec;
 
+/* How a key is spread over the ranks of a multi-GPU proof.
+ *   PM_SHARD_PAIRS : only the MSM pair ranges are sharded (contiguous 1/N slices); witness map, NTTs and scans are
+ *                    replicated on every rank (BASELINE.json configs[2]: "MSM buckets sharded").
+ *   PM_SHARD_VECTOR: the vector phases are sharded too (configs[3]: "NTT domain + MSM both 8-way partitioned"):
+ *                    evaluations cyclic, coefficients blocked (polymath_amd/host/layout.hpp), four-step NTT with one
+ *                    all-to-all per transform, scans exchange per-segment values; the ranks' contexts must be joined
+ *                    by a pm_comm (pm_ctx_set_comm).  Needs shard_count a power of two with shard_count^2 | n. */
+typedef enum pm_shard_layout { PM_SHARD_PAIRS = 0, PM_SHARD_VECTOR = 1 } pm_shard_layout;
+
 typedef struct pm_base_array {
     const void *points; /* host pointer, G1 affine-in convention above */
     size_t len;         /* number of points */
@@ -130,6 +139,19 @@ int pm_pk_load(pm_ctx *ctx, int curve, uint64_t n, uint64_t m0, uint64_t mw, uin
 int pm_pk_generate(pm_ctx *ctx, int curve, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a,
                    const pm_csr *b, const pm_csr *c, const uint64_t *x_trapdoor, const uint64_t *z_trapdoor,
                    int shard_rank, int shard_count, pm_pk **out);
+/* The same two with the shard layout chosen (pm_shard_layout); pm_pk_load / pm_pk_generate are layout PM_SHARD_PAIRS. */
+int pm_pk_load_sharded(pm_ctx *ctx, int curve, uint64_t n, uint64_t m0, uint64_t mw, uint64_t nr, uint64_t sigma,
+                       const pm_csr *a, const pm_csr *b, const pm_csr *c, const pm_base_array bases[PM_NUM_BASE_VECS],
+                       int shard_rank, int shard_count, int layout, pm_pk **out);
+int pm_pk_generate_sharded(pm_ctx *ctx, int curve, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a,
+                           const pm_csr *b, const pm_csr *c, const uint64_t *x_trapdoor, const uint64_t *z_trapdoor,
+                           int shard_rank, int shard_count, int layout, pm_pk **out);
+/* PM_SHARD_VECTOR index maps (polymath_amd/host/layout.hpp), host arithmetic only: out[p] = the global coefficient index
+ * (coefficients != 0) or evaluation row (coefficients == 0) of local position p < n / shard_count of rank shard_rank. */
+int pm_layout_indices(uint64_t n, int shard_count, int shard_rank, int coefficients, uint64_t *out);
+/* The resident pairs of merged MSM `which` on this key/shard, as ranges [cat_lo, cat_lo + count) of the logical base
+ * concatenation [uj_wj_lcs | x_powers_zh | x_powers | y_alpha | y_gamma | y_gamma_z], in device / scalar order. */
+int pm_pk_msm_pieces(const pm_pk *pk, int which, uint64_t *cat_lo, uint64_t *count, size_t capacity, size_t *n_pieces);
 int pm_pk_info(const pm_pk *pk, uint64_t *n, uint64_t *m0, uint64_t *sigma, uint64_t *omega /*Fr*/,
                uint64_t base_lens[PM_NUM_BASE_VECS]);
 /* How merged MSM `which` (0 = [a]_1: prover.rs:118,330-338; 1 = [c]_1: :121,340-357; 2 = [d]_1: :229) runs on
@@ -189,6 +211,39 @@ int pm_host_prove_sharded(pm_ctx *ctx, const pm_pk *pk, int transcript, const ui
 /* Host helper: Keccak-f[1600] on 25 little-endian lanes, shared by the host mirrors' Merlin / Keccak256
  * transcripts (the reference's transcripts are host code too: src/transcript/ *.rs). */
 void pm_host_keccak_f1600(uint64_t state[25]);
+
+/* ---- multi-GPU exchange layer (no reference counterpart: the reference is single-process CPU code) ------
+ * One pm_comm per rank.  The sharded prover needs two collectives: an all-to-all of equal DEVICE blocks (the transpose of
+ * the four-step NTT, prover.rs:239-243 / 315-328 split over ranks) and an all-gather of small HOST payloads (partial
+ * points, status flags, scan carries).  RCCL form: rank 0 calls pm_comm_rccl_unique_id and ships the 128 bytes to the
+ * other ranks by any means (the Rust host's own channel, torch.distributed's store, MPI ...); every rank then calls
+ * pm_comm_rccl_create (collective: ncclCommInitRank).  librccl is loaded at first use (dlopen): no link-time dependency. */
+typedef struct pm_comm pm_comm;
+int pm_comm_rccl_unique_id(void *out_128_bytes);
+int pm_comm_rccl_create(const void *unique_id_128_bytes, int rank, int world, int device, pm_comm **out);
+/* `world` ranks as threads of ONE process (one or several devices): rendezvous + device-to-device copies.  out[world]. */
+int pm_comm_local_create(int world, pm_comm **out);
+/* The host brings its own transport. */
+typedef struct pm_comm_ops {
+    void *user;
+    /* block p of d_send (bytes_per_peer each) goes to rank p; block p of d_recv comes from rank p; device pointers;
+     * must be ordered after the work already enqueued on hip_stream and complete (or be enqueued on it) on return */
+    int (*all_to_all)(void *user, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream);
+    /* host pointers; recv holds world x bytes, rank r's block at r * bytes */
+    int (*all_gather)(void *user, const void *send, void *recv, size_t bytes);
+} pm_comm_ops;
+int pm_comm_from_callbacks(const pm_comm_ops *ops, int rank, int world, pm_comm **out);
+void pm_comm_destroy(pm_comm *c);
+int pm_comm_rank(const pm_comm *c);
+int pm_comm_world(const pm_comm *c);
+const char *pm_comm_last_error(const pm_comm *c);
+int pm_comm_all_gather(pm_comm *c, const void *send, void *recv, size_t bytes);
+int pm_comm_all_to_all(pm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream);
+/* Sum over ranks of `count` partial G1 points, in place (all-gather + pm_g1_sum): the native pm_combine_fn. */
+int pm_comm_combine_points(pm_comm *c, int curve, int count, uint64_t *xy, int *inf);
+/* Join a context to its rank's communicator.  Required before proving on a PM_SHARD_VECTOR key; with it,
+ * pm_host_prove_sharded needs no `combine` callback either.  The context does not own the comm. */
+int pm_ctx_set_comm(pm_ctx *ctx, pm_comm *comm);
 
 /* Harness workload (no reference counterpart in src/; benches/bench.rs:38-61 is the reference's own): the synthetic
  * "random A*B=C gates" R1CS of BASELINE.json configs[1..4], generated natively with the same splitmix64

@@ -52,7 +52,12 @@ EXPORTS = [
     "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
     "pm_pk_info", "pm_pk_msm_plan", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3", "pm_host_prove", "pm_host_prove_sharded",
     "pm_prove_tap", "pm_host_keccak_f1600", "pm_synth_r1cs",
+    "pm_pk_load_sharded", "pm_pk_generate_sharded", "pm_layout_indices", "pm_pk_msm_pieces",
+    "pm_comm_rccl_unique_id", "pm_comm_rccl_create", "pm_comm_local_create", "pm_comm_from_callbacks", "pm_comm_destroy", "pm_comm_rank",
+    "pm_comm_world", "pm_comm_last_error", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
 ]
+SHARD_PAIRS, SHARD_VECTOR = 0, 1
+LAYOUTS = {"pairs": SHARD_PAIRS, "vector": SHARD_VECTOR, 0: 0, 1: 1}
 
 _lib = None
 
@@ -107,6 +112,26 @@ def load_library():
     L.pm_host_keccak_f1600.argtypes = [u64p]
     L.pm_host_keccak_f1600.restype = None
     L.pm_synth_r1cs.argtypes = [i, u64, u64, u64p, u32p, u64p, u32p, u64p, u32p, u64p, u64p]
+    L.pm_pk_load_sharded.argtypes = [vp, i, u64, u64, u64, u64, u64, ct.POINTER(PmCsr), ct.POINTER(PmCsr), ct.POINTER(PmCsr),
+                                     ct.POINTER(PmBaseArray), i, i, i, ct.POINTER(vp)]
+    L.pm_pk_generate_sharded.argtypes = [vp, i, u64, u64, u64, ct.POINTER(PmCsr), ct.POINTER(PmCsr), ct.POINTER(PmCsr), u64p,
+                                         u64p, i, i, i, ct.POINTER(vp)]
+    L.pm_layout_indices.argtypes = [u64, i, i, i, u64p]
+    L.pm_pk_msm_pieces.argtypes = [vp, i, u64p, u64p, sz, ct.POINTER(sz)]
+    L.pm_comm_rccl_unique_id.argtypes = [vp]
+    L.pm_comm_rccl_create.argtypes = [vp, i, i, i, ct.POINTER(vp)]
+    L.pm_comm_local_create.argtypes = [i, ct.POINTER(vp)]
+    L.pm_comm_from_callbacks.argtypes = [vp, i, i, ct.POINTER(vp)]
+    L.pm_comm_destroy.argtypes = [vp]
+    L.pm_comm_destroy.restype = None
+    L.pm_comm_rank.argtypes = [vp]
+    L.pm_comm_world.argtypes = [vp]
+    L.pm_comm_last_error.argtypes = [vp]
+    L.pm_comm_last_error.restype = ct.c_char_p
+    L.pm_comm_all_gather.argtypes = [vp, vp, vp, sz]
+    L.pm_comm_all_to_all.argtypes = [vp, vp, vp, sz, vp]
+    L.pm_comm_combine_points.argtypes = [vp, i, i, u64p, intp]
+    L.pm_ctx_set_comm.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -147,6 +172,73 @@ def synth_r1cs(curve, nr, seed):
     return [CsrArrays(rowptr, cols[k], vals[k]) for k in range(3)], inst, wit
 
 
+def layout_indices(n, shard_count, shard_rank, coefficients=True):
+    """pm_layout_indices: global coefficient indices (blocked layout) or evaluation rows (cyclic) of a rank's local positions."""
+    L = load_library()
+    out = np.zeros(n // shard_count, dtype=np.uint64)
+    st = L.pm_layout_indices(n, shard_count, shard_rank, int(coefficients), _p(out))
+    if st:
+        raise PolymathError(st, "pm_layout_indices")
+    return out
+
+
+class Comm:
+    """pm_comm: one rank's end of the exchange layer."""
+
+    def __init__(self, handle, keep=None):
+        self.L, self.h, self._keep = load_library(), handle, keep
+
+    @classmethod
+    def local_group(cls, world):
+        """`world` ranks as threads of this process (tests, emulation, single-process multi-GPU)."""
+        L = load_library()
+        arr = (ct.c_void_p * world)()
+        st = L.pm_comm_local_create(world, arr)
+        if st:
+            raise PolymathError(st, "pm_comm_local_create")
+        return [cls(ct.c_void_p(arr[r])) for r in range(world)]
+
+    @staticmethod
+    def rccl_unique_id():
+        L = load_library()
+        buf = ct.create_string_buffer(128)
+        st = L.pm_comm_rccl_unique_id(buf)
+        if st:
+            raise PolymathError(st, "pm_comm_rccl_unique_id (librccl not loadable?)")
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, unique_id, rank, world, device):
+        """ncclCommInitRank over the 128-byte id rank 0 made with rccl_unique_id(); collective."""
+        L = load_library()
+        h = ct.c_void_p()
+        st = L.pm_comm_rccl_create(ct.c_char_p(unique_id), rank, world, device, ct.byref(h))
+        if st:
+            raise PolymathError(st, "pm_comm_rccl_create")
+        return cls(h)
+
+    @property
+    def rank(self):
+        return self.L.pm_comm_rank(self.h)
+
+    @property
+    def world(self):
+        return self.L.pm_comm_world(self.h)
+
+    def all_gather(self, arr):
+        arr = np.ascontiguousarray(arr)
+        out = np.zeros((self.world,) + arr.shape, dtype=arr.dtype)
+        st = self.L.pm_comm_all_gather(self.h, arr.ctypes.data_as(ct.c_void_p), out.ctypes.data_as(ct.c_void_p), arr.nbytes)
+        if st:
+            raise PolymathError(st, self.L.pm_comm_last_error(self.h).decode())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pm_comm_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """pm_ctx: one HIP stream + workspaces on one GPU; one proof in flight."""
 
@@ -173,6 +265,11 @@ class Context:
     def check(self, st):
         if st:
             raise PolymathError(st, self.L.pm_last_error(self.h).decode())
+
+    def set_comm(self, comm):
+        """Join this context to its rank's communicator (needed by PM_SHARD_VECTOR keys)."""
+        self.comm = comm
+        self.check(self.L.pm_ctx_set_comm(self.h, comm.h if comm is not None else None))
 
     def timings(self):
         arr = (ct.c_double * len(TIMING_SLOTS))()
@@ -286,25 +383,30 @@ class ProvingKey:
         self.nq = FQ_LIMBS64[self.cid]
 
     @classmethod
-    def generate(cls, ctx, curve, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1):
-        """a, b, c: CsrArrays; trapdoors: np.uint64[4] Montgomery (generator.rs:72,77 draws)."""
+    def generate(cls, ctx, curve, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1, layout="pairs"):
+        """a, b, c: CsrArrays; trapdoors: np.uint64[4] Montgomery (generator.rs:72,77 draws).  layout: "pairs" (MSM pair
+        ranges sharded, vector phases replicated) or "vector" (everything sharded; the context needs set_comm)."""
         h = ct.c_void_p()
-        ctx.check(ctx.L.pm_pk_generate(ctx.h, CURVE_IDS[curve], m0, mw, nr, ct.byref(a.struct), ct.byref(b.struct),
-                                       ct.byref(c.struct), _p(_c(x_trapdoor)), _p(_c(z_trapdoor)), shard_rank, shard_count,
-                                       ct.byref(h)))
-        return cls(ctx, curve, h, (a, b, c))
+        ctx.check(ctx.L.pm_pk_generate_sharded(ctx.h, CURVE_IDS[curve], m0, mw, nr, ct.byref(a.struct), ct.byref(b.struct),
+                                               ct.byref(c.struct), _p(_c(x_trapdoor)), _p(_c(z_trapdoor)), shard_rank, shard_count,
+                                               LAYOUTS[layout], ct.byref(h)))
+        pk = cls(ctx, curve, h, (a, b, c))
+        pk.shard_rank, pk.shard_count, pk.layout = shard_rank, shard_count, LAYOUTS[layout]
+        return pk
 
     @classmethod
-    def load(cls, ctx, curve, n, m0, mw, nr, sigma, a, b, c, base_arrays, shard_rank=0, shard_count=1):
+    def load(cls, ctx, curve, n, m0, mw, nr, sigma, a, b, c, base_arrays, shard_rank=0, shard_count=1, layout="pairs"):
         """base_arrays: six np.uint64 2-D arrays in pm_base_vec order."""
         arrs = [_c(x) for x in base_arrays]
         BA = (PmBaseArray * 6)()
         for k, x in enumerate(arrs):
             BA[k] = PmBaseArray(x.ctypes.data_as(ct.c_void_p), x.shape[0], x.strides[0])
         h = ct.c_void_p()
-        ctx.check(ctx.L.pm_pk_load(ctx.h, CURVE_IDS[curve], n, m0, mw, nr, sigma, ct.byref(a.struct), ct.byref(b.struct),
-                                   ct.byref(c.struct), BA, shard_rank, shard_count, ct.byref(h)))
-        return cls(ctx, curve, h, (a, b, c))
+        ctx.check(ctx.L.pm_pk_load_sharded(ctx.h, CURVE_IDS[curve], n, m0, mw, nr, sigma, ct.byref(a.struct), ct.byref(b.struct),
+                                           ct.byref(c.struct), BA, shard_rank, shard_count, LAYOUTS[layout], ct.byref(h)))
+        pk = cls(ctx, curve, h, (a, b, c))
+        pk.shard_rank, pk.shard_count, pk.layout = shard_rank, shard_count, LAYOUTS[layout]
+        return pk
 
     def view(self, ctx):
         """The same resident key used from another context (a pm_pk is immutable and shareable; each context runs
@@ -319,6 +421,14 @@ class ProvingKey:
         pairs, win, bits, tb = ct.c_uint64(), ct.c_uint(), ct.c_uint(), ct.c_int()
         self.ctx.check(self.ctx.L.pm_pk_msm_plan(self.h, which, ct.byref(pairs), ct.byref(win), ct.byref(bits), ct.byref(tb)))
         return pairs.value, win.value, bits.value, bool(tb.value)
+
+    def msm_pieces(self, which):
+        """[(cat_lo, count), ...]: the resident pairs of merged MSM `which` as ranges of the logical base concatenation."""
+        n = ct.c_size_t(0)
+        self.ctx.check(self.ctx.L.pm_pk_msm_pieces(self.h, which, None, None, 0, ct.byref(n)))
+        lo, cnt = np.zeros(n.value, dtype=np.uint64), np.zeros(n.value, dtype=np.uint64)
+        self.ctx.check(self.ctx.L.pm_pk_msm_pieces(self.h, which, _p(lo), _p(cnt), n.value, ct.byref(n)))
+        return [(int(a), int(b)) for a, b in zip(lo, cnt)]
 
     def msm_windows(self, which):
         return self.msm_plan(which)[1]

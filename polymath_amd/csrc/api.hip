@@ -54,6 +54,9 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     ctx->pk = nullptr;
     ctx->phase = 0;
     ctx->aux = nullptr;
+    ctx->comm = nullptr;
+    ctx->tw_clock = 0;
+    ctx->shard_roots_n = 0; ctx->shard_roots_N = 0; ctx->shard_roots_curve = -1;
     ctx->keep_timings = false;
     timing_reset(ctx);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -78,7 +81,8 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     MsmWorkspace &m = ctx->msm;
     for (DevBuf *b : {&m.digits, &m.sorted, &m.counts, &m.bucket_off, &m.task_off, &m.cursor, &m.partials, &m.wsum,
                       &m.region, &m.sub, &m.digits2, &m.order, &m.len_bins, &m.block_cnt, &m.task_cnt, &m.hot, &ctx->scratch, &ctx->flags, &ctx->xw, &ctx->ue, &ctx->we, &ctx->u, &ctx->w,
-                      &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra})
+                      &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra, &ctx->sh_a, &ctx->sh_b, &ctx->sh_c, &ctx->halo,
+                      &ctx->shard_roots})
         b->release();
     for (auto &b : ctx->lvl) b.release();
     for (auto &b : ctx->fb_table) b.release();
@@ -348,6 +352,7 @@ static void pk_release(pm_pk *pk) {
         if (pk->d_val[i]) (void)hipFree(pk->d_val[i]);
     }
     if (pk->d_bases) (void)hipFree(pk->d_bases);
+    if (pk->d_segs) (void)hipFree(pk->d_segs);
     for (int k = 0; k < 3; ++k) {
         if (pk->d_tab[k]) (void)hipFree(pk->d_tab[k]);
         if (pk->d_tab_inf[k]) (void)hipFree(pk->d_tab_inf[k]);
@@ -359,9 +364,11 @@ extern "C" void pm_pk_free(pm_pk *pk) { pk_release(pk); }
 
 // Shapes, domain, the logical base concatenation and this shard's resident ranges.
 template <class C>
-static int pk_init_layout(pm_ctx *ctx, pm_pk *pk, uint64_t m0, uint64_t mw, uint64_t nr, int shard_rank, int shard_count) {
+static int pk_init_layout(pm_ctx *ctx, pm_pk *pk, uint64_t m0, uint64_t mw, uint64_t nr, int shard_rank, int shard_count, int layout = PM_SHARD_PAIRS) {
     typedef typename C::FrP P;
     if (m0 < 1 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return PM_ERR_INVALID_ARG;
+    if (layout != PM_SHARD_PAIRS && layout != PM_SHARD_VECTOR) return PM_ERR_INVALID_ARG;
+    pk->layout = layout;
     pk->curve = C::ID;
     pk->device = ctx->device;
     pk->m0 = m0; pk->mw = mw; pk->nr = nr;
@@ -395,21 +402,52 @@ static int pk_init_layout(pm_ctx *ctx, pm_pk *pk, uint64_t m0, uint64_t mw, uint
         pk->res_lo[k] = pk->msm_len[k] * (uint64_t)shard_rank / (uint64_t)shard_count;
         pk->res_hi[k] = pk->msm_len[k] * (uint64_t)(shard_rank + 1) / (uint64_t)shard_count;
     }
+    if (layout == PM_SHARD_VECTOR) {
+        if (!pmlayout::layout_ok(n, (uint32_t)shard_count)) return PM_ERR_INVALID_ARG;   // N a power of two, N^2 | n
+        const pmlayout::Layout L = pmlayout::make_layout(n, (uint32_t)shard_count, (uint32_t)shard_rank);
+        const pmlayout::KeyShape ks = pmlayout::key_shape(n, m0, mw, nr);
+        pk->max_seg = pmlayout::pick_max_seg(n, (uint32_t)shard_count);
+        if (const char *e = getenv("PM_MAX_SEG_LOG")) pk->max_seg = (uint64_t)1 << atoi(e);   // test knob: many tiny sub-segments
+        pk->segs = pmlayout::quotient_segments(n, (uint32_t)shard_count, (uint32_t)shard_rank, pk->max_seg);
+        pk->seg_slots = 0;
+        for (uint32_t r = 0; r < (uint32_t)shard_count; ++r) {
+            const std::vector<pmlayout::Segment> sr = (int)r == shard_rank ? pk->segs : pmlayout::quotient_segments(n, (uint32_t)shard_count, r, pk->max_seg);
+            pk->seg_slots = std::max(pk->seg_slots, sr.size());
+            for (size_t i = 0; i < sr.size(); ++i) pk->all_segs.push_back(pm_pk::SegRef{sr[i].a, sr[i].b, r, (uint32_t)i});
+        }
+        std::sort(pk->all_segs.begin(), pk->all_segs.end(), [](const pm_pk::SegRef &x, const pm_pk::SegRef &y) { return x.a < y.a; });
+        uint64_t at = 0;                                    // the ranks' segments must tile [0, len) exactly
+        for (const auto &e : pk->all_segs) {
+            if (e.a != at || e.b <= e.a) return PM_ERR_STATE;
+            at = e.b;
+        }
+        if (at != pmlayout::numerator_len(n)) return PM_ERR_STATE;
+        PM_HIP(ctx, hipMalloc(&pk->d_segs, pk->segs.size() * sizeof(pmlayout::Segment)));
+        PM_HIP(ctx, hipMemcpy(pk->d_segs, pk->segs.data(), pk->segs.size() * sizeof(pmlayout::Segment), hipMemcpyHostToDevice));
+        pk->pieces[0] = pmlayout::pieces_a(ks, L);
+        pk->pieces[1] = pmlayout::pieces_c(ks, L);
+        pk->pieces[2] = pmlayout::pieces_d(ks, pk->segs);
+        for (int k = 0; k < 3; ++k) { pk->res_lo[k] = 0; pk->res_hi[k] = 0; }   // not contiguous: unused in this layout
+    } else {
+        for (int k = 0; k < 3; ++k) pk->pieces[k] = {pmlayout::Piece{pk->msm_lo[k] + pk->res_lo[k], pk->res_hi[k] - pk->res_lo[k]}};
+    }
+    for (int k = 0; k < 3; ++k) {
+        pk->res_cnt[k] = 0;
+        for (const auto &pc : pk->pieces[k]) pk->res_cnt[k] += pc.count;
+    }
     if (shard_count == 1) {
         for (int k = 0; k < 3; ++k) pk->res_dev_off[k] = pk->msm_lo[k];
-    } else {  // device layout [c slice | a slice | d slice]
+    } else {  // device layout [c pairs | a pairs | d pairs]
         pk->res_dev_off[1] = 0;
-        pk->res_dev_off[0] = pk->res_hi[1] - pk->res_lo[1];
-        pk->res_dev_off[2] = pk->res_dev_off[0] + (pk->res_hi[0] - pk->res_lo[0]);
+        pk->res_dev_off[0] = pk->res_cnt[1];
+        pk->res_dev_off[2] = pk->res_dev_off[0] + pk->res_cnt[0];
     }
     return PM_OK;
 }
 
 static uint64_t pk_resident_points(const pm_pk *pk) {
     if (pk->shard_count == 1) return pk->total_points;
-    uint64_t t = 0;
-    for (int k = 0; k < 3; ++k) t += pk->res_hi[k] - pk->res_lo[k];
-    return t;
+    return pk->res_cnt[0] + pk->res_cnt[1] + pk->res_cnt[2];
 }
 
 template <class C>
@@ -461,8 +499,13 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     if (pk->shard_count == 1) {
         PM_TRY(for_cat_range<C>(pk, 0, pk->total_points, d, fill));
     } else {
-        for (int k = 0; k < 3; ++k)
-            PM_TRY(for_cat_range<C>(pk, pk->msm_lo[k] + pk->res_lo[k], pk->msm_lo[k] + pk->res_hi[k], d + pk->res_dev_off[k], fill));
+        for (int k = 0; k < 3; ++k) {
+            uint64_t at = pk->res_dev_off[k];
+            for (const auto &pc : pk->pieces[k]) {
+                if (pc.count) PM_TRY(for_cat_range<C>(pk, pc.cat_lo, pc.cat_lo + pc.count, d + at, fill));
+                at += pc.count;
+            }
+        }
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tables_disabled_by_env()) return PM_OK;
@@ -478,15 +521,15 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     if (const char *e = getenv("PM_INFLIGHT_CONTEXTS")) inflight = atoi(e) > 1 ? atoi(e) : 1;
     double budget = 0.9 * (double)free_b - (double)inflight * 64.0 * 40.0 * (double)pk->n;
     {
-        const uint64_t len_d = pk->res_hi[2] - pk->res_lo[2], len_a = pk->res_hi[0] - pk->res_lo[0];
+        const uint64_t len_d = pk->res_cnt[2], len_a = pk->res_cnt[0];
         budget -= (double)inflight * 48.0 * 16.0 * (double)(len_d < (uint64_t)msm_max_piece() ? len_d : (uint64_t)msm_max_piece());
         budget -= (double)inflight * 48.0 * 16.0 * (double)len_a;
     }
     int order[3] = {0, 1, 2};
-    std::sort(order, order + 3, [&](int x, int y) { return pk->res_hi[x] - pk->res_lo[x] < pk->res_hi[y] - pk->res_lo[y]; });
+    std::sort(order, order + 3, [&](int x, int y) { return pk->res_cnt[x] < pk->res_cnt[y]; });
     for (int q = 0; q < 3; ++q) {
         const int k = order[q];
-        const uint64_t len = pk->res_hi[k] - pk->res_lo[k];
+        const uint64_t len = pk->res_cnt[k];
         if (!len) continue;
         MsmTables tb = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS);
         if (!tb.c) continue;
@@ -506,11 +549,11 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
 
 template <class C>
 static int pk_load_impl(pm_ctx *ctx, uint64_t n, uint64_t m0, uint64_t mw, uint64_t nr, uint64_t sigma, const pm_csr *a,
-                        const pm_csr *b, const pm_csr *c, const pm_base_array *bases, int shard_rank, int shard_count,
+                        const pm_csr *b, const pm_csr *c, const pm_base_array *bases, int shard_rank, int shard_count, int layout,
                         pm_pk **out) {
     pm_pk *pk = new pm_pk();
     auto guard = [&](int st) { if (st != PM_OK) pk_release(pk); return st; };
-    int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count);
+    int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count, layout);
     if (st) return guard(st);
     if (pk->n != n || pk->sigma != sigma) return guard(PM_ERR_INVALID_ARG);
     for (int v = 0; v < PM_NUM_BASE_VECS; ++v)
@@ -533,13 +576,19 @@ static int pk_load_impl(pm_ctx *ctx, uint64_t n, uint64_t m0, uint64_t mw, uint6
     return PM_OK;
 }
 
+extern "C" int pm_pk_load_sharded(pm_ctx *ctx, int curve, uint64_t n, uint64_t m0, uint64_t mw, uint64_t nr, uint64_t sigma,
+                                  const pm_csr *a, const pm_csr *b, const pm_csr *c, const pm_base_array bases[PM_NUM_BASE_VECS],
+                                  int shard_rank, int shard_count, int layout, pm_pk **out) {
+    if (!ctx || !a || !b || !c || !bases || !out) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(curve, pk_load_impl<BlsCurve>(ctx, n, m0, mw, nr, sigma, a, b, c, bases, shard_rank, shard_count, layout, out),
+                       pk_load_impl<BnCurve>(ctx, n, m0, mw, nr, sigma, a, b, c, bases, shard_rank, shard_count, layout, out));
+}
+
 extern "C" int pm_pk_load(pm_ctx *ctx, int curve, uint64_t n, uint64_t m0, uint64_t mw, uint64_t nr, uint64_t sigma,
                           const pm_csr *a, const pm_csr *b, const pm_csr *c, const pm_base_array bases[PM_NUM_BASE_VECS],
                           int shard_rank, int shard_count, pm_pk **out) {
-    if (!ctx || !a || !b || !c || !bases || !out) return PM_ERR_INVALID_ARG;
-    PM_TRY(set_device(ctx));
-    return PM_DISPATCH(curve, pk_load_impl<BlsCurve>(ctx, n, m0, mw, nr, sigma, a, b, c, bases, shard_rank, shard_count, out),
-                       pk_load_impl<BnCurve>(ctx, n, m0, mw, nr, sigma, a, b, c, bases, shard_rank, shard_count, out));
+    return pm_pk_load_sharded(ctx, curve, n, m0, mw, nr, sigma, a, b, c, bases, shard_rank, shard_count, PM_SHARD_PAIRS, out);
 }
 
 // generate_proving_key (generator.rs:24-167) with the trapdoors supplied.  The dense uj_wj_lcs loop
@@ -551,12 +600,12 @@ extern "C" int pm_pk_load(pm_ctx *ctx, int curve, uint64_t n, uint64_t m0, uint6
 template <class C>
 static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a, const pm_csr *b,
                             const pm_csr *c, const uint64_t *x_trap, const uint64_t *z_trap, int shard_rank,
-                            int shard_count, pm_pk **out) {
+                            int shard_count, int layout, pm_pk **out) {
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
     pm_pk *pk = new pm_pk();
     auto guard = [&](int st) { if (st != PM_OK) pk_release(pk); return st; };
-    int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count);
+    int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count, layout);
     if (st) return guard(st);
     HostCsr host[3];
     st = pk_upload_matrices<C>(ctx, pk, a, b, c, host);
@@ -645,13 +694,37 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
     return PM_OK;
 }
 
+extern "C" int pm_pk_generate_sharded(pm_ctx *ctx, int curve, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a,
+                                      const pm_csr *b, const pm_csr *c, const uint64_t *x_trapdoor, const uint64_t *z_trapdoor,
+                                      int shard_rank, int shard_count, int layout, pm_pk **out) {
+    if (!ctx || !a || !b || !c || !x_trapdoor || !z_trapdoor || !out) return PM_ERR_INVALID_ARG;
+    PM_TRY(set_device(ctx));
+    return PM_DISPATCH(curve, pk_generate_impl<BlsCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, layout, out),
+                       pk_generate_impl<BnCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, layout, out));
+}
+
 extern "C" int pm_pk_generate(pm_ctx *ctx, int curve, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a,
                               const pm_csr *b, const pm_csr *c, const uint64_t *x_trapdoor, const uint64_t *z_trapdoor,
                               int shard_rank, int shard_count, pm_pk **out) {
-    if (!ctx || !a || !b || !c || !x_trapdoor || !z_trapdoor || !out) return PM_ERR_INVALID_ARG;
-    PM_TRY(set_device(ctx));
-    return PM_DISPATCH(curve, pk_generate_impl<BlsCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, out),
-                       pk_generate_impl<BnCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, out));
+    return pm_pk_generate_sharded(ctx, curve, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, PM_SHARD_PAIRS, out);
+}
+
+// ---- layout helpers for hosts and tests (polymath_amd/host/layout.hpp): pure index arithmetic, no GPU
+extern "C" int pm_layout_indices(uint64_t n, int shard_count, int shard_rank, int coefficients, uint64_t *out /* n / shard_count */) {
+    if (!out || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count || !pmlayout::layout_ok(n, (uint32_t)shard_count)) return PM_ERR_INVALID_ARG;
+    const pmlayout::Layout L = pmlayout::make_layout(n, (uint32_t)shard_count, (uint32_t)shard_rank);
+    for (uint64_t p = 0; p < L.m; ++p) out[p] = coefficients ? pmlayout::coeff_global(L, p) : pmlayout::eval_global(L, p);
+    return PM_OK;
+}
+
+extern "C" int pm_pk_msm_pieces(const pm_pk *pk, int which, uint64_t *cat_lo, uint64_t *count, size_t capacity, size_t *n_pieces) {
+    if (!pk || which < 0 || which > 2 || !n_pieces) return PM_ERR_INVALID_ARG;
+    *n_pieces = pk->pieces[which].size();
+    for (size_t i = 0; i < pk->pieces[which].size() && i < capacity; ++i) {
+        if (cat_lo) cat_lo[i] = pk->pieces[which][i].cat_lo;
+        if (count) count[i] = pk->pieces[which][i].count;
+    }
+    return PM_OK;
 }
 
 extern "C" int pm_pk_info(const pm_pk *pk, uint64_t *n, uint64_t *m0, uint64_t *sigma, uint64_t *omega,
@@ -667,7 +740,7 @@ extern "C" int pm_pk_info(const pm_pk *pk, uint64_t *n, uint64_t *m0, uint64_t *
 
 extern "C" int pm_pk_msm_plan(const pm_pk *pk, int which, uint64_t *pairs, unsigned *windows, unsigned *window_bits, int *tables) {
     if (!pk || which < 0 || which > 2) return PM_ERR_INVALID_ARG;
-    const uint64_t len = pk->res_hi[which] - pk->res_lo[which];
+    const uint64_t len = pk->res_cnt[which];
     unsigned nwin = 0, c = 0;
     if (pk->tables[which].c) {
         nwin = pk->tables[which].nwin;
@@ -696,8 +769,11 @@ extern "C" int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_
         found = true;
     } else {
         for (int k = 0; k < 3 && !found; ++k) {
-            uint64_t rl = pk->msm_lo[k] + pk->res_lo[k], rh = pk->msm_lo[k] + pk->res_hi[k];
-            if (lo >= rl && hi <= rh) { dev_off = pk->res_dev_off[k] + (lo - rl); found = true; }
+            uint64_t at = pk->res_dev_off[k];
+            for (const auto &pc : pk->pieces[k]) {
+                if (lo >= pc.cat_lo && hi <= pc.cat_lo + pc.count) { dev_off = at + (lo - pc.cat_lo); found = true; break; }
+                at += pc.count;
+            }
         }
     }
     if (!found) return PM_ERR_INVALID_ARG;  // not resident on this shard
@@ -727,6 +803,9 @@ extern "C" int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, 
     if (pk->device != ctx->device) return PM_ERR_INVALID_ARG;
     PM_TRY(set_device(ctx));
     return guarded(ctx, [&] {
+        if (pk->layout == PM_SHARD_VECTOR)
+            return PM_DISPATCH(pk->curve, prove_phase1_sharded<BlsCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false),
+                               prove_phase1_sharded<BnCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false));
         return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false),
                            prove_phase1_impl<BnCurve>(ctx, pk, x, w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, false));
     });
@@ -738,6 +817,9 @@ extern "C" int pm_prove_phase1_device(pm_ctx *ctx, const pm_pk *pk, const uint64
     if (pk->device != ctx->device) return PM_ERR_INVALID_ARG;
     PM_TRY(set_device(ctx));
     return guarded(ctx, [&] {
+        if (pk->layout == PM_SHARD_VECTOR)
+            return PM_DISPATCH(pk->curve, prove_phase1_sharded<BlsCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true),
+                               prove_phase1_sharded<BnCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true));
         return PM_DISPATCH(pk->curve, prove_phase1_impl<BlsCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true),
                            prove_phase1_impl<BnCurve>(ctx, pk, d_x, d_w, r_a, a_g1_xy, a_inf, c_g1_xy, c_inf, true));
     });
@@ -747,7 +829,11 @@ extern "C" int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x
     if (!ctx || !x1 || !u_at_x1) return PM_ERR_INVALID_ARG;
     if (!ctx->pk) return PM_ERR_STATE;
     PM_TRY(set_device(ctx));
-    return guarded(ctx, [&] { return PM_DISPATCH(ctx->pk->curve, prove_phase2_impl<BlsCurve>(ctx, x1, u_at_x1), prove_phase2_impl<BnCurve>(ctx, x1, u_at_x1)); });
+    return guarded(ctx, [&] {
+        if (ctx->pk->layout == PM_SHARD_VECTOR)
+            return PM_DISPATCH(ctx->pk->curve, prove_phase2_sharded<BlsCurve>(ctx, x1, u_at_x1), prove_phase2_sharded<BnCurve>(ctx, x1, u_at_x1));
+        return PM_DISPATCH(ctx->pk->curve, prove_phase2_impl<BlsCurve>(ctx, x1, u_at_x1), prove_phase2_impl<BnCurve>(ctx, x1, u_at_x1));
+    });
 }
 
 extern "C" int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
@@ -756,6 +842,9 @@ extern "C" int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *
     if (!ctx->pk) return PM_ERR_STATE;
     PM_TRY(set_device(ctx));
     return guarded(ctx, [&] {
+        if (ctx->pk->layout == PM_SHARD_VECTOR)
+            return PM_DISPATCH(ctx->pk->curve, prove_phase3_sharded<BlsCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf),
+                               prove_phase3_sharded<BnCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf));
         return PM_DISPATCH(ctx->pk->curve, prove_phase3_impl<BlsCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf),
                            prove_phase3_impl<BnCurve>(ctx, x1, x2, a_at_x1, c_at_x1, d_g1_xy, d_inf));
     });
@@ -769,6 +858,27 @@ extern "C" int pm_prove_tap(pm_ctx *ctx, int which, uint64_t *out, size_t max_el
     const uint64_t n = pk->n, Lz = 2 * pk->m0 + pk->mw + pk->nr;
     const void *src = nullptr;
     size_t cnt = 0;
+    if (pk->layout == PM_SHARD_VECTOR) {
+        // this rank's LOCAL vectors (coefficients in the blocked layout: pm_layout_indices); the evaluations are consumed
+        // by the in-place transforms and are not available
+        const uint64_t N = (uint64_t)pk->shard_count, q = (uint64_t)pk->shard_rank, m = n / N;
+        const uint64_t zcnt = pmlayout::ztail_lo(Lz, (uint32_t)N, (uint32_t)q + 1) - pmlayout::ztail_lo(Lz, (uint32_t)N, (uint32_t)q);
+        switch (which) {
+            case 2: src = ctx->u.p; cnt = m; break;
+            case 3: src = ctx->w.p; cnt = m; break;
+            case 4: src = (const uint8_t *)ctx->sc_c.p + zcnt * 32; cnt = m - (q == N - 1 ? 1 : 0); break;
+            case 5: src = ctx->wit_u.p; cnt = m; break;
+            case 6: src = ctx->sc_c.p; cnt = zcnt; break;
+            case 7:
+                if (ctx->phase < 3) return PM_ERR_STATE;
+                src = ctx->quotient.p; cnt = pk->res_cnt[2]; break;
+            default: return PM_ERR_INVALID_ARG;
+        }
+        *n_elems = cnt;
+        const size_t kk = std::min(cnt, max_elems);
+        if (kk) PM_HIP(ctx, hipMemcpy(out, src, kk * 32, hipMemcpyDeviceToHost));
+        return PM_OK;
+    }
     switch (which) {
         case 0: src = ctx->ue.p; cnt = n; break;
         case 1: src = ctx->we.p; cnt = n; break;

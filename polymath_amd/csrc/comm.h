@@ -1,0 +1,20 @@
+// Internal view of pm_comm (comm.hip implements it; prove_sharded.hip and host_prove.hip call it).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+struct pm_comm {
+    int rank = 0, world = 1;
+    std::string err;
+    virtual ~pm_comm() {}
+    // send/recv: world blocks of `bytes` each; block p of `send` goes to rank p, block p of `recv` comes from rank p.
+    // Ordered after everything already enqueued on `stream`; the received data is visible to work enqueued after the call.
+    virtual int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) = 0;
+    // host buffers: recv holds world x bytes, rank r's contribution at r * bytes.  Blocking.  `stream`: the caller's
+    // stream (RCCL runs every collective of a communicator on ONE stream, in program order); null = the comm's own.
+    virtual int all_gather(const void *send, void *recv, size_t bytes, hipStream_t stream) = 0;
+    // end of a prover phase: nothing to exchange until the host calls again (local serialised emulation: pass the turn on)
+    virtual void phase_end() {}
+};
+

@@ -1,0 +1,290 @@
+// pm_comm: the exchange layer of a multi-GPU proof.  Two collectives are all the sharded prover needs:
+//   all_to_all  equal blocks of DEVICE memory, stream-ordered (the transpose of the four-step NTT: one per transform);
+//   all_gather  a few hundred bytes of HOST memory (partial G1 points, status flags, Horner partial sums and halo
+//               coefficients, the per-segment values of the division scan).
+// Implementations:
+//   RCCL   (pm_comm_rccl_create)  -- one process per GPU over xGMI; librccl is dlopen'ed at first use, so the library
+//                                    has no link-time dependency on it and single-GPU hosts never load it.  The
+//                                    all-to-all is one ncclAllToAll on the context's stream: no host synchronisation.
+//   local  (pm_comm_local_create) -- N ranks as N threads of ONE process (any mix of devices): rendezvous through a
+//                                    barrier, device-to-device copies.  What the single-GPU lockstep tests and the
+//                                    per-rank emulation of bench.py run on; also a valid single-process multi-GPU mode.
+//   callbacks (pm_comm_from_callbacks) -- the host brings its own transport (torch.distributed in tests).
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "internal.h"
+#include "comm.h"
+
+using namespace pm;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------- local
+struct LocalGroup {
+    int world;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> send;
+    std::vector<void *> recv;
+    bool failed = false;
+    // PM_LOCAL_COMM_SERIALIZE=1: between collectives only ONE rank runs at a time (a turnstile), so that N ranks emulated on
+    // one GPU do not time-slice it: each rank's kernels then take what they would take alone (bench.py's emulation).
+    bool serialize = false;
+    std::mutex turn;
+    explicit LocalGroup(int w) : world(w), send(w), recv(w) {
+        const char *e = getenv("PM_LOCAL_COMM_SERIALIZE");
+        serialize = e && e[0] == '1';
+    }
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
+struct LocalComm : pm_comm {
+    std::shared_ptr<LocalGroup> g;
+    bool holds_turn = false;
+    void release_turn() {
+        if (g->serialize && holds_turn) { g->turn.unlock(); holds_turn = false; }
+    }
+    void take_turn() {
+        if (g->serialize && !holds_turn) { g->turn.lock(); holds_turn = true; }
+    }
+    ~LocalComm() override { release_turn(); }
+    void phase_end() override { release_turn(); }
+    int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
+        if (hipStreamSynchronize(stream) != hipSuccess) { err = "local all_to_all: stream sync failed"; g->failed = true; }
+        release_turn();
+        g->send[rank] = d_send;
+        g->recv[rank] = d_recv;
+        g->barrier();                                   // every rank's send buffer is complete and published
+        take_turn();
+        int st = PM_OK;
+        for (int p = 0; p < world && !g->failed; ++p) {
+            const uint8_t *src = (const uint8_t *)g->send[p] + (size_t)rank * bytes;
+            if (hipMemcpyAsync((uint8_t *)d_recv + (size_t)p * bytes, src, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+                err = "local all_to_all: copy failed";
+                g->failed = true;
+            }
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess) g->failed = true;
+        release_turn();
+        g->barrier();                                   // nobody reuses a send buffer before every peer has read it
+        take_turn();
+        if (g->failed) st = PM_ERR_HIP;
+        return st;
+    }
+    int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t) override {
+        release_turn();
+        g->send[rank] = send_h;
+        g->barrier();
+        for (int p = 0; p < world; ++p) memcpy((uint8_t *)recv_h + (size_t)p * bytes, g->send[p], bytes);
+        g->barrier();
+        take_turn();
+        return g->failed ? PM_ERR_HIP : PM_OK;
+    }
+};
+
+// ----------------------------------------------------------------------------------------------------- RCCL
+// The handful of RCCL entry points, resolved at run time.  Under torch the process already holds a librccl (same
+// soname): dlopen then returns that instance instead of loading a second copy.
+struct Id128 { char b[128]; };   // ncclUniqueId, passed BY VALUE to ncclCommInitRank
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllToAll)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+
+static RcclApi *rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) { api.err = std::string("librccl not found: ") + dlerror(); return; }
+        auto sym = [&](const char *n) {
+            void *p = dlsym(api.lib, n);
+            if (!p && api.err.empty()) api.err = std::string("librccl lacks ") + n;
+            return p;
+        };
+        api.GetUniqueId = (int (*)(void *))sym("ncclGetUniqueId");
+        api.CommInitRank = (int (*)(void **, int, Id128, int))sym("ncclCommInitRank");
+        api.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+        api.AllToAll = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))sym("ncclAllToAll");
+        api.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))sym("ncclAllGather");
+        api.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+    });
+    return &api;
+}
+constexpr int NCCL_UINT8 = 1;   // ncclUint8 (rccl.h)
+
+struct RcclComm : pm_comm {
+    void *comm = nullptr;
+    int device = 0;
+    hipStream_t side = nullptr;     // stream of the small host all-gathers
+    void *d_stage = nullptr;        // device staging of the host all-gather: [send | world x recv]
+    size_t stage_bytes = 0;
+    int fail(const char *what, int rc) {
+        RcclApi *a = rccl_api();
+        err = std::string(what) + ": " + (a->GetErrorString ? a->GetErrorString(rc) : "rccl error");
+        return PM_ERR_HIP;
+    }
+    ~RcclComm() override {
+        (void)hipSetDevice(device);
+        if (comm) rccl_api()->CommDestroy(comm);
+        if (d_stage) (void)hipFree(d_stage);
+        if (side) (void)hipStreamDestroy(side);
+    }
+    int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
+        const int rc = rccl_api()->AllToAll(d_send, d_recv, bytes, NCCL_UINT8, comm, stream);
+        return rc ? fail("ncclAllToAll", rc) : PM_OK;
+    }
+    int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t stream) override {
+        hipStream_t side = stream ? stream : this->side;
+        const size_t need = bytes * (size_t)(world + 1);
+        if (need > stage_bytes) {
+            if (d_stage) (void)hipFree(d_stage);
+            d_stage = nullptr;
+            stage_bytes = need < 65536 ? 65536 : need;
+            if (hipMalloc(&d_stage, stage_bytes) != hipSuccess) { err = "all_gather staging allocation failed"; return PM_ERR_HIP; }
+        }
+        uint8_t *ds = (uint8_t *)d_stage, *dr = ds + bytes;
+        if (hipMemcpyAsync(ds, send_h, bytes, hipMemcpyHostToDevice, side) != hipSuccess) { err = "all_gather H2D failed"; return PM_ERR_HIP; }
+        const int rc = rccl_api()->AllGather(ds, dr, bytes, NCCL_UINT8, comm, side);
+        if (rc) return fail("ncclAllGather", rc);
+        if (hipMemcpyAsync(recv_h, dr, bytes * (size_t)world, hipMemcpyDeviceToHost, side) != hipSuccess || hipStreamSynchronize(side) != hipSuccess) {
+            err = "all_gather D2H failed";
+            return PM_ERR_HIP;
+        }
+        return PM_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ callbacks
+struct CallbackComm : pm_comm {
+    pm_comm_ops ops;
+    int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
+        return ops.all_to_all ? ops.all_to_all(ops.user, d_send, d_recv, bytes, (void *)stream) : (int)PM_ERR_INVALID_ARG;
+    }
+    int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t) override {
+        return ops.all_gather ? ops.all_gather(ops.user, send_h, recv_h, bytes) : (int)PM_ERR_INVALID_ARG;
+    }
+};
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------- C ABI
+extern "C" int pm_comm_local_create(int world, pm_comm **out /* world handles */) {
+    if (world < 1 || !out) return PM_ERR_INVALID_ARG;
+    auto g = std::make_shared<LocalGroup>(world);
+    for (int r = 0; r < world; ++r) {
+        LocalComm *c = new LocalComm();
+        c->rank = r;
+        c->world = world;
+        c->g = g;
+        out[r] = c;
+    }
+    return PM_OK;
+}
+
+extern "C" int pm_comm_rccl_unique_id(void *out_128_bytes) {
+    if (!out_128_bytes) return PM_ERR_INVALID_ARG;
+    RcclApi *a = rccl_api();
+    if (!a->GetUniqueId) return PM_ERR_STATE;
+    return a->GetUniqueId(out_128_bytes) ? (int)PM_ERR_HIP : (int)PM_OK;
+}
+
+extern "C" int pm_comm_rccl_create(const void *unique_id_128_bytes, int rank, int world, int device, pm_comm **out) {
+    if (!unique_id_128_bytes || !out || world < 1 || rank < 0 || rank >= world) return PM_ERR_INVALID_ARG;
+    *out = nullptr;
+    RcclApi *a = rccl_api();
+    if (!a->CommInitRank || !a->AllToAll || !a->AllGather || !a->CommDestroy) return PM_ERR_STATE;
+    if (hipSetDevice(device) != hipSuccess) return PM_ERR_HIP;
+    std::unique_ptr<RcclComm> c(new RcclComm());
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    Id128 id;
+    memcpy(id.b, unique_id_128_bytes, 128);
+    if (a->CommInitRank(&c->comm, world, id, rank)) return PM_ERR_HIP;
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return PM_ERR_HIP;
+    *out = c.release();
+    return PM_OK;
+}
+
+extern "C" int pm_comm_from_callbacks(const pm_comm_ops *ops, int rank, int world, pm_comm **out) {
+    if (!ops || !out || world < 1 || rank < 0 || rank >= world) return PM_ERR_INVALID_ARG;
+    CallbackComm *c = new CallbackComm();
+    c->rank = rank;
+    c->world = world;
+    c->ops = *ops;
+    *out = c;
+    return PM_OK;
+}
+
+extern "C" void pm_comm_destroy(pm_comm *c) { delete c; }
+extern "C" int pm_comm_rank(const pm_comm *c) { return c ? c->rank : -1; }
+extern "C" int pm_comm_world(const pm_comm *c) { return c ? c->world : 0; }
+extern "C" const char *pm_comm_last_error(const pm_comm *c) { return c ? c->err.c_str() : "null comm"; }
+
+extern "C" int pm_comm_all_gather(pm_comm *c, const void *send, void *recv, size_t bytes) {
+    if (!c || !send || !recv) return PM_ERR_INVALID_ARG;
+    return c->all_gather(send, recv, bytes, nullptr);
+}
+
+extern "C" int pm_comm_all_to_all(pm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream) {
+    if (!c || !d_send || !d_recv) return PM_ERR_INVALID_ARG;
+    return c->all_to_all(d_send, d_recv, bytes_per_peer, (hipStream_t)hip_stream);
+}
+
+extern "C" int pm_ctx_set_comm(pm_ctx *ctx, pm_comm *comm) {
+    if (!ctx) return PM_ERR_INVALID_ARG;
+    ctx->comm = comm;
+    return PM_OK;
+}
+
+// sum over ranks of `count` partial G1 points, in place: all-gather (x||y, inf) + pm_g1_sum (RCCL has no
+// elliptic-curve reduction op; ncclSum over limbs would be wrong).  The native form of pm_combine_fn.
+extern "C" int pm_comm_combine_points(pm_comm *c, int curve, int count, uint64_t *xy, int *inf) {
+    if (!c || !xy || !inf || count < 1 || count > 8) return PM_ERR_INVALID_ARG;
+    const size_t words = curve == PM_BLS12_381 ? 12 : 8;
+    const size_t rec = words + 1;                                    // u64 words per point record
+    std::vector<uint64_t> mine(rec * count), all(rec * count * (size_t)c->world);
+    for (int j = 0; j < count; ++j) {
+        memcpy(&mine[j * rec], xy + j * words, words * 8);
+        mine[j * rec + words] = (uint64_t)(inf[j] != 0);
+    }
+    PM_TRY(c->all_gather(mine.data(), all.data(), mine.size() * 8, nullptr));
+    std::vector<uint64_t> pts(words * (size_t)c->world);
+    std::vector<int> infs(c->world);
+    for (int j = 0; j < count; ++j) {
+        for (int r = 0; r < c->world; ++r) {
+            const uint64_t *src = &all[((size_t)r * count + j) * rec];
+            memcpy(&pts[r * words], src, words * 8);
+            infs[r] = (int)src[words];
+        }
+        PM_TRY(pm_g1_sum(curve, pts.data(), infs.data(), (size_t)c->world, xy + j * words, &inf[j]));
+    }
+    return PM_OK;
+}

@@ -27,6 +27,10 @@ int host_prove_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *instance_host,
     try {
         pmhost::Polymath<C, T> pm(view);
         typename pmhost::Polymath<C, T>::Combine cb = nullptr;
+        if (!combine && pk->shard_count != 1 && ctx->comm) {   // the context's own communicator: all-gather + pm_g1_sum, no callback
+            combine = [](void *user, int count, uint64_t *xy, int *inf) -> int { return pm_comm_combine_points((pm_comm *)user, C::ID, count, xy, inf); };
+            user = ctx->comm;
+        }
         if (combine)
             cb = [&](pmhost::G1Point<C> *pts, int count) -> int {
                 uint64_t xy[2][sizeof(pm::Affine<C>) / 8];
@@ -70,7 +74,7 @@ extern "C" int pm_host_prove_sharded(pm_ctx *ctx, const pm_pk *pk, int transcrip
                                      uint8_t *proof_bytes, size_t capacity, size_t *proof_len) {
     if (!ctx || !pk || !instance_host || !x || !r_a || !proof_bytes || (pk->mw && !w)) return PM_ERR_INVALID_ARG;
     if (pk->device != ctx->device) return PM_ERR_INVALID_ARG;
-    if (pk->shard_count != 1 && !combine) return PM_ERR_INVALID_ARG;   // a shard's points are partial sums: somebody has to add them
+    if (pk->shard_count != 1 && !combine && !ctx->comm) return PM_ERR_INVALID_ARG;   // a shard's points are partial sums: somebody has to add them
     if (hipSetDevice(ctx->device) != hipSuccess) return PM_ERR_HIP;
     return pk->curve == PM_BLS12_381
                ? host_prove_curve<pm::BlsCurve>(ctx, pk, transcript, instance_host, x, w, assignment_on_device, r_a, combine, user, proof_bytes, capacity, proof_len)

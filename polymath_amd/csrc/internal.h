@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/polymath_hip.h"
+#include "../host/layout.hpp"
 #include "ec.cuh"
 
 namespace pm {
@@ -97,6 +98,7 @@ struct MsmTables {
 struct TwiddleCache {
     int curve = -1;
     unsigned log_n = 0;
+    unsigned long long stamp = 0;   // last use (LRU eviction)
     DevBuf fwd, inv;          // n/2 twiddles each, standard Montgomery form
     DevBuf fwd_int, inv_int;  // the same powers in the reduced-radix internal form (ntt.hip butterflies)
 };
@@ -135,6 +137,20 @@ struct pm_pk {
     // stored at d_bases + res_dev_off[k]
     uint64_t res_lo[3], res_hi[3], res_dev_off[3];
     uint64_t msm_lo[3], msm_len[3];  // logical pair range of each merged MSM inside the concatenation
+    // Generalisation of [res_lo, res_hi): MSM k's resident pairs are `pieces[k]` (ranges of the logical concatenation),
+    // stored back to back at d_bases + res_dev_off[k]; res_cnt[k] = their total.  layout 0 (PM_SHARD_PAIRS): one
+    // contiguous piece per MSM, the prover's scalar vectors are whole and this rank reads them at res_lo[k].
+    // layout 1 (PM_SHARD_VECTOR, host/layout.hpp): the pieces follow the blocked coefficient layout, the prover builds
+    // only this rank's scalars (in piece order) and `segs` is this rank's part of the quotient index space.
+    int layout;
+    std::vector<pmlayout::Piece> pieces[3];
+    uint64_t res_cnt[3];
+    std::vector<pmlayout::Segment> segs;
+    uint64_t max_seg;
+    struct SegRef { uint64_t a, b; uint32_t rank, idx; };
+    std::vector<SegRef> all_segs;    // the segments of ALL ranks in increasing index order (the carry chain of the division scan)
+    size_t seg_slots;                // max over ranks of the segment count
+    void *d_segs;                    // device copy of `segs`
     // Window tables, ONE SET PER MERGED MSM (its own window width: the optimum depends on the pair count):
     // d_tab[k] holds [nwin_k][res_hi[k] - res_lo[k]] points, window 0 being a copy of the MSM's resident slice.
     pm::MsmTables tables[3];
@@ -154,8 +170,10 @@ struct pm_ctx {
     double timing_ms[pm::T_NUM_SLOTS];
     hipEvent_t ev_sc_a;       // recorded when the [a]_1 scalars are ready (prove.hip: the helper stream waits on it)
     pm::MsmWorkspace msm;
-    pm::TwiddleCache tw[4];
+    pm::TwiddleCache tw[8];   // the sharded prover works with log m, log n and log 2n tables of both directions
+    unsigned long long tw_clock;
     pm::DevBuf scratch, flags;
+    pm_comm *comm;            // this rank's communicator (pm_ctx_set_comm); null on single-GPU contexts
     pm_ctx *aux;              // helper context (own stream + MSM workspace) for the second of two concurrent MSMs
     pm::DevBuf fb_table[2];   // setup.hip: 8-bit-window multiples of the G1 generator, per curve id (built on first use)
     // proof in flight
@@ -163,6 +181,11 @@ struct pm_ctx {
     int phase;
     bool keep_timings;   // pm_host_prove: the stage slots accumulate over the three phases of one proof
     pm::DevBuf xw, ue, we, u, w, wit_u, u2, sc_a, sc_c, quotient, ztail, lvl[6], ra;
+    // PM_SHARD_VECTOR prover (prove_sharded.hip): transform temporaries, halo coefficients, roots of the cross-rank butterfly
+    pm::DevBuf sh_a, sh_b, sh_c, halo, shard_roots;
+    uint64_t shard_roots_n;
+    uint32_t shard_roots_N;
+    int shard_roots_curve;
 };
 
 namespace pm {
@@ -216,6 +239,10 @@ template <class C>
 int powers_fill(pm_ctx *ctx, Fp<typename C::FrP> *d_out, size_t count, const Fp<typename C::FrP> &scale,
                 const Fp<typename C::FrP> &x);
 
+// MSM `which` (0 = a, 1 = c, 2 = d) over this rank's resident pairs; d_scalars in the order of pk->pieces[which]
+template <class C>
+int msm_resident(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars, uint64_t *out_xy, int *out_inf);
+
 template <class C>
 int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
                       uint64_t *a_xy, int *a_inf, uint64_t *c_xy, int *c_inf, bool assignment_on_device);
@@ -224,6 +251,15 @@ int prove_phase2_impl(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
 template <class C>
 int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
                       const uint64_t *c_at_x1, uint64_t *d_xy, int *d_inf);
+
+template <class C>
+int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a, uint64_t *a_xy, int *a_inf,
+                         uint64_t *c_xy, int *c_inf, bool assignment_on_device);
+template <class C>
+int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
+template <class C>
+int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1, const uint64_t *c_at_x1, uint64_t *d_xy,
+                         int *d_inf);
 
 inline void timing_reset(pm_ctx *ctx) {
     for (int i = 0; i < T_NUM_SLOTS; ++i) ctx->timing_ms[i] = 0;

@@ -134,9 +134,13 @@ int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C:
     TwiddleCache *slot = nullptr;
     for (auto &t : ctx->tw)
         if (t.curve == cid && t.log_n == log_n) slot = &t;
+    if (slot) slot->stamp = ++ctx->tw_clock;
     if (!slot) {
-        // evict round-robin: slot index by log_n parity keeps n and 2n tables both resident
-        slot = &ctx->tw[(log_n & 1) + 2 * (cid & 1)];
+        // evict the least recently used table
+        slot = &ctx->tw[0];
+        for (auto &t : ctx->tw)
+            if (t.stamp < slot->stamp) slot = &t;
+        slot->stamp = ++ctx->tw_clock;
         slot->curve = cid;
         slot->log_n = log_n;
         size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;

@@ -9,28 +9,9 @@
 #include <thread>
 
 #include "internal.h"
+#include "prove_common.cuh"
 
 namespace pm {
-
-// --------------------------------------------------------------------------- witness map
-// rows 2m0+r and 2m0+nr+r of (U z, W z) and y_{m0+r} = ((A-B) xw)_r^2  (prover.rs:279-302,
-// common.rs:138-207).  CSR values are Montgomery Fr.
-template <class P>
-__device__ __forceinline__ Fp<P> csr_row_dot(const uint64_t *rowptr, const uint32_t *col, const uint64_t *val,
-                                             const Fp<P> *z, uint64_t r) {
-    Fp<P> acc = Fp<P>::zero();
-    for (uint64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-        Fp<P> v = *(const Fp<P> *)(val + 4 * k);
-        acc = add<P>(acc, mul<P>(v, z[col[k]]));
-    }
-    return acc;
-}
-
-struct CsrDev {
-    const uint64_t *rowptr;
-    const uint32_t *col;
-    const uint64_t *val;
-};
 
 template <class P>
 __global__ void k_witness_rows(CsrDev A, CsrDev B, CsrDev Cm, const Fp<P> *xw, Fp<P> *ue, Fp<P> *we, Fp<P> *y,
@@ -239,15 +220,6 @@ __global__ __launch_bounds__(256) void k_sum_small(const Fp<P> *in, unsigned cou
 //   3s + [0,n)       x2 * witness_u                          (prover.rs:168-171)
 //   5s + [0,n+1)     u + x2 * 2 r_a u  - (a + x2 c) at +0    (prover.rs:145-152,366-368,196-197)
 //   8s + [0,2n-1)    x2 * u^2     (witness_w + (u^2 - w) = u^2: N6 == N2)
-struct NumParams {
-    uint64_t n, sigma, len;
-};
-
-template <class P>
-struct NumConsts {
-    Fp<P> x2, r0, r1, x2r0, x2r1, b2[3], two_x2_r0, two_x2_r1, minus_const;
-};
-
 template <class P>
 __device__ __forceinline__ Fp<P> numerator_at(uint64_t k, const NumParams &np, const NumConsts<P> &nc, const Fp<P> *u,
                                               const Fp<P> *wit_u, const Fp<P> *u2) {
@@ -349,39 +321,28 @@ __global__ void k_div_expand0(NumParams np, NumConsts<P> nc, const Fp<P> *u, con
     }
 }
 
-// ------------------------------------------------------------------------------- helpers
-template <class P>
-static Fp<P> load_fr(const uint64_t *p) {
-    Fp<P> r;
-    memcpy(r.l, p, sizeof(r.l));
-    return r;
-}
+// MSM `which` over THIS rank's resident pairs.  d_scalars: the rank's scalars in the order of pk->pieces[which].
 template <class C>
-static void store_affine_host(const Affine<C> &a, int inf, uint64_t *xy, int *out_inf) {
-    if (inf) memset(xy, 0, sizeof(Affine<C>));
-    else memcpy(xy, &a, sizeof(Affine<C>));
-    *out_inf = inf;
-}
-
-static inline unsigned nblk(uint64_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
-
-template <class C>
-static int msm_shard(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars, uint64_t *out_xy,
-                     int *out_inf) {
-    // logical pair range [0, msm_len) of MSM `which`; this device holds [res_lo, res_hi)
-    uint64_t lo = pk->res_lo[which], hi = pk->res_hi[which];
+int msm_resident(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars, uint64_t *out_xy, int *out_inf) {
     const Affine<C> *bases = (const Affine<C> *)pk->d_bases + pk->res_dev_off[which];
     Affine<C> r;
     int inf = 1;
-    if (pk->tables[which].c) {   // this MSM's own window tables (window 0 = its resident slice)
+    if (pk->tables[which].c) {   // this MSM's own window tables (window 0 = its resident pairs)
         MsmTables tb = pk->tables[which];
         tb.base_index = 0;
-        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)nullptr, d_scalars + lo, (size_t)(hi - lo), &r, &inf, &tb));
+        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)nullptr, d_scalars, (size_t)pk->res_cnt[which], &r, &inf, &tb));
     } else {
-        PM_TRY(msm_run<C>(ctx, bases, d_scalars + lo, (size_t)(hi - lo), &r, &inf));
+        PM_TRY(msm_run<C>(ctx, bases, d_scalars, (size_t)pk->res_cnt[which], &r, &inf));
     }
     store_affine_host<C>(r, inf, out_xy, out_inf);
     return PM_OK;
+}
+
+// PM_SHARD_PAIRS: the scalar vector is the whole logical one; this rank's pairs are the contiguous range at res_lo
+template <class C>
+static int msm_shard(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars, uint64_t *out_xy,
+                     int *out_inf) {
+    return msm_resident<C>(ctx, pk, which, d_scalars + pk->res_lo[which], out_xy, out_inf);
 }
 
 // ------------------------------------------------------------------------------- phase 1
@@ -579,18 +540,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     PM_HIP(ctx, hipMemcpyAsync(rah, ctx->ra.p, sizeof(rah), hipMemcpyDeviceToHost, st));
     PM_HIP(ctx, hipStreamSynchronize(st));
     NumParams np{n, sigma, 8 * sigma + 2 * n - 1};
-    NumConsts<P> nc;
-    nc.x2 = x2;
-    nc.r0 = rah[0];
-    nc.r1 = rah[1];
-    nc.x2r0 = mul<P>(x2, rah[0]);
-    nc.x2r1 = mul<P>(x2, rah[1]);
-    nc.b2[0] = add<P>(rah[0], mul<P>(x2, sqr<P>(rah[0])));
-    nc.b2[1] = add<P>(rah[1], mul<P>(x2, dbl<P>(mul<P>(rah[0], rah[1]))));
-    nc.b2[2] = mul<P>(x2, sqr<P>(rah[1]));
-    nc.two_x2_r0 = dbl<P>(nc.x2r0);
-    nc.two_x2_r1 = dbl<P>(nc.x2r1);
-    nc.minus_const = neg<P>(add<P>(a_at, mul<P>(x2, c_at)));
+    const NumConsts<P> nc = make_num_consts<P>(x2, rah, a_at, c_at);
     // levels of the chunked recurrence
     const unsigned L = 32;
     uint64_t cnt[8];
@@ -657,6 +607,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
 }
 
 #define PM_INST(C)                                                                                                     \
+    template int msm_resident<C>(pm_ctx *, const pm_pk *, int, const Fp<typename C::FrP> *, uint64_t *, int *);        \
     template int prove_phase1_impl<C>(pm_ctx *, const pm_pk *, const uint64_t *, const uint64_t *, const uint64_t *,   \
                                       uint64_t *, int *, uint64_t *, int *, bool);                                         \
     template int prove_phase2_impl<C>(pm_ctx *, const uint64_t *, uint64_t *);                                         \

@@ -1,0 +1,709 @@
+// create_proof_with_assignment (/root/reference/src/prover.rs:66-237) with the VECTOR phases sharded over N GPUs
+// (BASELINE.json configs[3]; layout: polymath_amd/host/layout.hpp):
+//   witness map       each rank evaluates the rows i = N j + q it owns (prover.rs:245-302, common.rs:138-207)   row 3
+//   iNTT / NTT        N local size-n/N transforms + ONE all-to-all + a size-N butterfly (prover.rs:239-243,:315-328) row 2
+//   pointwise, h      local on the blocked coefficient layout (prover.rs:104-108, 321-323)                          row 4
+//   u(x1)             per-rank partial Horner sums, all-gather of N values (prover.rs:132)                          row 5
+//   division scan     per-segment values, all-gather, carries folded on every rank, local expansion (:211-225)     row 6
+//   MSMs              the pairs follow the coefficients: no scalar moves between GPUs (prover.rs:118-123, 229)     row 1
+// Same three phases, same outputs (partial points) as prove.hip; every rank returns the same status because the
+// check flags are exchanged before any rank decides.
+#include <thread>
+
+#include "comm.h"
+#include "internal.h"
+#include "prove_common.cuh"
+
+namespace pm {
+
+using pmlayout::Layout;
+using pmlayout::Segment;
+
+// omega^e from the half-size table tw[j] = omega^j, j < n/2 (omega^(n/2) = -1)
+template <class P>
+__device__ __forceinline__ Fp<P> tw_pow(const Fp<P> *tw, uint64_t n, uint64_t e) {
+    e &= n - 1;
+    const uint64_t half = n >> 1;
+    return e < half ? tw[e] : neg<P>(tw[e - half]);
+}
+
+template <class P>
+__global__ void k_check_sap_L(const Fp<P> *ue, const Fp<P> *we, uint64_t count, unsigned *flags) {   // (Uz)^2 == Wz, prover.rs:108
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && !sqr<P>(ue[i]).eq(we[i])) atomicOr(flags, 1u);
+}
+template <class P>
+__global__ void k_square_L(Fp<P> *a, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) a[i] = sqr<P>(a[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ witness map
+// Row i = N j + q of (U z, W z): the closed form of SURVEY.md App. A (k_witness_head / k_witness_rows of prove.hip, one
+// row at a time).  Second-half rows recompute (A - B) z: 2 dot products more per rank instead of an exchange.
+template <class P>
+__device__ __forceinline__ void sap_row(const CsrDev &A, const CsrDev &B, const CsrDev &Cm, const Fp<P> *xw, uint64_t m0, uint64_t nr,
+                                        uint64_t i, Fp<P> &u, Fp<P> &w) {
+    const Fp<P> one = Fp<P>::one();
+    u = Fp<P>::zero();
+    w = Fp<P>::zero();
+    if (i < 2 * m0) {
+        if (i == 0) {
+            u = dbl<P>(one);
+            w = dbl<P>(u);
+        } else if (i < m0) {
+            const Fp<P> xi = xw[i], omx = sub<P>(one, xi);
+            u = add<P>(one, xi);
+            w = add<P>(dbl<P>(dbl<P>(xi)), sqr<P>(omx));
+        } else if (i > m0) {
+            const Fp<P> omx = sub<P>(one, xw[i - m0]);
+            u = omx;
+            w = sqr<P>(omx);
+        }
+    } else if (i < 2 * m0 + nr) {
+        const uint64_t r = i - 2 * m0;
+        const Fp<P> az = csr_row_dot<P>(A.rowptr, A.col, A.val, xw, r), bz = csr_row_dot<P>(B.rowptr, B.col, B.val, xw, r);
+        const Fp<P> cz = csr_row_dot<P>(Cm.rowptr, Cm.col, Cm.val, xw, r), d = sub<P>(az, bz);
+        u = add<P>(az, bz);
+        w = add<P>(dbl<P>(dbl<P>(cz)), sqr<P>(d));
+    } else if (i < 2 * m0 + 2 * nr) {
+        const uint64_t r = i - 2 * m0 - nr;
+        const Fp<P> d = sub<P>(csr_row_dot<P>(A.rowptr, A.col, A.val, xw, r), csr_row_dot<P>(B.rowptr, B.col, B.val, xw, r));
+        u = d;
+        w = sqr<P>(d);
+    }
+}
+
+template <class P>
+__global__ void k_witness_cyclic(CsrDev A, CsrDev B, CsrDev Cm, const Fp<P> *xw, Fp<P> *ue, Fp<P> *we, uint64_t m0, uint64_t nr, Layout L) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= L.m) return;
+    Fp<P> u, w;
+    sap_row<P>(A, B, Cm, xw, m0, nr, pmlayout::eval_global(L, j), u, w);
+    ue[j] = u;
+    we[j] = w;
+}
+
+// the first `count` rows of U z (public-input rows): every rank needs them for the witness-only part of u
+template <class P>
+__global__ void k_ue_head(CsrDev A, CsrDev B, CsrDev Cm, const Fp<P> *xw, Fp<P> *head, uint64_t m0, uint64_t nr, unsigned count) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fp<P> u, w;
+    sap_row<P>(A, B, Cm, xw, m0, nr, i, u, w);
+    head[i] = u;
+}
+
+// z_tail[lo .. hi) = (x || w || y)[lo .. hi)  (prover.rs:75-80, 279-302): this rank's slice of the [c]_1 scalars
+template <class P>
+__global__ void k_ztail_slice(CsrDev A, CsrDev B, const Fp<P> *xw, Fp<P> *out, uint64_t m0, uint64_t mw, uint64_t lo, uint64_t hi) {
+    const uint64_t t = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= hi) return;
+    Fp<P> v;
+    if (t < m0 + mw) {
+        v = xw[t];
+    } else {
+        const uint64_t i = t - (m0 + mw);
+        if (i < m0) {
+            v = i ? sqr<P>(sub<P>(Fp<P>::one(), xw[i])) : Fp<P>::zero();
+        } else {
+            const uint64_t r = i - m0;
+            v = sqr<P>(sub<P>(csr_row_dot<P>(A.rowptr, A.col, A.val, xw, r), csr_row_dot<P>(B.rowptr, B.col, B.val, xw, r)));
+        }
+    }
+    out[t - lo] = v;
+}
+
+// --------------------------------------------------------------------------------------- distributed transform
+// The size-N butterfly across what used to be ranks.  in[i][b], out[o][b]  (i, o < N; b < B):
+//   out[o][b] = scale * omega^(o k2) * sum_i roots[i o mod N] * (omega^(i k2) in[i][b]),   k2 = k2_base + b,
+// the omega^(..) factors taken from `tw` (forward or inverse table of the size-n domain) when the flag is set:
+//   inverse transform: twiddle on the INPUT side (i = sending rank), roots = (omega^-m)^t, scale = 1/N;
+//   forward transform: twiddle on the OUTPUT side (o = receiving rank), roots = (omega^m)^t.
+template <class P>
+__global__ void k_cross_dft(const Fp<P> *in, Fp<P> *out, const Fp<P> *roots, uint32_t N, uint64_t B, const Fp<P> *tw, uint64_t n,
+                            uint64_t k2_base, int in_twiddle, int out_twiddle, Fp<P> scale, int use_scale) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (uint64_t)N * B) return;
+    const uint64_t o = g / B, b = g % B, k2 = k2_base + b;
+    Fp<P> acc = in[b];
+    for (uint32_t i = 1; i < N; ++i) {
+        Fp<P> v = in[(uint64_t)i * B + b];
+        if (in_twiddle) v = mul<P>(v, tw_pow<P>(tw, n, (uint64_t)i * k2));
+        const uint32_t e = (uint32_t)((i * o) & (N - 1));
+        acc = add<P>(acc, e ? mul<P>(v, roots[e]) : v);
+    }
+    if (use_scale) acc = mul<P>(acc, scale);
+    if (out_twiddle && o) acc = mul<P>(acc, tw_pow<P>(tw, n, o * k2));
+    out[o * B + b] = acc;
+}
+
+template <class C>
+static int shard_roots(pm_ctx *ctx, const pm_pk *pk, const Fp<typename C::FrP> **fwd, const Fp<typename C::FrP> **inv) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    const uint32_t N = (uint32_t)pk->shard_count;
+    if (ctx->shard_roots_n != pk->n || ctx->shard_roots_N != N || ctx->shard_roots_curve != C::ID) {
+        Fr omega;
+        memcpy(omega.l, pk->omega, 32);
+        const Fr wm = pow_u64<P>(omega, pk->n / N), wmi = inverse<P>(wm);
+        std::vector<Fr> h(2 * (size_t)N);
+        h[0] = Fr::one();
+        h[N] = Fr::one();
+        for (uint32_t t = 1; t < N; ++t) {
+            h[t] = mul<P>(h[t - 1], wm);
+            h[N + t] = mul<P>(h[N + t - 1], wmi);
+        }
+        PM_HIP(ctx, ctx->shard_roots.reserve(h.size() * sizeof(Fr)));
+        PM_HIP(ctx, hipMemcpyAsync(ctx->shard_roots.p, h.data(), h.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->shard_roots_n = pk->n;
+        ctx->shard_roots_N = N;
+        ctx->shard_roots_curve = C::ID;
+    }
+    *fwd = ctx->shard_roots.as<Fr>();
+    *inv = *fwd + N;
+    return PM_OK;
+}
+
+// evaluations (cyclic, `x`, destroyed) -> coefficients (blocked, `y`); `tmp`: m elements of scratch
+template <class C>
+static int dist_intt(pm_ctx *ctx, const pm_pk *pk, const Layout &L, Fp<typename C::FrP> *x, Fp<typename C::FrP> *tmp, Fp<typename C::FrP> *y) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    unsigned log_m = 0;
+    while (((uint64_t)1 << log_m) < L.m) ++log_m;
+    PM_TRY(ntt_run<C>(ctx, x, log_m, true));                                    // N local transforms (this rank's), scaled by 1/m
+    StageTimer t(ctx, T_NTT);
+    const int st = ctx->comm->all_to_all(x, tmp, (size_t)L.B * sizeof(Fr), ctx->stream);   // block p -> rank p
+    if (st) { ctx->err = "all_to_all: " + ctx->comm->err; return st; }
+    const Fr *rf = nullptr, *ri = nullptr, *tw = nullptr;
+    PM_TRY(shard_roots<C>(ctx, pk, &rf, &ri));
+    PM_TRY(twiddles_get<C>(ctx, pk->log_n, true, &tw));
+    const Fr ninv = inverse<P>(from_u64<P>(L.N));
+    hipLaunchKernelGGL(k_cross_dft<P>, dim3(nblk(L.m)), dim3(256), 0, ctx->stream, (const Fr *)tmp, y, ri, L.N, L.B, tw, L.n,
+                       (uint64_t)L.q * L.B, 1, 0, ninv, 1);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+}
+
+// coefficients (blocked, `y`, kept) -> evaluations (cyclic, `x`); `tmp`: m elements of scratch
+template <class C>
+static int dist_ntt(pm_ctx *ctx, const pm_pk *pk, const Layout &L, const Fp<typename C::FrP> *y, Fp<typename C::FrP> *tmp, Fp<typename C::FrP> *x) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    unsigned log_m = 0;
+    while (((uint64_t)1 << log_m) < L.m) ++log_m;
+    {
+        StageTimer t(ctx, T_NTT);
+        const Fr *rf = nullptr, *ri = nullptr, *tw = nullptr;
+        PM_TRY(shard_roots<C>(ctx, pk, &rf, &ri));
+        PM_TRY(twiddles_get<C>(ctx, pk->log_n, false, &tw));
+        hipLaunchKernelGGL(k_cross_dft<P>, dim3(nblk(L.m)), dim3(256), 0, ctx->stream, y, tmp, rf, L.N, L.B, tw, L.n, (uint64_t)L.q * L.B, 0,
+                           1, Fr::one(), 0);
+        PM_HIP(ctx, hipGetLastError());
+        const int st = ctx->comm->all_to_all(tmp, x, (size_t)L.B * sizeof(Fr), ctx->stream);   // block r -> rank r
+        if (st) { ctx->err = "all_to_all: " + ctx->comm->err; return st; }
+    }
+    return ntt_run<C>(ctx, x, log_m, false);
+}
+
+// ------------------------------------------------------------------------------------- pointwise, blocked layout
+template <class P>
+__global__ void k_twist_L(const Fp<P> *u, const Fp<P> *psi_pow, Fp<P> *out, Layout L) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < L.m) out[p] = mul<P>(u[p], psi_pow[pmlayout::coeff_global(L, p)]);
+}
+template <class P>
+__global__ void k_untwist_combine_L(const Fp<P> *neg_tw, const Fp<P> *psi_inv_pow, const Fp<P> *w, Fp<P> *lo, Fp<P> *hi, Layout L, Fp<P> half) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L.m) return;
+    const Fp<P> neg = mul<P>(neg_tw[p], psi_inv_pow[pmlayout::coeff_global(L, p)]), wk = w[p];
+    lo[p] = mul<P>(add<P>(wk, neg), half);
+    hi[p] = mul<P>(sub<P>(wk, neg), half);
+}
+// wit_u[k] = u[k] - n^-1 sum_{j < head} ue[j] w^(-jk)  (k_wit_u_sparse of prove.hip at the global index of p)
+template <class P>
+__global__ void k_wit_u_sparse_L(const Fp<P> *u, const Fp<P> *ue_head, const Fp<P> *winv, Fp<P> ninv, unsigned head, Fp<P> *wit_u, Layout L) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L.m) return;
+    const Fp<P> wk = tw_pow<P>(winv, L.n, pmlayout::coeff_global(L, p));
+    Fp<P> s = ue_head[head - 1];
+    for (int j = (int)head - 2; j >= 0; --j) s = add<P>(mul<P>(s, wk), ue_head[j]);
+    wit_u[p] = sub<P>(u[p], mul<P>(s, ninv));
+}
+template <class P>
+__global__ void k_zero_head_cyclic(Fp<P> *ue, uint64_t zero_rows, Layout L) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < L.m && pmlayout::eval_global(L, j) < zero_rows) ue[j] = Fp<P>::zero();
+}
+
+// This rank's [c]_1 scalars after the z_tail slice (layout.hpp: pieces_c):  h blocks | 2 r_a u blocks of B + 1 | constants
+template <class P>
+__global__ void k_phase1_scalars_L(const Fp<P> *u, const Fp<P> *u2hi, const Fp<P> *ra, Fp<P> *sc_h, Fp<P> *sc_ru, Fp<P> *sc_tail, Layout L,
+                                   unsigned *flags) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const Fp<P> r0 = ra[0], r1 = ra[1];
+    if (p < L.m) {
+        const uint64_t k = pmlayout::coeff_global(L, p), k1 = p / L.B, b = p % L.B;
+        const Fp<P> hi = u2hi[p];
+        if (k < L.n - 1) {
+            sc_h[p] = hi;
+            if (!hi.is_zero()) atomicOr(flags, 4u);
+        } else if (!hi.is_zero()) {
+            atomicOr(flags, 2u);                       // deg h > n - 2  (prover.rs:107)
+        }
+        Fp<P> t = mul<P>(r0, u[p]);
+        if (b) t = add<P>(t, mul<P>(r1, u[p - 1]));
+        Fp<P> *blk = sc_ru + k1 * (L.B + 1);
+        blk[b] = dbl<P>(t);
+        if (b == L.B - 1) blk[L.B] = dbl<P>(mul<P>(r1, u[p]));   // the pair (2 r1 u_{e-1}, X_e) of the next block's first base
+    }
+    if (p == 0 && sc_tail) {
+        sc_tail[0] = sqr<P>(r0);
+        sc_tail[1] = dbl<P>(mul<P>(r0, r1));
+        sc_tail[2] = sqr<P>(r1);
+        sc_tail[3] = r0;
+        sc_tail[4] = r1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ Horner (phase 2)
+// lane t owns Lh consecutive LOCAL coefficients (Lh divides B: a lane never straddles a block)
+template <class P>
+__global__ __launch_bounds__(256) void k_horner_partial_L(const Fp<P> *u, Layout L, Fp<P> x1, unsigned Lh, Fp<P> *partials) {
+    __shared__ Fp<P> sh[256];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo = t * Lh;
+    Fp<P> acc = Fp<P>::zero();
+    if (lo < L.m) {
+        for (uint64_t k = lo + Lh; k-- > lo;) acc = add<P>(mul<P>(acc, x1), u[k]);
+        acc = mul<P>(acc, pow_u64<P>(x1, pmlayout::coeff_global(L, lo)));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = add<P>(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+// out[0] = sum of `count` partials; out[1 + k1] = the last coefficient of block k1 (the halo the next block's owner needs)
+template <class P>
+__global__ __launch_bounds__(256) void k_phase2_pack(const Fp<P> *partials, unsigned count, const Fp<P> *u, Layout L, Fp<P> *out) {
+    __shared__ Fp<P> sh[256];
+    Fp<P> acc = Fp<P>::zero();
+    for (unsigned i = threadIdx.x; i < count; i += 256) acc = add<P>(acc, partials[i]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = add<P>(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+    if (threadIdx.x < L.N) out[1 + threadIdx.x] = u[(uint64_t)threadIdx.x * L.B + L.B - 1];
+}
+
+// ----------------------------------------------------------------------------------- division scan (phase 3)
+struct SegData {   // what numerator_seg reads
+    uint64_t n, sigma;
+};
+
+// numerator coefficient at index a + j of segment g (numerator_at of prove.hip on this rank's local arrays)
+template <class P>
+__device__ __forceinline__ Fp<P> numerator_seg(const Segment &g, uint64_t j, const SegData &sd, const NumConsts<P> &nc, const Fp<P> *u,
+                                               const Fp<P> *wit_u, const Fp<P> *u2lo, const Fp<P> *u2hi, const Fp<P> *halo) {
+    switch (g.kind) {
+        case pmlayout::SEG_WITU: return mul<P>(nc.x2, wit_u[g.loc0 + j]);
+        case pmlayout::SEG_U2LO: return mul<P>(nc.x2, u2lo[g.loc0 + j]);
+        case pmlayout::SEG_U2HI: return mul<P>(nc.x2, u2hi[g.loc0 + j]);
+        case pmlayout::SEG_U: {
+            const uint64_t i = g.a + j - 5 * sd.sigma;
+            Fp<P> t = Fp<P>::zero();
+            if (i < sd.n) {
+                const Fp<P> ui = u[g.loc0 + j];
+                t = add<P>(ui, mul<P>(nc.two_x2_r0, ui));
+            }
+            if (i > 0) {
+                const Fp<P> prev = (j == 0 && g.halo) ? halo[g.halo - 1] : u[g.loc0 + j - 1];
+                t = add<P>(t, mul<P>(nc.two_x2_r1, prev));
+            } else {
+                t = add<P>(t, nc.minus_const);
+            }
+            return t;
+        }
+        default: {
+            const uint64_t k = g.a + j;
+            if (k == 0) return nc.x2r0;
+            if (k == 1) return nc.x2r1;
+            if (k >= 2 * sd.sigma && k < 2 * sd.sigma + 3) return nc.b2[k - 2 * sd.sigma];
+            return Fp<P>::zero();
+        }
+    }
+}
+
+constexpr unsigned SEG_THREADS = 1024;
+
+// One workgroup per segment.  Lane t owns the `span` consecutive indices from a + t span:  v_t = their local Horner
+// value; V = sum_t v_t x1^(t span) is the segment's value H_a with carry-in 0.  v_t is kept for the expansion.
+template <class P>
+__global__ __launch_bounds__(SEG_THREADS) void k_seg_reduce(const Segment *segs, SegData sd, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u,
+                                                            const Fp<P> *u2lo, const Fp<P> *u2hi, const Fp<P> *halo, Fp<P> x1, Fp<P> *lane_vals,
+                                                            Fp<P> *V) {
+    __shared__ Fp<P> sh[SEG_THREADS];
+    const Segment g = segs[blockIdx.x];
+    const uint64_t len = g.b - g.a, span = (len + SEG_THREADS - 1) / SEG_THREADS;
+    const uint64_t lo = (uint64_t)threadIdx.x * span;
+    uint64_t hi = lo + span;
+    if (hi > len) hi = len;
+    Fp<P> acc = Fp<P>::zero();
+    if (lo < len) {
+        for (uint64_t j = hi; j-- > lo;) acc = add<P>(mul<P>(acc, x1), numerator_seg<P>(g, j, sd, nc, u, wit_u, u2lo, u2hi, halo));
+    }
+    lane_vals[(size_t)blockIdx.x * SEG_THREADS + threadIdx.x] = acc;
+    sh[threadIdx.x] = lo < len ? mul<P>(acc, pow_u64<P>(x1, lo)) : acc;
+    __syncthreads();
+    for (unsigned off = SEG_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = add<P>(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) V[blockIdx.x] = sh[0];
+}
+
+// carry[s] = H_b of segment s (from the chain over ALL ranks' segment values).  Suffix scan of the lane values with the
+// constant multiplier X = x1^span (every lane but the last active one owns a full span; the carry-in is folded into the
+// last lane's value), then every lane re-walks its span and writes q_{k-1} = H_k.
+template <class P>
+__global__ __launch_bounds__(SEG_THREADS) void k_seg_expand(const Segment *segs, SegData sd, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u,
+                                                            const Fp<P> *u2lo, const Fp<P> *u2hi, const Fp<P> *halo, Fp<P> x1,
+                                                            const Fp<P> *lane_vals, const Fp<P> *carry, Fp<P> *q) {
+    __shared__ Fp<P> sh[SEG_THREADS];
+    const Segment g = segs[blockIdx.x];
+    const uint64_t len = g.b - g.a, span = (len + SEG_THREADS - 1) / SEG_THREADS;
+    const unsigned t = threadIdx.x, active = (unsigned)((len + span - 1) / span);
+    const uint64_t lo = (uint64_t)t * span;
+    uint64_t hi = lo + span;
+    if (hi > len) hi = len;
+    const Fp<P> cin = carry[blockIdx.x];
+    Fp<P> w = Fp<P>::zero();
+    if (t < active) {
+        w = lane_vals[(size_t)blockIdx.x * SEG_THREADS + t];
+        if (t == active - 1) w = add<P>(w, mul<P>(cin, pow_u64<P>(x1, hi - lo)));
+    }
+    sh[t] = w;
+    __syncthreads();
+    Fp<P> Xd = pow_u64<P>(x1, span);
+    for (unsigned d = 1; d < SEG_THREADS; d <<= 1) {      // W_t = sum_{t' >= t} w_t' X^(t' - t)
+        Fp<P> add_in = Fp<P>::zero();
+        const bool take = t + d < active;
+        if (take) add_in = mul<P>(sh[t + d], Xd);
+        __syncthreads();
+        if (take) sh[t] = add<P>(sh[t], add_in);
+        __syncthreads();
+        Xd = sqr<P>(Xd);
+    }
+    if (t >= active) return;
+    Fp<P> acc = t + 1 < active ? sh[t + 1] : cin;          // H at this lane's upper end
+    const uint64_t skip = g.a == 0 ? 1 : 0;                // index 0 is the remainder, not a quotient coefficient
+    for (uint64_t j = hi; j-- > lo;) {
+        acc = add<P>(mul<P>(acc, x1), numerator_seg<P>(g, j, sd, nc, u, wit_u, u2lo, u2hi, halo));
+        if (g.a + j > 0) q[g.qoff + j - skip] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- helpers
+static int require_comm(pm_ctx *ctx, const pm_pk *pk) {
+    if (!ctx->comm || ctx->comm->world != pk->shard_count || ctx->comm->rank != pk->shard_rank) {
+        ctx->err = "a PM_SHARD_VECTOR key needs pm_ctx_set_comm with this rank's communicator";
+        return PM_ERR_STATE;
+    }
+    return PM_OK;
+}
+
+// OR of a flag word over all ranks: every rank then takes the same decision (and reaches the same collectives)
+static int flags_or(pm_ctx *ctx, unsigned *flags) {
+    const int W = ctx->comm->world;
+    std::vector<unsigned> all(W);
+    const int st = ctx->comm->all_gather(flags, all.data(), sizeof(unsigned), ctx->stream);
+    if (st) { ctx->err = "all_gather: " + ctx->comm->err; return st; }
+    for (int r = 0; r < W; ++r) *flags |= all[r];
+    return PM_OK;
+}
+
+struct PhaseEnd {   // every return path hands the turn on (local serialised emulation); no-op for RCCL
+    pm_comm *c;
+    ~PhaseEnd() { if (c) c->phase_end(); }
+};
+
+// ------------------------------------------------------------------------------------------------- phase 1
+template <class C>
+int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a, uint64_t *a_xy, int *a_inf,
+                         uint64_t *c_xy, int *c_inf, bool assignment_on_device) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    PM_TRY(require_comm(ctx, pk));
+    PhaseEnd phase_end{ctx->comm};
+    const uint64_t n = pk->n, m0 = pk->m0, mw = pk->mw, nr = pk->nr, Lz = 2 * m0 + mw + nr;
+    if (pk->log_n + 1 > (unsigned)C::TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;   // prover.rs:317
+    const Layout L = pmlayout::make_layout(n, (uint32_t)pk->shard_count, (uint32_t)pk->shard_rank);
+    const uint64_t m = L.m, B = L.B;
+    const uint32_t N = L.N, q = L.q;
+    hipStream_t st = ctx->stream;
+    if (!ctx->keep_timings) timing_reset(ctx);
+    ctx->pk = pk;
+    ctx->phase = 0;
+    TimingGuard timing_guard{ctx};
+    StageTimer t_phase(ctx, T_PHASE);
+    const uint64_t zl = pmlayout::ztail_lo(Lz, N, q), zh = pmlayout::ztail_lo(Lz, N, q + 1), zcnt = zh - zl;
+    const uint64_t hcnt = m - (q == N - 1 ? 1 : 0), rucnt = (uint64_t)N * (B + 1), tail = q == 0 ? 5 : 0;
+    const uint64_t len_c = zcnt + hcnt + rucnt + tail;
+    if (len_c != pk->res_cnt[1] || m + (q == 0 ? 2 : 0) != pk->res_cnt[0]) return PM_ERR_STATE;   // key and prover disagree on the layout
+    PM_HIP(ctx, ctx->xw.reserve((m0 + mw) * sizeof(Fr)));
+    PM_HIP(ctx, ctx->ue.reserve(m * sizeof(Fr)));
+    PM_HIP(ctx, ctx->we.reserve(m * sizeof(Fr)));
+    PM_HIP(ctx, ctx->u.reserve((m + 2) * sizeof(Fr)));
+    PM_HIP(ctx, ctx->w.reserve(m * sizeof(Fr)));
+    PM_HIP(ctx, ctx->wit_u.reserve(m * sizeof(Fr)));
+    PM_HIP(ctx, ctx->u2.reserve(2 * m * sizeof(Fr)));
+    PM_HIP(ctx, ctx->sc_c.reserve((len_c + 1) * sizeof(Fr)));
+    PM_HIP(ctx, ctx->ra.reserve(2 * sizeof(Fr)));
+    PM_HIP(ctx, ctx->flags.reserve(64));
+    PM_HIP(ctx, ctx->sh_a.reserve(m * sizeof(Fr)));
+    PM_HIP(ctx, ctx->sh_b.reserve(m * sizeof(Fr)));
+    PM_HIP(ctx, ctx->sh_c.reserve((m > 2 * m0 ? m : 2 * m0) * sizeof(Fr)));
+    Fr *xw = ctx->xw.as<Fr>(), *ue = ctx->ue.as<Fr>(), *we = ctx->we.as<Fr>(), *u = ctx->u.as<Fr>(), *wv = ctx->w.as<Fr>();
+    Fr *wit_u = ctx->wit_u.as<Fr>(), *u2lo = ctx->u2.as<Fr>(), *u2hi = u2lo + m, *sc_c = ctx->sc_c.as<Fr>(), *ra = ctx->ra.as<Fr>();
+    Fr *ta = ctx->sh_a.as<Fr>(), *tb = ctx->sh_b.as<Fr>(), *tc = ctx->sh_c.as<Fr>();
+    unsigned *flags = ctx->flags.as<unsigned>();
+    PM_HIP(ctx, hipMemsetAsync(flags, 0, 64, st));
+    const hipMemcpyKind kind = assignment_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    PM_HIP(ctx, hipMemcpyAsync(xw, x, m0 * sizeof(Fr), kind, st));
+    if (mw) PM_HIP(ctx, hipMemcpyAsync(xw + m0, w, mw * sizeof(Fr), kind, st));
+    PM_HIP(ctx, hipMemcpyAsync(ra, r_a, 2 * sizeof(Fr), hipMemcpyHostToDevice, st));
+    CsrDev A{pk->d_rowptr[0], pk->d_col[0], pk->d_val[0]}, Bm{pk->d_rowptr[1], pk->d_col[1], pk->d_val[1]},
+        Cm{pk->d_rowptr[2], pk->d_col[2], pk->d_val[2]};
+    const bool sparse_head = 2 * m0 <= 16;
+    {
+        StageTimer t(ctx, T_WITNESS_MAP);
+        hipLaunchKernelGGL(k_witness_cyclic<P>, dim3(nblk(m)), dim3(256), 0, st, A, Bm, Cm, xw, ue, we, m0, nr, L);
+        PM_HIP(ctx, hipGetLastError());
+        if (zcnt) {
+            hipLaunchKernelGGL(k_ztail_slice<P>, dim3(nblk(zcnt)), dim3(256), 0, st, A, Bm, xw, sc_c, m0, mw, zl, zh);
+            PM_HIP(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_check_sap_L<P>, dim3(nblk(m)), dim3(256), 0, st, ue, we, m, flags);   // rem == 0 of prover.rs:108
+        PM_HIP(ctx, hipGetLastError());
+    }
+    // N1, N2 (prover.rs:94,96): the transforms consume their input, so the witness-only U part (N5) is prepared first
+    if (!sparse_head) {
+        PM_HIP(ctx, hipMemcpyAsync(tc, ue, m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_zero_head_cyclic<P>, dim3(nblk(m)), dim3(256), 0, st, tc, 2 * m0, L);
+        PM_HIP(ctx, hipGetLastError());
+        PM_TRY(dist_intt<C>(ctx, pk, L, tc, ta, wit_u));
+    }
+    PM_TRY(dist_intt<C>(ctx, pk, L, ue, ta, u));
+    if (q == 0) PM_HIP(ctx, hipMemcpyAsync(u + m, ra, 2 * sizeof(Fr), hipMemcpyDeviceToDevice, st));   // sc_a = u || r_a on rank 0
+    // [a]_1 on the helper context while the remaining transforms run (prove.hip does the same)
+    const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
+    int st_a = PM_OK;
+    struct Joiner {
+        std::thread t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } helper;
+    bool a_early = overlap && ctx->aux;
+    if (a_early) {
+        pm_ctx *aux = ctx->aux;
+        PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
+        timing_reset(aux);
+        try {
+            helper.t = std::thread([&, aux] {
+                if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0) != hipSuccess) {
+                    st_a = PM_ERR_HIP;
+                    aux->err = "helper stream setup failed";
+                    return;
+                }
+                try {
+                    st_a = msm_resident<C>(aux, pk, 0, u, a_xy, a_inf);
+                } catch (const std::exception &e) {
+                    st_a = PM_ERR_STATE;
+                    aux->err = e.what();
+                }
+                timing_flush(aux);
+            });
+        } catch (const std::system_error &) {
+            a_early = false;
+        }
+    }
+    PM_TRY(dist_intt<C>(ctx, pk, L, we, ta, wv));
+    if (sparse_head) {
+        const Fr *winv = nullptr;
+        PM_TRY(twiddles_get<C>(ctx, pk->log_n, true, &winv));
+        StageTimer t(ctx, T_NTT);
+        hipLaunchKernelGGL(k_ue_head<P>, dim3(1), dim3(64), 0, st, A, Bm, Cm, xw, tc, m0, nr, (unsigned)(2 * m0));
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_wit_u_sparse_L<P>, dim3(nblk(m)), dim3(256), 0, st, u, tc, winv, inverse<P>(from_u64<P>(n)), (unsigned)(2 * m0), wit_u, L);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    {   // square_polynomial (prover.rs:315-328) through the negacyclic half (prove.hip: k_twist): u^2 = lo + X^n hi
+        const Fr *psi = nullptr, *psi_inv = nullptr;
+        PM_TRY(twiddles_get<C>(ctx, pk->log_n + 1, false, &psi));
+        PM_TRY(twiddles_get<C>(ctx, pk->log_n + 1, true, &psi_inv));
+        hipLaunchKernelGGL(k_twist_L<P>, dim3(nblk(m)), dim3(256), 0, st, u, psi, ta, L);
+        PM_HIP(ctx, hipGetLastError());
+        PM_TRY(dist_ntt<C>(ctx, pk, L, ta, tb, tc));
+        hipLaunchKernelGGL(k_square_L<P>, dim3(nblk(m)), dim3(256), 0, st, tc, m);
+        PM_HIP(ctx, hipGetLastError());
+        PM_TRY(dist_intt<C>(ctx, pk, L, tc, tb, ta));
+        hipLaunchKernelGGL(k_untwist_combine_L<P>, dim3(nblk(m)), dim3(256), 0, st, ta, psi_inv, wv, u2lo, u2hi, L, inverse<P>(from_u64<P>(2)));
+        PM_HIP(ctx, hipGetLastError());
+    }
+    {
+        StageTimer t(ctx, T_POLY);
+        hipLaunchKernelGGL(k_phase1_scalars_L<P>, dim3(nblk(m)), dim3(256), 0, st, u, u2hi, ra, sc_c + zcnt, sc_c + zcnt + hcnt,
+                           tail ? sc_c + zcnt + hcnt + rucnt : (Fr *)nullptr, L, flags);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    unsigned hflags = 0;
+    PM_HIP(ctx, hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    PM_TRY(flags_or(ctx, &hflags));
+    if (hflags & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
+    if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
+    if (a_early) {
+        const int st_c = msm_resident<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
+        helper.t.join();
+        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];
+        if (st_a != PM_OK) { ctx->err = ctx->aux->err; return st_a; }
+        PM_TRY(st_c);
+    } else {
+        PM_TRY(msm_resident<C>(ctx, pk, 0, u, a_xy, a_inf));
+        PM_TRY(msm_resident<C>(ctx, pk, 1, sc_c, c_xy, c_inf));
+    }
+    t_phase.stop();
+    timing_flush(ctx);
+    ctx->phase = 1;
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- phase 2
+template <class C>
+int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    if (ctx->phase < 1 || !ctx->pk) return PM_ERR_STATE;
+    const pm_pk *pk = ctx->pk;
+    PM_TRY(require_comm(ctx, pk));
+    PhaseEnd phase_end{ctx->comm};
+    const Layout L = pmlayout::make_layout(pk->n, (uint32_t)pk->shard_count, (uint32_t)pk->shard_rank);
+    hipStream_t st = ctx->stream;
+    const Fr x1 = load_fr<P>(x1_in);
+    unsigned Lh = 16;
+    while (Lh > L.B) Lh >>= 1;
+    const uint64_t lanes = L.m / Lh;
+    const unsigned blocks = nblk(lanes);
+    const size_t rec = 1 + (size_t)L.N;
+    PM_HIP(ctx, ctx->scratch.reserve(((size_t)blocks + rec) * sizeof(Fr)));
+    Fr *part = ctx->scratch.as<Fr>(), *out = part + blocks;
+    hipLaunchKernelGGL(k_horner_partial_L<P>, dim3(blocks), dim3(256), 0, st, ctx->u.as<Fr>(), L, x1, Lh, part);
+    PM_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_phase2_pack<P>, dim3(1), dim3(256), 0, st, (const Fr *)part, blocks, (const Fr *)ctx->u.as<Fr>(), L, out);
+    PM_HIP(ctx, hipGetLastError());
+    std::vector<Fr> mine(rec), all(rec * L.N);
+    PM_HIP(ctx, hipMemcpyAsync(mine.data(), out, rec * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    const int rc = ctx->comm->all_gather(mine.data(), all.data(), rec * sizeof(Fr), st);
+    if (rc) { ctx->err = "all_gather: " + ctx->comm->err; return rc; }
+    Fr sum = Fr::zero();
+    for (uint32_t r = 0; r < L.N; ++r) sum = add<P>(sum, all[r * rec]);
+    memcpy(u_at_x1, sum.l, sizeof(Fr));
+    // halo of my block k1 = the coefficient just below its first one: the last of rank q-1's block k1, or (q = 0) of
+    // rank N-1's block k1-1; block (0, 0) starts at coefficient 0 and has none
+    std::vector<Fr> halo(L.N, Fr::zero());
+    for (uint32_t k1 = 0; k1 < L.N; ++k1) {
+        if (L.q > 0) halo[k1] = all[(L.q - 1) * rec + 1 + k1];
+        else if (k1 > 0) halo[k1] = all[(L.N - 1) * rec + 1 + (k1 - 1)];
+    }
+    PM_HIP(ctx, ctx->halo.reserve(L.N * sizeof(Fr)));
+    PM_HIP(ctx, hipMemcpyAsync(ctx->halo.p, halo.data(), L.N * sizeof(Fr), hipMemcpyHostToDevice, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    ctx->phase = 2;
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- phase 3
+template <class C>
+int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in, const uint64_t *a_in, const uint64_t *c_in, uint64_t *d_xy,
+                         int *d_inf) {
+    typedef typename C::FrP P;
+    typedef Fp<P> Fr;
+    if (ctx->phase < 2 || !ctx->pk) return PM_ERR_STATE;            // the halo coefficients come from phase 2's exchange
+    const pm_pk *pk = ctx->pk;
+    PM_TRY(require_comm(ctx, pk));
+    PhaseEnd phase_end{ctx->comm};
+    hipStream_t st = ctx->stream;
+    if (!ctx->keep_timings) timing_reset(ctx);
+    TimingGuard timing_guard{ctx};
+    StageTimer t_phase(ctx, T_PHASE);
+    const uint64_t n = pk->n, sigma = pk->sigma, m = n / (uint64_t)pk->shard_count;
+    const uint32_t N = (uint32_t)pk->shard_count, q = (uint32_t)pk->shard_rank;
+    const Fr x1 = load_fr<P>(x1_in), x2 = load_fr<P>(x2_in), a_at = load_fr<P>(a_in), c_at = load_fr<P>(c_in);
+    Fr rah[2];
+    PM_HIP(ctx, hipMemcpyAsync(rah, ctx->ra.p, sizeof(rah), hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    const NumConsts<P> nc = make_num_consts<P>(x2, rah, a_at, c_at);
+    const SegData sd{n, sigma};
+    const size_t S = pk->segs.size(), SS = pk->seg_slots;   // SS = the longest segment list of any rank (the exchanged record size)
+    PM_HIP(ctx, ctx->quotient.reserve((pk->res_cnt[2] + 1) * sizeof(Fr)));
+    PM_HIP(ctx, ctx->lvl[0].reserve(S * SEG_THREADS * sizeof(Fr)));    // lane values
+    PM_HIP(ctx, ctx->lvl[1].reserve(2 * S * sizeof(Fr)));              // V | carry
+    Fr *qv = ctx->quotient.as<Fr>(), *lane_vals = ctx->lvl[0].as<Fr>(), *V = ctx->lvl[1].as<Fr>(), *carry = V + S;
+    const Fr *u = ctx->u.as<Fr>(), *wit_u = ctx->wit_u.as<Fr>(), *u2lo = ctx->u2.as<Fr>(), *u2hi = u2lo + m, *halo = ctx->halo.as<Fr>();
+    const Segment *d_segs = (const Segment *)pk->d_segs;
+    std::vector<Fr> hV(SS, Fr::zero()), hall(SS * N), hcarry(S);
+    {
+        StageTimer t(ctx, T_POLY);
+        hipLaunchKernelGGL(k_seg_reduce<P>, dim3((unsigned)S), dim3(SEG_THREADS), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1, lane_vals, V);
+        PM_HIP(ctx, hipGetLastError());
+        PM_HIP(ctx, hipMemcpyAsync(hV.data(), V, S * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    }
+    PM_HIP(ctx, hipStreamSynchronize(st));
+    const int rc = ctx->comm->all_gather(hV.data(), hall.data(), SS * sizeof(Fr), st);
+    if (rc) { ctx->err = "all_gather: " + ctx->comm->err; return rc; }
+    // the chain over ALL segments in descending index order: H_b(s) = carry into s; H_a(s) = V_s + x1^(b-a) H_b(s)
+    Fr Hb = Fr::zero();
+    {
+        uint64_t pow_len = 0;
+        Fr pow_val = Fr::one();
+        for (size_t i = pk->all_segs.size(); i-- > 0;) {
+            const auto &e = pk->all_segs[i];
+            if (e.rank == q) hcarry[e.idx] = Hb;
+            const uint64_t len = e.b - e.a;
+            if (len != pow_len) { pow_len = len; pow_val = pow_u64<P>(x1, len); }
+            Hb = add<P>(hall[(size_t)e.rank * SS + e.idx], mul<P>(pow_val, Hb));
+        }
+    }
+    if (!Hb.is_zero()) return PM_ERR_REMAINDER_NONZERO;               // prover.rs:221 -- the same value on every rank
+    {
+        StageTimer t(ctx, T_POLY);
+        PM_HIP(ctx, hipMemcpyAsync(carry, hcarry.data(), S * sizeof(Fr), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_seg_expand<P>, dim3((unsigned)S), dim3(SEG_THREADS), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
+                           (const Fr *)lane_vals, (const Fr *)carry, qv);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    PM_TRY(msm_resident<C>(ctx, pk, 2, qv, d_xy, d_inf));              // [d]_1 = M8, prover.rs:229
+    t_phase.stop();
+    timing_flush(ctx);
+    ctx->phase = 3;
+    return PM_OK;
+}
+
+#define PM_INST_SH(C)                                                                                                               \
+    template int prove_phase1_sharded<C>(pm_ctx *, const pm_pk *, const uint64_t *, const uint64_t *, const uint64_t *, uint64_t *, \
+                                         int *, uint64_t *, int *, bool);                                                           \
+    template int prove_phase2_sharded<C>(pm_ctx *, const uint64_t *, uint64_t *);                                                   \
+    template int prove_phase3_sharded<C>(pm_ctx *, const uint64_t *, const uint64_t *, const uint64_t *, const uint64_t *, uint64_t *, int *);
+PM_INST_SH(BlsCurve)
+PM_INST_SH(BnCurve)
+
+}  // namespace pm

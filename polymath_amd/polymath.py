@@ -319,7 +319,7 @@ class Polymath:
         self.collect_timings, self.phase_timings = False, []    # per-phase stage timings (pm_last_timings), opt-in
 
     # circuit_specific_setup (lib.rs:63-70) -> generate_proving_key (generator.rs:24-167)
-    def setup(self, circuit, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1):
+    def setup(self, circuit, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1, layout="pairs"):
         f = self.field
         if isinstance(circuit, LimbCircuit):
             r1cs, (A, B, C) = circuit, circuit.csrs
@@ -327,7 +327,7 @@ class Polymath:
             r1cs = self._synthesize(circuit)[0]
             A, B, C = _csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)
         pk = api.ProvingKey.generate(self.ctx, self.curve, r1cs.m0, r1cs.mw, r1cs.nr, A, B, C,
-                                     f.fr_limbs([x_trapdoor])[0], f.fr_limbs([z_trapdoor])[0], shard_rank, shard_count)
+                                     f.fr_limbs([x_trapdoor])[0], f.fr_limbs([z_trapdoor])[0], shard_rank, shard_count, layout)
         pk.omega = f.fr_int(pk.omega_limbs)
         return pk
 

@@ -1,0 +1,217 @@
+"""PM_SHARD_VECTOR: ONE proof with the vector phases sharded over N ranks.
+
+CPU (no GPU): the layout's index arithmetic (polymath_amd/host/layout.hpp through pm_layout_indices) -- the blocked /
+cyclic maps are permutations, and the four-step transform built on them with the CPU oracle's size-n/N NTTs and a
+numpy "all-to-all" equals the direct size-n transform.
+GPU: N ranks as N threads of one process on one GPU (pm_comm_local_create), every rank holding ONLY its share of the
+vectors and of the key; the proofs must be byte-identical to the single-GPU proof, for N = 2, 4, 8, both curves."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle.pyref import circuits as CI
+from oracle.pyref.fields import CURVES
+
+
+def _four_step_intt(oracle, curve, evals, n, N):
+    """evals: list of n ints.  Inverse transform through the sharded algorithm, all ranks simulated here."""
+    from polymath_amd import api
+    c = CURVES[curve]
+    m, B = n // N, n // N // N
+    omega = pow(c.two_adic_root, 1 << (c.two_adicity - (n.bit_length() - 1)), c.r)
+    rows = [api.layout_indices(n, N, q, coefficients=False) for q in range(N)]
+    coef = [api.layout_indices(n, N, q, coefficients=True) for q in range(N)]
+    assert sorted(np.concatenate(rows).tolist()) == list(range(n)) and sorted(np.concatenate(coef).tolist()) == list(range(n))
+    log_m = m.bit_length() - 1
+    local = []
+    for q in range(N):     # N local size-m transforms on the cyclic sub-sequences
+        x = oracle.fr_to_mont_limbs(curve, [evals[int(i)] for i in rows[q]])
+        local.append(oracle.fr_from_mont_limbs(curve, oracle.ntt(curve, x, log_m, True)))
+    out = [0] * n
+    winv, ninv = pow(omega, -1, c.r), pow(N, -1, c.r)
+    for q in range(N):     # after the all-to-all rank q holds block q of every rank's transform
+        for b in range(B):
+            k2 = q * B + b
+            col = [local[r][k2] * pow(winv, r * k2, c.r) % c.r for r in range(N)]
+            for k1 in range(N):
+                v = sum(col[r] * pow(winv, m * r * k1, c.r) for r in range(N)) % c.r * ninv % c.r
+                p = k1 * B + b
+                out[int(coef[q][p])] = v
+                assert int(coef[q][p]) == k1 * m + k2
+    return out
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_layout_four_step_equals_direct_transform(oracle, N):
+    curve, n = "bls12_381", 64
+    c = CURVES[curve]
+    g = CI.SplitMix64(64 + N)
+    evals = [g.fr(c.r) for _ in range(n)]
+    direct = oracle.fr_from_mont_limbs(curve, oracle.ntt(curve, oracle.fr_to_mont_limbs(curve, evals), 6, True))
+    assert _four_step_intt(oracle, curve, evals, n, N) == direct
+
+
+def test_layout_rejects_bad_shapes():
+    from polymath_amd import api
+    with pytest.raises(api.PolymathError):
+        api.layout_indices(64, 3, 0)            # not a power of two
+    with pytest.raises(api.PolymathError):
+        api.layout_indices(32, 8, 0)            # N^2 > n
+
+
+# ------------------------------------------------------------------------------------------------------ GPU
+def _run_ranks(N, fn):
+    """fn(rank) on N threads; re-raises the first exception."""
+    errs, outs = [None] * N, [None] * N
+
+    def body(r):
+        try:
+            outs[r] = fn(r)
+        except BaseException as e:     # noqa: BLE001 -- reported below
+            errs[r] = e
+    th = [threading.Thread(target=body, args=(r,)) for r in range(N)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    return outs
+
+
+def _sharded_proofs(curve, lc, x, z, r_a, N, transcript="merlin", device_assignment=False):
+    from polymath_amd import api
+    from polymath_amd.polymath import Polymath
+    comms = api.Comm.local_group(N)
+    pms = [Polymath(curve, transcript, device=0) for _ in range(N)]
+    for r in range(N):
+        pms[r].ctx.set_comm(comms[r])
+    pks = [pms[r].setup(lc, x, z, shard_rank=r, shard_count=N, layout="vector") for r in range(N)]
+    proofs = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a))
+    return pms, pks, comms, proofs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+@pytest.mark.parametrize("N", [2, 4, 8])
+def test_vector_sharded_proof_equals_single_gpu(curve, N):
+    """5000 gates (n = 16384): every rank proves on 1/N of the rows, coefficients, scans and MSM pairs; the N proofs are
+    identical to the unsharded proof.  The shards' local vectors, scattered through the layout, equal the whole ones."""
+    from polymath_amd import api, circuits as PC
+    from polymath_amd.polymath import Polymath
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, 5000)
+    g = PC.SplitMix64(0x5A4D + N)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    ref_pm = Polymath(curve, "merlin", device=0)
+    ref_pk = ref_pm.setup(lc, x, z)
+    ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+    n = ref_pk.n
+    whole = {w: ref_pk.tap(w, 11 * n) for w in (2, 3, 4, 5, 6, 7)}
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    assert all(p == ref for p in proofs)
+    # local vectors -> global through the layout
+    Lz = len(whole[6])
+    for w in (2, 3, 5):                                    # u, w, wit_u: blocked coefficient layout
+        got = np.zeros((n, 4), dtype=np.uint64)
+        for r in range(N):
+            got[api.layout_indices(n, N, r)] = pks[r].tap(w, n)
+        assert np.array_equal(got, whole[w]), w
+    got = np.zeros((n, 4), dtype=np.uint64)               # h: the same layout, index n - 1 does not exist
+    for r in range(N):
+        idx = api.layout_indices(n, N, r)
+        loc = pks[r].tap(4, n)
+        got[idx[:len(loc)]] = loc
+    assert np.array_equal(got[:n - 1], whole[4])
+    assert np.array_equal(np.concatenate([pks[r].tap(6, Lz) for r in range(N)]), whole[6])     # z_tail: contiguous slices
+    # quotient: scatter every rank's scalars through its [d] pieces (bases y_gamma_z[k - 1] <-> H_k)
+    qn = len(whole[7])
+    got = np.zeros((qn + 1, 4), dtype=np.uint64)
+    seen = np.zeros(qn + 1, dtype=np.int32)
+    off_ygz = None
+    for r in range(N):
+        loc, at = pks[r].tap(7, 11 * n), 0
+        pieces = pks[r].msm_pieces(2)
+        if off_ygz is None:
+            off_ygz = min(p[0] for rr in range(N) for p in pks[rr].msm_pieces(2))
+        for lo, cnt in pieces:
+            got[lo - off_ygz:lo - off_ygz + cnt] = loc[at:at + cnt]
+            seen[lo - off_ygz:lo - off_ygz + cnt] += 1
+            at += cnt
+        assert at == len(loc)
+    assert (seen[:qn] == 1).all() and np.array_equal(got[:qn], whole[7])
+    for pk in pks:
+        pk.free()
+    ref_pk.free()
+
+
+@pytest.mark.gpu
+def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
+    """Tiny sub-segments (PM_MAX_SEG_LOG=6: hundreds of segments per rank, several per block), a circuit with 12 public
+    inputs (2 m0 > 16: the witness-only part of u takes its own distributed transform), all three transcripts; an
+    unsatisfied witness makes EVERY rank return PM_ERR_REMAINDER_NONZERO (no rank is left waiting in a collective)."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import ConstraintSystem, LimbCircuit, Polymath, Field, _csr
+    from polymath_amd import api
+    curve, N = "bls12_381", 4
+    c = CURVES[curve]
+    monkeypatch.setenv("PM_MAX_SEG_LOG", "6")
+    f = Field(curve)
+    cs = ConstraintSystem(c.r)
+    g = PC.SplitMix64(1212)
+    vals = [g.fr(c.r) for _ in range(300)]
+    wv = [cs.new_witness_variable(v) for v in vals]
+    for i in range(0, 290):
+        prod = vals[i] * vals[i + 1] % c.r
+        out = cs.new_input_variable(prod) if i < 11 else cs.new_witness_variable(prod)
+        cs.enforce_constraint([(1, wv[i])], [(1, wv[i + 1])], [(1, out)])
+    r1cs = cs.to_r1cs()
+    assert r1cs.m0 == 12
+    lc = LimbCircuit(f, r1cs.m0, r1cs.mw, r1cs.nr, (_csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)), f.fr_limbs(cs.instance), f.fr_limbs(cs.witness))
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    for tname in ("merlin", "keccak256", "blake3"):
+        ref_pm = Polymath(curve, tname, device=0)
+        ref_pk = ref_pm.setup(lc, x, z)
+        ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+        pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, transcript=tname)
+        assert all(p == ref for p in proofs), tname
+        ref_pk.free()
+    bad = lc.wit_limbs.copy()
+    bad[7, 0] ^= np.uint64(1)
+    from polymath_amd.polymath import PolymathProverError
+
+    def prove_bad(r):
+        try:
+            pms[r].prove_native(pks[r], lc.inst_limbs, bad, r_a)
+        except PolymathProverError as e:
+            return e.status
+        return 0
+    assert _run_ranks(N, prove_bad) == [4] * N
+    # the contexts are still usable afterwards
+    assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a)))
+
+
+@pytest.mark.gpu
+def test_vector_sharded_mid_size_and_pairs_layout_agree():
+    """2^16-100 gates on 8 ranks (B = 2048 coefficients per block, several sub-segments per stretch): the vector-sharded
+    proof, the pairs-sharded proof (vector phases replicated, pm_comm combine) and the single-GPU proof are identical."""
+    from polymath_amd import api, circuits as PC
+    from polymath_amd.polymath import Polymath
+    curve, N = "bls12_381", 8
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, (1 << 16) - 100)
+    g = PC.SplitMix64(0x1616)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    ref_pm = Polymath(curve, "merlin", device=0)
+    ref_pk = ref_pm.setup(lc, x, z)
+    ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+    ref_pk.free()
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    assert all(p == ref for p in proofs)
+    for pk in pks:
+        pk.free()
+    # PM_SHARD_PAIRS keys on the same contexts and communicators: the native point combine replaces the callback
+    pks = [pms[r].setup(lc, x, z, shard_rank=r, shard_count=N, layout="pairs") for r in range(N)]
+    assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a)))
