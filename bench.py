@@ -155,10 +155,24 @@ def main():
     shard_rank, shard_count = rank, world
     if world == 1 and os.environ.get("BENCH_FAKE_SHARD"):
         shard_rank, shard_count = (int(v) for v in os.environ["BENCH_FAKE_SHARD"].split("/"))
-    pk = pm.setup(r1cs, x_trap, z_trap, shard_rank=shard_rank, shard_count=shard_count)
-    log(rank, "setup on device: n=%d, %d resident points (%.1f s)" % (pk.n, sum(pk.base_lens), time.time() - t0))
+    # N > 1: ONE proof over the N GPUs.  layout "vector" (default): witness map, NTTs, scans AND MSM pairs sharded, the
+    # ranks joined by a pm_comm (RCCL inside the library); "pairs": only the MSM pair ranges
+    # sharded, the partial points combined through torch.distributed (row 1 only; BENCH_SHARD_LAYOUT=pairs).
+    layout = os.environ.get("BENCH_SHARD_LAYOUT", "vector") if world > 1 else "pairs"
+    comm_desc = None
+    if world > 1 and layout == "vector":
+        from polymath_amd.distributed import make_comm
+        comm, comm_desc = make_comm(rank, world, local, native=(backend == "nccl" and not os.environ.get("BENCH_NO_RCCL")))
+        pm.ctx.set_comm(comm)
+        log(rank, "pm_comm:", comm_desc)
+    pk = pm.setup(r1cs, x_trap, z_trap, shard_rank=shard_rank, shard_count=shard_count, layout=layout)
+    log(rank, "setup on device: n=%d, layout=%s (%.1f s)" % (pk.n, layout, time.time() - t0))
     x_l, w_l = r1cs.inst_limbs, r1cs.wit_limbs
-    combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local, backend_gloo=(backend != "nccl")) if world > 1 else None
+    combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local, backend_gloo=(backend != "nccl")) if world > 1 and layout == "pairs" else None
+    py_combine = combine            # for the phase-by-phase (Python glue) proofs
+    if world > 1 and layout == "vector":
+        from polymath_amd.distributed import CommPointCombiner
+        py_combine = CommPointCombiner(comm, curve, pm.field.nq)   # the native path combines inside the library (ctx's pm_comm)
 
     def barrier():
         if world > 1:
@@ -177,7 +191,7 @@ def main():
     def prove_once():
         if native:
             return pm.prove_native(pk, x_l, w_l, r_a, dev_ptrs, combine)
-        return pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs).to_bytes()
+        return pm.prove_limbs(pk, inst, x_l, w_l, r_a, py_combine, dev_ptrs).to_bytes()
 
     proof_b = None
     for _ in range(args.warmup):
@@ -208,14 +222,14 @@ def main():
     # PCIe-inclusive variant (host x, w buffers through pm_prove_phase1): reported, never `value`
     barrier()
     t1 = time.perf_counter()
-    proof_host_b = pm.prove_native(pk, x_l, w_l, r_a, None, combine) if native else pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine).to_bytes()
+    proof_host_b = pm.prove_native(pk, x_l, w_l, r_a, None, combine) if native else pm.prove_limbs(pk, inst, x_l, w_l, r_a, py_combine).to_bytes()
     barrier()
     ms_host_inputs = (time.perf_counter() - t1) * 1e3
     assert proof_host_b == proof_b
     # one phase-by-phase proof outside the timed region: per-phase stage breakdown, and the two host paths agree
     pm.collect_timings = True
     t1 = time.perf_counter()
-    proof_py = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs).to_bytes()
+    proof_py = pm.prove_limbs(pk, inst, x_l, w_l, r_a, py_combine, dev_ptrs).to_bytes()
     ms_python_glue = (time.perf_counter() - t1) * 1e3
     pm.collect_timings = False
     assert proof_py == proof_b
@@ -228,7 +242,7 @@ def main():
     # inflates its HIP-event duration); these are the durations rocprofv3 --stats of the same configuration prints.
     os.environ["PM_MSM_OVERLAP"] = "0"
     pm.collect_timings = True
-    proof_serial = pm.prove_limbs(pk, inst, x_l, w_l, r_a, combine, dev_ptrs).to_bytes()
+    proof_serial = pm.prove_limbs(pk, inst, x_l, w_l, r_a, py_combine, dev_ptrs).to_bytes()
     pm.collect_timings = False
     del os.environ["PM_MSM_OVERLAP"]
     assert proof_serial == proof_b
@@ -239,7 +253,7 @@ def main():
             log(rank, " phase %d:" % (i + 1), {k: round(v, 2) for k, v in tm.items() if v})
     n = pk.n
     d_pairs_total = 10 * n + 22                     # quotient MSM M8 (prover.rs:229)
-    d_pairs_rank = d_pairs_total * (shard_rank + 1) // shard_count - d_pairs_total * shard_rank // shard_count
+    d_pairs_rank = pk.msm_plan(2)[0]
     pairs_per_proof = (n + 3) + (2 * r1cs.m0 + r1cs.mw + nr + (n - 1) + (n + 1) + 5) + d_pairs_total
     avg = lambda v: sum(v) / max(len(v), 1)
     if rank == 0:
@@ -271,7 +285,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "2^%d-100-constraint synthetic R1CS (random A*B=C gates), %s, n=2^%d, transcript=%s" %
                        (args.log_constraints, curve, n.bit_length() - 1, args.transcript),
-                       "msm_pairs_per_proof": pairs_per_proof, "parallelism": "msm-pairs-sharded x%d" % world},
+                       "msm_pairs_per_proof": pairs_per_proof,
+                       "parallelism": ("one proof over %d GPUs: witness map, four-step NTT (one all-to-all per transform), scans and MSM pairs sharded; %s"
+                                       % (world, comm_desc)) if layout == "vector" and world > 1 else "msm-pairs-sharded x%d" % world},
             "msm_pairs_per_sec": pairs_per_proof / (dt / args.steps),
             "ms_per_step_pcie_inclusive": ms_host_inputs,
             "host_glue": "native (pm_host_prove%s: C++ transcript + challenge arithmetic inside the library)" % ("_sharded" if world > 1 else "")

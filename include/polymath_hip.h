@@ -237,6 +237,9 @@ void pm_comm_destroy(pm_comm *c);
 int pm_comm_rank(const pm_comm *c);
 int pm_comm_world(const pm_comm *c);
 const char *pm_comm_last_error(const pm_comm *c);
+/* Local group with PM_LOCAL_COMM_SERIALIZE=1 (ranks take turns between collectives: emulation of N GPUs on one): the
+ * milliseconds this rank spent running, waits for its peers excluded; 0 for other communicators.  Measurement aid. */
+double pm_comm_busy_ms(pm_comm *c, int reset);
 int pm_comm_all_gather(pm_comm *c, const void *send, void *recv, size_t bytes);
 int pm_comm_all_to_all(pm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream);
 /* Sum over ranks of `count` partial G1 points, in place (all-gather + pm_g1_sum): the native pm_combine_fn. */

@@ -54,7 +54,7 @@ EXPORTS = [
     "pm_prove_tap", "pm_host_keccak_f1600", "pm_synth_r1cs",
     "pm_pk_load_sharded", "pm_pk_generate_sharded", "pm_layout_indices", "pm_pk_msm_pieces",
     "pm_comm_rccl_unique_id", "pm_comm_rccl_create", "pm_comm_local_create", "pm_comm_from_callbacks", "pm_comm_destroy", "pm_comm_rank",
-    "pm_comm_world", "pm_comm_last_error", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
+    "pm_comm_world", "pm_comm_last_error", "pm_comm_busy_ms", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
 ]
 SHARD_PAIRS, SHARD_VECTOR = 0, 1
 LAYOUTS = {"pairs": SHARD_PAIRS, "vector": SHARD_VECTOR, 0: 0, 1: 1}
@@ -128,6 +128,8 @@ def load_library():
     L.pm_comm_world.argtypes = [vp]
     L.pm_comm_last_error.argtypes = [vp]
     L.pm_comm_last_error.restype = ct.c_char_p
+    L.pm_comm_busy_ms.argtypes = [vp, i]
+    L.pm_comm_busy_ms.restype = ct.c_double
     L.pm_comm_all_gather.argtypes = [vp, vp, vp, sz]
     L.pm_comm_all_to_all.argtypes = [vp, vp, vp, sz, vp]
     L.pm_comm_combine_points.argtypes = [vp, i, i, u64p, intp]
@@ -224,6 +226,9 @@ class Comm:
     @property
     def world(self):
         return self.L.pm_comm_world(self.h)
+
+    def busy_ms(self, reset=True):
+        return float(self.L.pm_comm_busy_ms(self.h, int(reset)))
 
     def all_gather(self, arr):
         arr = np.ascontiguousarray(arr)

@@ -9,6 +9,7 @@
 #include <new>
 
 #include "internal.h"
+#include "comm.h"
 #include "fq28.cuh"
 #include "../host/hashes.hpp"
 
@@ -435,7 +436,7 @@ static int pk_init_layout(pm_ctx *ctx, pm_pk *pk, uint64_t m0, uint64_t mw, uint
         pk->res_cnt[k] = 0;
         for (const auto &pc : pk->pieces[k]) pk->res_cnt[k] += pc.count;
     }
-    if (shard_count == 1) {
+    if (shard_count == 1 && layout == PM_SHARD_PAIRS) {   // the whole logical concatenation is resident
         for (int k = 0; k < 3; ++k) pk->res_dev_off[k] = pk->msm_lo[k];
     } else {  // device layout [c pairs | a pairs | d pairs]
         pk->res_dev_off[1] = 0;
@@ -446,7 +447,7 @@ static int pk_init_layout(pm_ctx *ctx, pm_pk *pk, uint64_t m0, uint64_t mw, uint
 }
 
 static uint64_t pk_resident_points(const pm_pk *pk) {
-    if (pk->shard_count == 1) return pk->total_points;
+    if (pk->shard_count == 1 && pk->layout == PM_SHARD_PAIRS) return pk->total_points;
     return pk->res_cnt[0] + pk->res_cnt[1] + pk->res_cnt[2];
 }
 
@@ -496,7 +497,7 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     const uint64_t resident = pk_resident_points(pk);
     PM_HIP(ctx, hipMalloc(&pk->d_bases, (resident ? resident : 1) * sizeof(Affine<C>)));
     Affine<C> *d = (Affine<C> *)pk->d_bases;
-    if (pk->shard_count == 1) {
+    if (pk->shard_count == 1 && pk->layout == PM_SHARD_PAIRS) {
         PM_TRY(for_cat_range<C>(pk, 0, pk->total_points, d, fill));
     } else {
         for (int k = 0; k < 3; ++k) {
@@ -764,7 +765,7 @@ extern "C" int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_
     uint64_t lo = pk->seg_off[which] + offset, hi = lo + len;
     uint64_t dev_off = 0;
     bool found = false;
-    if (pk->shard_count == 1) {
+    if (pk->shard_count == 1 && pk->layout == PM_SHARD_PAIRS) {
         dev_off = lo;
         found = true;
     } else {
@@ -786,6 +787,11 @@ extern "C" int pm_pk_export_bases(pm_ctx *ctx, const pm_pk *pk, int which, size_
 // into the embedding host (a Rust shim or ctypes): it becomes a status with the message in pm_last_error.
 template <class F>
 static int guarded(pm_ctx *ctx, F body) {
+    struct Turn {   // local serialised emulation (comm.hip): a phase runs holding the turn; no-op otherwise
+        pm_comm *c;
+        explicit Turn(pm_comm *cc) : c(cc) { if (c) c->phase_begin(); }
+        ~Turn() { if (c) c->phase_end(); }
+    } turn(ctx->comm);
     try {
         return body();
     } catch (const std::bad_alloc &) {

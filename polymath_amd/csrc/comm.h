@@ -16,5 +16,7 @@ struct pm_comm {
     virtual int all_gather(const void *send, void *recv, size_t bytes, hipStream_t stream) = 0;
     // end of a prover phase: nothing to exchange until the host calls again (local serialised emulation: pass the turn on)
     virtual void phase_end() {}
+    virtual void phase_begin() {}
+    double busy_ms = 0.0;   // local serialised emulation only
 };
 

@@ -12,6 +12,7 @@
 //   callbacks (pm_comm_from_callbacks) -- the host brings its own transport (torch.distributed in tests).
 #include <dlfcn.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -58,12 +59,24 @@ struct LocalGroup {
 struct LocalComm : pm_comm {
     std::shared_ptr<LocalGroup> g;
     bool holds_turn = false;
+    // serialised emulation: the time this rank spent RUNNING (holding the turn), i.e. without the waits for its peers --
+    // what the rank would take on a GPU of its own, exchanges aside (pm_comm_busy_ms; tools/shard_emulation.py)
+    std::chrono::steady_clock::time_point mark;
     void release_turn() {
-        if (g->serialize && holds_turn) { g->turn.unlock(); holds_turn = false; }
+        if (g->serialize && holds_turn) {
+            busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - mark).count();
+            g->turn.unlock();
+            holds_turn = false;
+        }
     }
     void take_turn() {
-        if (g->serialize && !holds_turn) { g->turn.lock(); holds_turn = true; }
+        if (g->serialize && !holds_turn) {
+            g->turn.lock();
+            holds_turn = true;
+            mark = std::chrono::steady_clock::now();
+        }
     }
+    void phase_begin() override { take_turn(); }
     ~LocalComm() override { release_turn(); }
     void phase_end() override { release_turn(); }
     int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
@@ -246,11 +259,19 @@ extern "C" int pm_comm_from_callbacks(const pm_comm_ops *ops, int rank, int worl
 extern "C" void pm_comm_destroy(pm_comm *c) { delete c; }
 extern "C" int pm_comm_rank(const pm_comm *c) { return c ? c->rank : -1; }
 extern "C" int pm_comm_world(const pm_comm *c) { return c ? c->world : 0; }
+extern "C" double pm_comm_busy_ms(pm_comm *c, int reset) {
+    if (!c) return 0.0;
+    const double v = c->busy_ms;
+    if (reset) c->busy_ms = 0.0;
+    return v;
+}
 extern "C" const char *pm_comm_last_error(const pm_comm *c) { return c ? c->err.c_str() : "null comm"; }
 
 extern "C" int pm_comm_all_gather(pm_comm *c, const void *send, void *recv, size_t bytes) {
     if (!c || !send || !recv) return PM_ERR_INVALID_ARG;
-    return c->all_gather(send, recv, bytes, nullptr);
+    const int st = c->all_gather(send, recv, bytes, nullptr);
+    c->phase_end();   // a host-level collective: no prover phase is running, nothing to hold a turn for
+    return st;
 }
 
 extern "C" int pm_comm_all_to_all(pm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream) {
@@ -275,7 +296,9 @@ extern "C" int pm_comm_combine_points(pm_comm *c, int curve, int count, uint64_t
         memcpy(&mine[j * rec], xy + j * words, words * 8);
         mine[j * rec + words] = (uint64_t)(inf[j] != 0);
     }
-    PM_TRY(c->all_gather(mine.data(), all.data(), mine.size() * 8, nullptr));
+    const int st = c->all_gather(mine.data(), all.data(), mine.size() * 8, nullptr);
+    c->phase_end();   // called by the host glue BETWEEN the prover's phases
+    PM_TRY(st);
     std::vector<uint64_t> pts(words * (size_t)c->world);
     std::vector<int> infs(c->world);
     for (int j = 0; j < count; ++j) {

@@ -430,8 +430,9 @@ static int flags_or(pm_ctx *ctx, unsigned *flags) {
     return PM_OK;
 }
 
-struct PhaseEnd {   // every return path hands the turn on (local serialised emulation); no-op for RCCL
+struct PhaseEnd {   // a phase runs holding the turn and every return path hands it on (local serialised emulation); no-op for RCCL
     pm_comm *c;
+    explicit PhaseEnd(pm_comm *cc) : c(cc) { if (c) c->phase_begin(); }
     ~PhaseEnd() { if (c) c->phase_end(); }
 };
 
@@ -442,7 +443,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
     PM_TRY(require_comm(ctx, pk));
-    PhaseEnd phase_end{ctx->comm};
+    PhaseEnd phase_end(ctx->comm);
     const uint64_t n = pk->n, m0 = pk->m0, mw = pk->mw, nr = pk->nr, Lz = 2 * m0 + mw + nr;
     if (pk->log_n + 1 > (unsigned)C::TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;   // prover.rs:317
     const Layout L = pmlayout::make_layout(n, (uint32_t)pk->shard_count, (uint32_t)pk->shard_rank);
@@ -594,7 +595,7 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
     if (ctx->phase < 1 || !ctx->pk) return PM_ERR_STATE;
     const pm_pk *pk = ctx->pk;
     PM_TRY(require_comm(ctx, pk));
-    PhaseEnd phase_end{ctx->comm};
+    PhaseEnd phase_end(ctx->comm);
     const Layout L = pmlayout::make_layout(pk->n, (uint32_t)pk->shard_count, (uint32_t)pk->shard_rank);
     hipStream_t st = ctx->stream;
     const Fr x1 = load_fr<P>(x1_in);
@@ -640,7 +641,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     if (ctx->phase < 2 || !ctx->pk) return PM_ERR_STATE;            // the halo coefficients come from phase 2's exchange
     const pm_pk *pk = ctx->pk;
     PM_TRY(require_comm(ctx, pk));
-    PhaseEnd phase_end{ctx->comm};
+    PhaseEnd phase_end(ctx->comm);
     hipStream_t st = ctx->stream;
     if (!ctx->keep_timings) timing_reset(ctx);
     TimingGuard timing_guard{ctx};

@@ -7,6 +7,8 @@ residues), so partial points are all-gathered as bytes (104 B each) and summed l
 pm_g1_sum -- latency-bound, bandwidth irrelevant.  Challenges are then identical on all ranks
 because every rank hashes the same combined points.
 """
+import ctypes as ct
+
 import numpy as np
 
 
@@ -44,3 +46,125 @@ class PointCombiner:
             infs = np.ascontiguousarray(allp[:, j, -1]).astype(np.int32)
             res.append(api.g1_sum(self.curve, pts, infs))
         return res
+
+
+class CommPointCombiner:
+    """PointCombiner's interface on top of a pm_comm (pm_comm_combine_points: all-gather + pm_g1_sum inside the library),
+    for hosts that drive the three phases themselves (Polymath.prove_limbs) on a communicator-joined context."""
+
+    def __init__(self, comm, curve, nq):
+        self.comm, self.curve, self.nq = comm, curve, nq
+
+    def __call__(self, xy, inf):
+        return self.many([(xy, inf)])[0]
+
+    def many(self, points):
+        from . import api
+        k, words = len(points), 2 * self.nq
+        xy = np.zeros(k * words, dtype=np.uint64)
+        inf = (ct.c_int * k)()
+        for j, (p, i) in enumerate(points):
+            xy[j * words:(j + 1) * words] = np.asarray(p, dtype=np.uint64)
+            inf[j] = int(i)
+        st = self.comm.L.pm_comm_combine_points(self.comm.h, api.CURVE_IDS[self.curve], k, xy.ctypes.data_as(ct.POINTER(ct.c_uint64)), inf)
+        if st:
+            raise api.PolymathError(st, "pm_comm_combine_points")
+        return [(xy[j * words:(j + 1) * words].copy(), int(inf[j])) for j in range(k)]
+
+
+# ---------------------------------------------------------------------------------------- pm_comm construction
+class _CommOps(ct.Structure):
+    _fields_ = [("user", ct.c_void_p),
+                ("all_to_all", ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_void_p)),
+                ("all_gather", ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_size_t))]
+
+
+class TorchComm:
+    """A pm_comm whose two collectives run over torch.distributed with ANY backend, staging through host memory
+    (pm_comm_from_callbacks).  For tests (gloo, several ranks sharing one GPU) and hosts without a usable RCCL; the
+    production form is api.Comm.rccl, where the all-to-all never leaves the GPUs."""
+
+    def __init__(self, rank, world):
+        import torch
+        import torch.distributed as dist
+        from . import api
+        self.torch, self.dist, self.rank_, self.world_ = torch, dist, rank, world
+        self.dev = "cuda" if dist.get_backend() == "nccl" else "cpu"     # NCCL/RCCL process groups move device tensors only
+        self.hip = ct.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [ct.c_void_p]
+        self.failure = None
+        self._ops = _CommOps(None, _CommOps._fields_[1][1](self._all_to_all), _CommOps._fields_[2][1](self._all_gather))
+        L = api.load_library()
+        h = ct.c_void_p()
+        st = L.pm_comm_from_callbacks(ct.byref(self._ops), rank, world, ct.byref(h))
+        if st:
+            raise api.PolymathError(st, "pm_comm_from_callbacks")
+        self.comm = api.Comm(h, keep=self)
+
+    def _all_to_all(self, _user, d_send, d_recv, nbytes, stream):
+        try:
+            total = nbytes * self.world_
+            if self.hip.hipStreamSynchronize(stream):
+                return 6
+            src = np.empty(total, dtype=np.uint8)
+            if self.hip.hipMemcpy(src.ctypes.data_as(ct.c_void_p), d_send, total, 2):        # device -> host
+                return 6
+            t_in = self.torch.from_numpy(src).to(self.dev)
+            t_out = self.torch.empty_like(t_in)
+            self.dist.all_to_all_single(t_out, t_in)
+            out = t_out.cpu().numpy()
+            if self.hip.hipMemcpy(d_recv, out.ctypes.data_as(ct.c_void_p), total, 1):         # host -> device
+                return 6
+            return 0
+        except Exception as e:   # noqa: BLE001 -- never unwind through the C frames
+            self.failure = e
+            return 8
+
+    def _all_gather(self, _user, send, recv, nbytes):
+        try:
+            mine = np.ctypeslib.as_array(ct.cast(send, ct.POINTER(ct.c_uint8)), shape=(nbytes,)).copy()
+            t_in = self.torch.from_numpy(mine).to(self.dev)
+            outs = [self.torch.empty_like(t_in) for _ in range(self.world_)]
+            self.dist.all_gather(outs, t_in)
+            dst = np.ctypeslib.as_array(ct.cast(recv, ct.POINTER(ct.c_uint8)), shape=(nbytes * self.world_,))
+            for r, t in enumerate(outs):
+                dst[r * nbytes:(r + 1) * nbytes] = t.cpu().numpy()
+            return 0
+        except Exception as e:   # noqa: BLE001
+            self.failure = e
+            return 8
+
+
+def make_comm(rank, world, device, native=True):
+    """This rank's pm_comm for a torch.distributed job.  native: RCCL inside the library (rank 0's unique id travels
+    over torch.distributed); every rank learns whether ALL ranks succeeded, otherwise all fall back to TorchComm.
+    -> (api.Comm, description)."""
+    import torch
+    import torch.distributed as dist
+    from . import api
+    tdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+    def all_ok(ok):
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+    if native:
+        uid = None
+        try:
+            uid = api.Comm.rccl_unique_id()              # every rank: proves librccl loads here (rank 0's id is the one used)
+        except Exception:       # noqa: BLE001 -- the fallback below is the handling
+            uid = None
+        if all_ok(uid is not None):                       # nobody enters ncclCommInitRank unless everybody can
+            box = [uid if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm, ok = None, False
+            try:
+                comm = api.Comm.rccl(box[0], rank, world, device)
+                probe = comm.all_gather(np.array([rank], dtype=np.int64))
+                ok = probe.reshape(-1).tolist() == list(range(world))
+            except Exception:   # noqa: BLE001
+                ok = False
+            if all_ok(ok):
+                return comm, "rccl (native: ncclAllToAll / ncclAllGather inside the library)"
+    return TorchComm(rank, world).comm, "torch.distributed callbacks (%s), host-staged" % dist.get_backend()

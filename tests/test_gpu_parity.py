@@ -493,6 +493,15 @@ def test_bench_two_ranks_one_gpu_same_proof():
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["proof_bytes"] == j2["proof_bytes"] and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert "four-step NTT" in j2["config"]["parallelism"]          # the default N > 1 layout shards the vector phases too
+    # ... and the pairs-only layout (vector phases replicated, points combined through torch.distributed) still agrees
+    env["BENCH_SHARD_LAYOUT"] = "pairs"
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29545", os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j3 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j3["proof_bytes"] == j1["proof_bytes"] and "msm-pairs-sharded" in j3["config"]["parallelism"]
 
 
 def test_full_size_2p20_proof_passes_pairing_verifier(oracle):

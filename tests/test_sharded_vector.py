@@ -215,3 +215,32 @@ def test_vector_sharded_mid_size_and_pairs_layout_agree():
     # PM_SHARD_PAIRS keys on the same contexts and communicators: the native point combine replaces the callback
     pks = [pms[r].setup(lc, x, z, shard_rank=r, shard_count=N, layout="pairs") for r in range(N)]
     assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a)))
+
+
+@pytest.mark.gpu
+def test_rccl_comm_world_of_one():
+    """The RCCL implementation of pm_comm (librccl dlopen'ed by the library, ncclCommInitRank / ncclAllToAll / ncclAllGather)
+    on the single GPU of this box: a world of ONE rank -- the code path of an N-GPU job, with every collective degenerate.
+    The PM_SHARD_VECTOR prover on it (B = n: one block) gives the single-GPU proof."""
+    from polymath_amd import api, circuits as PC
+    from polymath_amd.polymath import Polymath
+    curve = "bls12_381"
+    c = CURVES[curve]
+    comm = api.Comm.rccl(api.Comm.rccl_unique_id(), 0, 1, 0)
+    assert (comm.rank, comm.world) == (0, 1)
+    assert comm.all_gather(np.arange(5, dtype=np.int64)).tolist() == [[0, 1, 2, 3, 4]]
+    lc = PC.synthetic_r1cs_native(curve, 3000)
+    ref_pm = Polymath(curve, "merlin", device=0)
+    ref_pk = ref_pm.setup(lc, 11, 13)
+    ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, [3, 5])
+    pm = Polymath(curve, "merlin", device=0)
+    pm.ctx.set_comm(comm)
+    pk = pm.setup(lc, 11, 13, shard_rank=0, shard_count=1, layout="vector")
+    assert pm.prove_native(pk, lc.inst_limbs, lc.wit_limbs, [3, 5]) == ref
+    # without a communicator the vector layout refuses to run (status, no crash)
+    pm2 = Polymath(curve, "merlin", device=0)
+    rc, _ = pk.view(pm2.ctx).host_prove("merlin", lc.inst_limbs, lc.inst_limbs, lc.wit_limbs, pm.field.fr_limbs([3, 5]))
+    assert rc == 8
+    pk.free()
+    ref_pk.free()
+    comm.close()

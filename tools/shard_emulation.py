@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Per-rank cost of an N-GPU PM_SHARD_VECTOR proof, emulated on ONE GPU (no 8-GPU node needed): the N ranks run as N
+threads over pm_comm_local_create with PM_LOCAL_COMM_SERIALIZE=1 -- between collectives only one rank runs at a time, so
+every rank's kernels take what they would take alone; the exchanges are device-to-device copies (their xGMI cost is NOT
+in the number).  per-rank ms = wall time of K proofs / (K N).
+  python tools/shard_emulation.py --ranks 8 --log-constraints 20 --steps 3 [--layout pairs]"""
+import argparse, json, os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["PM_LOCAL_COMM_SERIALIZE"] = "1"
+os.environ.setdefault("PM_MSM_OVERLAP", "0")       # the helper thread of the overlapped [a] MSM would escape the turnstile
+from polymath_amd import api, circuits as PC   # noqa: E402
+from polymath_amd.polymath import Polymath, FIELDS   # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--ranks", type=int, default=8)
+ap.add_argument("--log-constraints", type=int, default=20)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--curve", default="bls12_381")
+ap.add_argument("--layout", default="vector")
+a = ap.parse_args()
+N, curve = a.ranks, a.curve
+r = FIELDS[curve]["r"]
+lc = PC.synthetic_r1cs_native(curve, (1 << a.log_constraints) - 100)
+g = PC.SplitMix64(0xBE7C4)
+x, z, r_a = g.fr(r), g.fr(r), [g.fr(r), g.fr(r)]
+comms = api.Comm.local_group(N)
+pms = [Polymath(curve, "merlin", device=0) for _ in range(N)]
+for k in range(N):
+    pms[k].ctx.set_comm(comms[k])
+t0 = time.time()
+pks = [pms[k].setup(lc, x, z, shard_rank=k, shard_count=N, layout=a.layout) for k in range(N)]
+setup_s = time.time() - t0
+proofs, timings = [None] * N, [None] * N
+
+
+def body(k, steps):
+    for _ in range(steps):
+        proofs[k] = pms[k].prove_native(pks[k], lc.inst_limbs, lc.wit_limbs, r_a)
+    timings[k] = pms[k].ctx.timings()
+
+
+def run(steps):
+    th = [threading.Thread(target=body, args=(k, steps)) for k in range(N)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return time.perf_counter() - t0
+
+
+run(1)
+for c in comms:
+    c.busy_ms()
+dt = run(a.steps)
+busy = [c.busy_ms() / a.steps for c in comms]
+assert all(p == proofs[0] for p in proofs)
+print(json.dumps({"ranks": N, "layout": a.layout, "curve": curve, "log_constraints": a.log_constraints, "steps": a.steps,
+                  "emulated_ms_per_rank": dt / a.steps / N * 1e3,
+                  "busy_ms_per_rank": [round(b, 3) for b in busy], "busy_ms_max_rank": max(busy), "wall_ms_per_proof_all_ranks_serialised": dt / a.steps * 1e3,
+                  "setup_s_all_ranks": setup_s, "stage_ms_rank0": {k: round(v, 3) for k, v in timings[0].items()},
+                  "stage_ms_last_rank": {k: round(v, 3) for k, v in timings[N - 1].items()},
+                  "note": "exchanges are local device-to-device copies: xGMI latency / bandwidth not included", "proof": proofs[0].hex()}))
