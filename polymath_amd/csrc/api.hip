@@ -83,7 +83,7 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     for (DevBuf *b : {&m.digits, &m.sorted, &m.counts, &m.bucket_off, &m.task_off, &m.cursor, &m.partials, &m.wsum,
                       &m.region, &m.sub, &m.digits2, &m.order, &m.len_bins, &m.block_cnt, &m.task_cnt, &m.hot, &ctx->scratch, &ctx->flags, &ctx->xw, &ctx->ue, &ctx->we, &ctx->u, &ctx->w,
                       &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra, &ctx->sh_a, &ctx->sh_b, &ctx->sh_c, &ctx->halo,
-                      &ctx->shard_roots})
+                      &ctx->shard_roots, &ctx->ntt_tmp})
         b->release();
     for (auto &b : ctx->lvl) b.release();
     for (auto &b : ctx->fb_table) b.release();

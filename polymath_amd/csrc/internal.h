@@ -4,7 +4,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/polymath_hip.h"
@@ -157,6 +161,58 @@ struct pm_pk {
     void *d_tab[3], *d_tab_inf[3];   // tables and their infinity flags (tables[k].inf)
 };
 
+// One persistent host thread per context that runs a helper job (the overlapped [a]_1 MSM of prove.hip): created on first
+// use, parked on a condition variable between proofs -- a std::thread per proof costs 30-50 us, which matters once a
+// proof's share of an 8-GPU job is ~15 ms.
+struct pm_worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, stop = false;
+    bool submit(std::function<void()> fn) {      // false: the thread could not be created (caller runs the job inline)
+        std::unique_lock<std::mutex> lk(mu);
+        if (!th.joinable()) {
+            try {
+                th = std::thread([this] {
+                    std::unique_lock<std::mutex> l(mu);
+                    for (;;) {
+                        cv.wait(l, [this] { return has_job || stop; });
+                        if (stop) return;
+                        std::function<void()> f = std::move(job);
+                        has_job = false;
+                        l.unlock();
+                        f();
+                        l.lock();
+                        done = true;
+                        cv.notify_all();
+                    }
+                });
+            } catch (const std::system_error &) {
+                return false;
+            }
+        }
+        job = std::move(fn);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+        return true;
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return done; });
+    }
+    ~pm_worker() {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [this] { return done; });
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct PendingTimer {
     int slot;
     hipEvent_t a, b;
@@ -172,8 +228,9 @@ struct pm_ctx {
     pm::MsmWorkspace msm;
     pm::TwiddleCache tw[8];   // the sharded prover works with log m, log n and log 2n tables of both directions
     unsigned long long tw_clock;
-    pm::DevBuf scratch, flags;
+    pm::DevBuf scratch, flags, ntt_tmp;   // ntt_tmp: the out-of-place first / last passes of ntt_run
     pm_comm *comm;            // this rank's communicator (pm_ctx_set_comm); null on single-GPU contexts
+    pm_worker worker;         // runs the helper context's MSM concurrently with this context's own work
     pm_ctx *aux;              // helper context (own stream + MSM workspace) for the second of two concurrent MSMs
     pm::DevBuf fb_table[2];   // setup.hip: 8-bit-window multiples of the G1 generator, per curve id (built on first use)
     // proof in flight

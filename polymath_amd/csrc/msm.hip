@@ -939,7 +939,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 template <class C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level1(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0, unsigned K0,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0, unsigned K0,
                                                        unsigned R, XYZZ<C> *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
@@ -1151,8 +1151,9 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     PM_HIP(ctx, ws.cursor.reserve(((NB + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
     PM_HIP(ctx, ws.partials.reserve(max_tasks * sizeof(XYZZ<C>)));
     const bool two_level = NB >= 4096;
-    unsigned K0 = 8;                                   // level-0 fan-in: <= 2^17 lanes, one full round of the chip
-    while (NB / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;
+    unsigned K0 = 4;                                   // level-0 fan-in: <= 2^17 lanes = 2 waves per SIMD, one round of the chip
+    while (NB / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;   // (a lone wave issues a mad every ~11 cycles, two interleave at ~5.6;
+                                                               //  swept in profiles/r02_levers.jsonl: K0 = 2 doubles level 1's work and loses)
     if (const char *e = getenv("PM_RED_K0")) K0 = (unsigned)atoi(e);        // developer knobs (powers of two)
     unsigned R1 = 2;                                   // swept on MI355X (tools/sweep_reduce.sh): K0 = 16, R = 2 at 2^21 buckets
     if (const char *e = getenv("PM_RED_R")) R1 = (unsigned)atoi(e);

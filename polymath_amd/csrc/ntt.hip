@@ -60,9 +60,11 @@ constexpr int LOG_TILE = 8;
 // The butterfly product runs on 28-bit limbs (fq28.cuh: 200 carry-free mads + 70 instead of the dense
 // 32-bit-limb Montgomery product the compiler lowers to ~700 instructions, half of them register moves);
 // `tw` holds INTERNAL-form twiddles (k_twiddles), the tile stays canonical standard-form Fr.
+// `dst` may be `a` (in place: a workgroup reads and writes the same positions) or another buffer; `do_scale`: multiply the
+// outputs by `scale` on the way out (the n^-1 of an inverse transform, folded into its last pass).
 template <class P, class RR>
-__global__ __launch_bounds__(256) void k_ntt_pass(Fp<P> *a, const Fp<P> *tw, unsigned log_n, unsigned s0, unsigned ns,
-                                                   unsigned log_cols) {
+__global__ __launch_bounds__(256) void k_ntt_pass(const Fp<P> *a, Fp<P> *dst, const Fp<P> *tw, unsigned log_n, unsigned s0, unsigned ns,
+                                                   unsigned log_cols, Fp<P> scale, int do_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fp<P> *tile = (Fp<P> *)smem_raw;  // [2^ns][cols]
     const unsigned cols = 1u << log_cols, rows = 1u << ns;
@@ -116,7 +118,67 @@ __global__ __launch_bounds__(256) void k_ntt_pass(Fp<P> *a, const Fp<P> *tw, uns
     }
     for (unsigned e = tid; e < rows * cols; e += blockDim.x) {
         unsigned r = e >> log_cols, c = e & (cols - 1);
-        a[base + ((size_t)r << s0) + c] = tile[e];
+        dst[base + ((size_t)r << s0) + c] = do_scale ? mul<P>(tile[e], scale) : tile[e];
+    }
+}
+
+// FIRST pass with the bit reversal folded into its loads (no k_bitrev round trip): stages [0, ns) of the DIT network
+// need, for every value `hi` of the upper H = log_n - ns index bits, the 2^ns elements src[brev(hi 2^ns + r)] =
+// src[(brev_ns(r) << H) + brev_H(hi)].  A workgroup takes the 2^log_cols values of hi whose brev_H are CONSECUTIVE
+// (8g .. 8g + 7): its loads are then 256-byte-contiguous segments like every other pass's, and it writes, for each of
+// its hi, 2^ns contiguous outputs.  Reads and writes touch different positions, so the pass goes src -> dst.
+// The tile is swizzled (column (c + r) & (cols - 1)) so that the column-major store phase is bank-conflict free.
+template <class P, class RR>
+__global__ __launch_bounds__(256) void k_ntt_first_pass(const Fp<P> *src, Fp<P> *dst, const Fp<P> *tw, unsigned log_n, unsigned ns,
+                                                         unsigned log_cols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Fp<P> *tile = (Fp<P> *)smem_raw;  // [2^ns][cols], swizzled
+    const unsigned cols = 1u << log_cols, rows = 1u << ns, H = log_n - ns, cm = cols - 1;
+    const size_t g = blockIdx.x;
+    const unsigned tid = threadIdx.x;
+    for (unsigned e = tid; e < rows * cols; e += blockDim.x) {
+        const unsigned rb = e >> log_cols, c = e & cm;
+        const unsigned r = __brev(rb) >> (32 - ns);
+        tile[r * cols + ((c + r) & cm)] = src[((size_t)rb << H) + (g << log_cols) + c];
+    }
+    __syncthreads();
+    const unsigned nbf = (rows >> 1) * cols;
+    for (unsigned t = 0; t < ns; ++t) {
+        const unsigned s = t + 1, half = 1u << t;
+        auto bfly = [&](unsigned r0, unsigned c, const Fp<P> &w) {
+            const unsigned r1 = r0 + half;
+            Fp<P> *p0 = &tile[r0 * cols + ((c + r0) & cm)], *p1 = &tile[r1 * cols + ((c + r1) & cm)];
+            const Fp<P> x = *p0, y0 = *p1;
+            Fp<P> y;
+            f28_pack_reduced<RR>(f28_mul<RR>(f28_unpack<RR>(y0.l), f28_unpack<RR>(w.l)), y.l);
+            *p0 = add<P>(x, y);
+            *p1 = sub<P>(x, y);
+        };
+        if (nbf == 4 * blockDim.x) {   // issue the four twiddle loads of this lane's butterflies before the arithmetic
+            Fp<P> w[4];
+            unsigned r0v[4], cv[4];
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) {
+                const unsigned e = tid + q * blockDim.x, k = e >> log_cols;
+                cv[q] = e & cm;
+                r0v[q] = ((k >> t) << (t + 1)) | (k & (half - 1));
+                w[q] = tw[(size_t)(r0v[q] & (half - 1)) << (log_n - s)];
+            }
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) bfly(r0v[q], cv[q], w[q]);
+        } else {
+            for (unsigned e = tid; e < nbf; e += blockDim.x) {
+                const unsigned c = e & cm, k = e >> log_cols;
+                const unsigned r0 = ((k >> t) << (t + 1)) | (k & (half - 1));
+                bfly(r0, c, tw[(size_t)(r0 & (half - 1)) << (log_n - s)]);
+            }
+        }
+        __syncthreads();
+    }
+    for (unsigned e = tid; e < rows * cols; e += blockDim.x) {
+        const unsigned c = e >> ns, r = e & (rows - 1);
+        const size_t hi = __brevll((unsigned long long)((g << log_cols) + c)) >> (64 - H);
+        dst[(hi << ns) + r] = tile[r * cols + ((c + r) & cm)];
     }
 }
 
@@ -181,11 +243,38 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     const size_t n = (size_t)1 << log_n;
     const Fr *tw = nullptr;
     PM_TRY(twiddles_get<C>(ctx, log_n, inv_dir, &tw, true));
-    hipLaunchKernelGGL(k_bitrev<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, log_n);
-    PM_HIP(ctx, hipGetLastError());
     // passes of LOG_TILE = 8 stages on 256-row x 8-column tiles; domains above 2^24 take 9 stages per pass
     // (512 rows x 4 columns, the same 64 KiB of LDS) so that 2^25..2^27 points still need only three passes
     const unsigned tile_log = log_n > 24 ? (unsigned)LOG_TILE + 1 : (unsigned)LOG_TILE;
+    const Fr ninv = inv_dir ? inverse<P>(from_u64<P>((uint64_t)n)) : Fr::one();
+    static const bool fused = [] { const char *e = getenv("PM_NTT_FUSED"); return !(e && e[0] == '0'); }();
+    if (fused && log_n >= tile_log + 3) {
+        // >= 2 passes: d -> tmp (bit reversal folded into the first pass's loads), middle passes in place on tmp,
+        // tmp -> d (n^-1 folded into the last pass's stores): no k_bitrev and no k_scale round trip through HBM
+        PM_HIP(ctx, ctx->ntt_tmp.reserve(n * sizeof(Fr)));
+        Fr *tmp = ctx->ntt_tmp.as<Fr>();
+        {
+            const unsigned ns = tile_log, log_cols = 11 - ns;
+            hipLaunchKernelGGL((k_ntt_first_pass<P, typename C::FrRR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(256),
+                               ((size_t)1 << (ns + log_cols)) * sizeof(Fr), ctx->stream, (const Fr *)d, tmp, tw, log_n, ns, log_cols);
+            PM_HIP(ctx, hipGetLastError());
+        }
+        unsigned s0 = tile_log;
+        while (s0 < log_n) {
+            const unsigned ns = log_n - s0 < tile_log ? log_n - s0 : tile_log;
+            unsigned log_cols = 11 - ns < 3 ? 11 - ns : 3;
+            if (s0 < log_cols) log_cols = s0;
+            const bool last = s0 + ns == log_n;
+            hipLaunchKernelGGL((k_ntt_pass<P, typename C::FrRR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(256),
+                               ((size_t)1 << (ns + log_cols)) * sizeof(Fr), ctx->stream, (const Fr *)tmp, last ? d : tmp, tw, log_n, s0, ns, log_cols,
+                               ninv, last && inv_dir ? 1 : 0);
+            PM_HIP(ctx, hipGetLastError());
+            s0 += ns;
+        }
+        return PM_OK;
+    }
+    hipLaunchKernelGGL(k_bitrev<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, log_n);
+    PM_HIP(ctx, hipGetLastError());
     unsigned s0 = 0;
     while (s0 < log_n) {
         unsigned ns = log_n - s0 < tile_log ? log_n - s0 : tile_log;
@@ -194,13 +283,12 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         if (s0 < log_cols) log_cols = s0;
         size_t tiles = n >> (ns + log_cols);
         size_t lds = ((size_t)1 << (ns + log_cols)) * sizeof(Fr);
-        hipLaunchKernelGGL((k_ntt_pass<P, typename C::FrRR>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, d, tw, log_n, s0, ns,
-                           log_cols);
+        hipLaunchKernelGGL((k_ntt_pass<P, typename C::FrRR>), dim3((unsigned)tiles), dim3(256), lds, ctx->stream, (const Fr *)d, d, tw, log_n, s0, ns,
+                           log_cols, ninv, 0);
         PM_HIP(ctx, hipGetLastError());
         s0 += ns;
     }
     if (inv_dir) {
-        Fr ninv = inverse<P>(from_u64<P>((uint64_t)n));
         hipLaunchKernelGGL(k_scale<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d, n, ninv);
         PM_HIP(ctx, hipGetLastError());
     }

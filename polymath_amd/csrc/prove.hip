@@ -410,10 +410,12 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();   // per call: bench.py toggles it
     if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
     int st_a = PM_OK;   // written by the helper thread: declared before the joiner so that it outlives the join
-    struct Joiner {     // an early error return must not leave a joinable thread behind
-        std::thread t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    } helper;
+    struct Joiner {     // an early error return must not leave the helper job running into freed stack variables
+        pm_worker *w;
+        bool pending;
+        void join() { if (pending) { w->wait(); pending = false; } }
+        ~Joiner() { join(); }
+    } helper{&ctx->worker, false};
     bool a_early = overlap && ctx->aux;
     if (a_early) {
         pm_ctx *aux = ctx->aux;
@@ -421,8 +423,8 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
         PM_HIP(ctx, hipGetLastError());
         PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
         timing_reset(aux);
-        try {
-            helper.t = std::thread([&, aux] {
+        {
+            helper.pending = ctx->worker.submit([&, aux] {
                 if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0) != hipSuccess) {
                     st_a = PM_ERR_HIP;
                     aux->err = "helper stream setup failed";
@@ -436,8 +438,7 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
                 }
                 timing_flush(aux);
             });
-        } catch (const std::system_error &) {
-            a_early = false;   // no helper thread: the two MSMs run back to back below (sc_a is already filled)
+            if (!helper.pending) a_early = false;   // no helper thread: the two MSMs run back to back below (sc_a is already filled)
         }
     }
     PM_TRY(ntt_run<C>(ctx, wv, pk->log_n, true));
@@ -484,7 +485,7 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
     if (a_early) {
         const int st_c = msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
-        helper.t.join();
+        helper.join();
         for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];
         if (st_a != PM_OK) { ctx->err = ctx->aux->err; return st_a; }
         PM_TRY(st_c);

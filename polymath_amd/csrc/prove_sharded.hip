@@ -508,17 +508,19 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
     if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
     int st_a = PM_OK;
-    struct Joiner {
-        std::thread t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    } helper;
+    struct Joiner {     // an early error return must not leave the helper job running into freed stack variables
+        pm_worker *w;
+        bool pending;
+        void join() { if (pending) { w->wait(); pending = false; } }
+        ~Joiner() { join(); }
+    } helper{&ctx->worker, false};
     bool a_early = overlap && ctx->aux;
     if (a_early) {
         pm_ctx *aux = ctx->aux;
         PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
         timing_reset(aux);
-        try {
-            helper.t = std::thread([&, aux] {
+        {
+            helper.pending = ctx->worker.submit([&, aux] {
                 if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0) != hipSuccess) {
                     st_a = PM_ERR_HIP;
                     aux->err = "helper stream setup failed";
@@ -532,8 +534,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
                 }
                 timing_flush(aux);
             });
-        } catch (const std::system_error &) {
-            a_early = false;
+            if (!helper.pending) a_early = false;
         }
     }
     PM_TRY(dist_intt<C>(ctx, pk, L, we, ta, wv));
@@ -573,7 +574,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
     if (a_early) {
         const int st_c = msm_resident<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
-        helper.t.join();
+        helper.join();
         for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];
         if (st_a != PM_OK) { ctx->err = ctx->aux->err; return st_a; }
         PM_TRY(st_c);

@@ -329,7 +329,7 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
     }
     if (const char *e = getenv("PM_TABLE_C")) {   // developer knob for tuning sweeps: widest window
         unsigned c = (unsigned)atoi(e);
-        if (c >= 4 && c <= 23) tables_layout(best_t, (256 + c - 1) / c);
+        if (c >= 4 && c <= 24) tables_layout(best_t, (256 + c - 1) / c);   // 24: the 11-window experiment (profiles/r02_levers_*.jsonl)
     }
     best_t.stride = resident_points;
     return best_t;
