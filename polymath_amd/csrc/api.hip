@@ -510,9 +510,11 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tables_disabled_by_env()) return PM_OK;
-    // Budget: free HBM minus the per-proof vectors (~40 Fr per domain point) and the MSM workspace (~48 B per
-    // table entry of one <= 2^27-pair piece).  Tables are granted per MSM, smallest first, while they fit;
-    // an MSM without tables runs the per-window pipeline on the plain array.
+    // Budget: free HBM minus the per-proof vectors (~40 Fr per domain point; 26 are in use) and the MSM workspaces: 16 B
+    // per (pair, window) entry of the sort's two ping-pong arrays and the sorted indices, 13-16 windows, plus the
+    // bucket-side arrays -> 256 B per pair of one <= 2^27-pair piece, for the main context's largest MSM and for the
+    // helper context's [a]_1 MSM.  Tables are granted per MSM, smallest first, while they fit; an MSM without tables
+    // runs the per-window pipeline on the plain array.
     size_t free_b = 0, total_b = 0;
     PM_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
     // PM_INFLIGHT_CONTEXTS: how many contexts will prove on this resident key at once (each owns the per-proof vectors
@@ -523,8 +525,8 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     double budget = 0.9 * (double)free_b - (double)inflight * 64.0 * 40.0 * (double)pk->n;
     {
         const uint64_t len_d = pk->res_cnt[2], len_a = pk->res_cnt[0];
-        budget -= (double)inflight * 48.0 * 16.0 * (double)(len_d < (uint64_t)msm_max_piece() ? len_d : (uint64_t)msm_max_piece());
-        budget -= (double)inflight * 48.0 * 16.0 * (double)len_a;
+        budget -= (double)inflight * 256.0 * (double)(len_d < (uint64_t)msm_max_piece() ? len_d : (uint64_t)msm_max_piece());
+        budget -= (double)inflight * 256.0 * (double)len_a;
     }
     int order[3] = {0, 1, 2};
     std::sort(order, order + 3, [&](int x, int y) { return pk->res_cnt[x] < pk->res_cnt[y]; });

@@ -244,3 +244,28 @@ def test_rccl_comm_world_of_one():
     pk.free()
     ref_pk.free()
     comm.close()
+
+
+@pytest.mark.gpu
+def test_config_2p22_eight_ranks_vector_sharded():
+    """BASELINE configs[2] as named -- the 2^22-100-gate circuit (n = 2^23, 117 M MSM pairs) proved as ONE proof by 8 ranks
+    (threads of this process on the one GPU of the box, pm_comm_local_create), each holding 1/8 of the key, of the rows, of
+    the coefficients (B = 2^17 per block), of the quotient and of the MSM pairs: byte-identical to the single-GPU proof,
+    which the pairing verifier accepts (test_gpu_configs.py::test_config_2p22_one_gpu)."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    curve, N = "bls12_381", 8
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, (1 << 22) - 100)
+    g = PC.SplitMix64(0x2222)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    ref_pm = Polymath(curve, "merlin", device=0)
+    ref_pk = ref_pm.setup(lc, x, z)
+    ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+    ref_pk.free()
+    ref_pm.ctx.close()
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    assert all(p == ref for p in proofs)
+    assert sum(pk.msm_plan(2)[0] for pk in pks) == 10 * (1 << 23) + 22          # the quotient's pairs, each exactly once
+    for pk in pks:
+        pk.free()
