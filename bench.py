@@ -129,7 +129,12 @@ def main():
     if os.environ.get("BENCH_FORCE_DEVICE") is not None:
         local = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
-    if world > 1:
+    # test hook: BENCH_FORCE_VECTOR=1 under `torch.distributed.run --nproc-per-node 1` takes the whole N > 1 code path with
+    # a world of ONE (process group, RCCL communicator inside the library next to torch's own, vector-sharded key): what
+    # a single-GPU box can check of the multi-GPU launch (tests/test_sharded_vector.py)
+    force_vec = bool(os.environ.get("BENCH_FORCE_VECTOR")) and "MASTER_ADDR" in os.environ
+    multi = world > 1 or force_vec
+    if multi:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -158,9 +163,9 @@ def main():
     # N > 1: ONE proof over the N GPUs.  layout "vector" (default): witness map, NTTs, scans AND MSM pairs sharded, the
     # ranks joined by a pm_comm (RCCL inside the library); "pairs": only the MSM pair ranges
     # sharded, the partial points combined through torch.distributed (row 1 only; BENCH_SHARD_LAYOUT=pairs).
-    layout = os.environ.get("BENCH_SHARD_LAYOUT", "vector") if world > 1 else "pairs"
+    layout = os.environ.get("BENCH_SHARD_LAYOUT", "vector") if multi else "pairs"
     comm_desc = None
-    if world > 1 and layout == "vector":
+    if multi and layout == "vector":
         from polymath_amd.distributed import make_comm
         comm, comm_desc = make_comm(rank, world, local, native=(backend == "nccl" and not os.environ.get("BENCH_NO_RCCL")))
         pm.ctx.set_comm(comm)
@@ -170,12 +175,12 @@ def main():
     x_l, w_l = r1cs.inst_limbs, r1cs.wit_limbs
     combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local, backend_gloo=(backend != "nccl")) if world > 1 and layout == "pairs" else None
     py_combine = combine            # for the phase-by-phase (Python glue) proofs
-    if world > 1 and layout == "vector":
+    if multi and layout == "vector":
         from polymath_amd.distributed import CommPointCombiner
         py_combine = CommPointCombiner(comm, curve, pm.field.nq)   # the native path combines inside the library (ctx's pm_comm)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -187,6 +192,7 @@ def main():
     # runs the transcript and challenge arithmetic between the phases); with several ranks it calls back into
     # PointCombiner.many between the phases to exchange the partial points (RCCL all-gather + pm_g1_sum).
     native = (world == shard_count) and not os.environ.get("BENCH_PYTHON_GLUE")
+    comm_info = comm_desc
 
     def prove_once():
         if native:
@@ -287,7 +293,7 @@ def main():
                        (args.log_constraints, curve, n.bit_length() - 1, args.transcript),
                        "msm_pairs_per_proof": pairs_per_proof,
                        "parallelism": ("one proof over %d GPUs: witness map, four-step NTT (one all-to-all per transform), scans and MSM pairs sharded; %s"
-                                       % (world, comm_desc)) if layout == "vector" and world > 1 else "msm-pairs-sharded x%d" % world},
+                                       % (world, comm_desc)) if layout == "vector" and multi else "msm-pairs-sharded x%d" % world},
             "msm_pairs_per_sec": pairs_per_proof / (dt / args.steps),
             "ms_per_step_pcie_inclusive": ms_host_inputs,
             "host_glue": "native (pm_host_prove%s: C++ transcript + challenge arithmetic inside the library)" % ("_sharded" if world > 1 else "")
@@ -316,7 +322,7 @@ def main():
                              "SQ counters (profiles/r02_pmc_valu_k_accumulate.json): 0.95 of the VALU issue slots, clock 1.98 GHz under this load"},
             "proof_bytes": proof_b.hex(),
         }
-        if world == 1 and shard_count == 1:
+        if world == 1 and shard_count == 1 and not multi:
             if not args.no_cpu_baseline:
                 cores = os.cpu_count() or 1
                 cb_log = args.cpu_baseline_log or (args.log_constraints if cores >= 32 and args.log_constraints <= 20 else 16)
@@ -334,7 +340,7 @@ def main():
                 log(rank, "standalone resident MSM legs: 2^{%s} pairs ..." % args.msm_micro)
                 out["msm_micro"] = msm_micro(pm.ctx, curve, [int(v) for v in args.msm_micro.split(",")])
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -18,6 +18,20 @@ using namespace pm;
 extern "C" void pm_host_keccak_f1600(uint64_t state[25]) { pmhost::keccak_f1600(state); }
 
 // ------------------------------------------------------------------------------ helpers
+// body(lo, hi, thread) over [0, count) in contiguous chunks on up to 32 host threads (one below 2^16 items)
+template <class F>
+static void parallel_chunks(uint64_t count, F body) {
+    unsigned T = std::thread::hardware_concurrency();
+    if (T > 32) T = 32;
+    if (T < 1 || count < ((uint64_t)1 << 16)) T = 1;
+    if (const char *e = getenv("PM_HOST_THREADS")) T = (unsigned)std::max(1, atoi(e));
+    if (T == 1) { body((uint64_t)0, count, 0u); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([=, &body] { body(count * t / T, count * (t + 1) / T, t); });
+    body((uint64_t)0, count / T, 0u);
+    for (auto &x : th) x.join();
+}
+
 template <class C>
 static void repack_bases(const void *src, size_t stride, size_t len, Affine<C> *dst) {
     const size_t PT = sizeof(Affine<C>);
@@ -522,7 +536,8 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     // its own as well.
     int inflight = 1;
     if (const char *e = getenv("PM_INFLIGHT_CONTEXTS")) inflight = atoi(e) > 1 ? atoi(e) : 1;
-    double budget = 0.9 * (double)free_b - (double)inflight * 64.0 * 40.0 * (double)pk->n;
+    const uint64_t vec_n = pk->layout == PM_SHARD_VECTOR ? pk->n / (uint64_t)pk->shard_count : pk->n;   // length of a rank's vectors
+    double budget = 0.9 * (double)free_b - (double)inflight * 64.0 * 40.0 * (double)vec_n;
     {
         const uint64_t len_d = pk->res_cnt[2], len_a = pk->res_cnt[0];
         budget -= (double)inflight * 256.0 * (double)(len_d < (uint64_t)msm_max_piece() ? len_d : (uint64_t)msm_max_piece());
@@ -623,50 +638,76 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
     Fr y = pow_u64<P>(x, sigma), yinv = inverse<P>(y);                            // generator.rs:73
     Fr y_alpha = pow_u64<P>(yinv, 3), y_to_minus_alpha = pow_u64<P>(y, 3), y_gamma = pow_u64<P>(yinv, 5);
     Fr zh = sub<P>(xn, one);                                                       // :106
-    // Lagrange coefficients at x (:113): L_i = zh/n * w^i / (x - w^i), host batch inversion
-    std::vector<Fr> L(n), den(n), pre(n);
+    // Lagrange coefficients at x (:113): L_i = zh/n * w^i / (x - w^i), host batch inversion -- in parallel chunks (every chunk
+    // starts from its own w^lo and inverts its own running product; the values are field elements, so the chunking cannot
+    // change them).  At n = 2^25 these loops are ~3 x 10^8 host multiplications: minutes on one thread.
+    std::vector<Fr> L(n);
     {
-        Fr wi = one, run = one;
-        for (uint64_t i = 0; i < n; ++i) {
-            den[i] = sub<P>(x, wi);
-            L[i] = wi;
-            pre[i] = run;
-            run = mul<P>(run, den[i]);
-            wi = mul<P>(wi, omega);
-        }
-        Fr inv = inverse<P>(run), k = mul<P>(zh, inverse<P>(from_u64<P>(n)));
-        for (uint64_t i = n; i-- > 0;) {
-            Fr di = mul<P>(inv, pre[i]);
-            inv = mul<P>(inv, den[i]);
-            L[i] = mul<P>(mul<P>(L[i], di), k);
-        }
+        const Fr kscale = mul<P>(zh, inverse<P>(from_u64<P>(n)));
+        parallel_chunks(n, [&](uint64_t lo, uint64_t hi, unsigned) {
+            std::vector<Fr> den(hi - lo), pre(hi - lo);
+            Fr wi = pow_u64<P>(omega, lo), run = one;
+            for (uint64_t i = lo; i < hi; ++i) {
+                den[i - lo] = sub<P>(x, wi);
+                L[i] = wi;
+                pre[i - lo] = run;
+                run = mul<P>(run, den[i - lo]);
+                wi = mul<P>(wi, omega);
+            }
+            Fr inv = inverse<P>(run);
+            for (uint64_t i = hi; i-- > lo;) {
+                Fr di = mul<P>(inv, pre[i - lo]);
+                inv = mul<P>(inv, den[i - lo]);
+                L[i] = mul<P>(mul<P>(L[i], di), kscale);
+            }
+        });
     }
+    // the sparse lcs pass: every thread owns a range of COLUMNS (no two threads add into one accumulator) and walks all rows
     std::vector<Fr> ucol(mcols, Fr::zero()), wcol(Lz, Fr::zero());
-    for (uint64_t r = 0; r < nr; ++r) {
-        Fr L1 = L[2 * m0 + r], L2 = L[2 * m0 + nr + r], sp = add<P>(L1, L2), sm = sub<P>(L1, L2), L1x4 = dbl<P>(dbl<P>(L1));
-        for (uint64_t k = host[0].rowptr[r]; k < host[0].rowptr[r + 1]; ++k) {
-            Fr v; memcpy(v.l, &host[0].val[4 * k], 32);
-            ucol[host[0].col[k]] = add<P>(ucol[host[0].col[k]], mul<P>(v, sp));
+    parallel_chunks(mcols, [&](uint64_t clo, uint64_t chi, unsigned) {
+        for (uint64_t r = 0; r < nr; ++r) {
+            const uint64_t a0 = host[0].rowptr[r], a1 = host[0].rowptr[r + 1], b0 = host[1].rowptr[r], b1 = host[1].rowptr[r + 1],
+                           c0 = host[2].rowptr[r], c1 = host[2].rowptr[r + 1];
+            bool mine = false;
+            for (uint64_t k = a0; k < a1 && !mine; ++k) mine = host[0].col[k] >= clo && host[0].col[k] < chi;
+            for (uint64_t k = b0; k < b1 && !mine; ++k) mine = host[1].col[k] >= clo && host[1].col[k] < chi;
+            for (uint64_t k = c0; k < c1 && !mine; ++k) mine = host[2].col[k] >= clo && host[2].col[k] < chi;
+            if (!mine) continue;
+            const Fr L1 = L[2 * m0 + r], L2 = L[2 * m0 + nr + r], sp = add<P>(L1, L2), sm = sub<P>(L1, L2), L1x4 = dbl<P>(dbl<P>(L1));
+            for (uint64_t k = a0; k < a1; ++k) {
+                const uint32_t cc = host[0].col[k];
+                if (cc < clo || cc >= chi) continue;
+                Fr v; memcpy(v.l, &host[0].val[4 * k], 32);
+                ucol[cc] = add<P>(ucol[cc], mul<P>(v, sp));
+            }
+            for (uint64_t k = b0; k < b1; ++k) {
+                const uint32_t cc = host[1].col[k];
+                if (cc < clo || cc >= chi) continue;
+                Fr v; memcpy(v.l, &host[1].val[4 * k], 32);
+                ucol[cc] = add<P>(ucol[cc], mul<P>(v, sm));
+            }
+            for (uint64_t k = c0; k < c1; ++k) {
+                const uint32_t cc = host[2].col[k];
+                if (cc < clo || cc >= chi) continue;
+                Fr v; memcpy(v.l, &host[2].val[4 * k], 32);
+                wcol[cc] = add<P>(wcol[cc], mul<P>(v, L1x4));
+            }
         }
-        for (uint64_t k = host[1].rowptr[r]; k < host[1].rowptr[r + 1]; ++k) {
-            Fr v; memcpy(v.l, &host[1].val[4 * k], 32);
-            ucol[host[1].col[k]] = add<P>(ucol[host[1].col[k]], mul<P>(v, sm));
-        }
-        for (uint64_t k = host[2].rowptr[r]; k < host[2].rowptr[r + 1]; ++k) {
-            Fr v; memcpy(v.l, &host[2].val[4 * k], 32);
-            wcol[host[2].col[k]] = add<P>(wcol[host[2].col[k]], mul<P>(v, L1x4));
-        }
-        wcol[mcols + m0 + r] = sp;
-    }
+    });
+    parallel_chunks(nr, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t r = lo; r < hi; ++r) wcol[mcols + m0 + r] = add<P>(L[2 * m0 + r], L[2 * m0 + nr + r]);
+    });
     for (uint64_t i = 0; i < m0; ++i) {
         wcol[i] = add<P>(wcol[i], dbl<P>(dbl<P>(L[i])));
         wcol[mcols + i] = add<P>(L[i], L[i + m0]);
     }
     std::vector<Fr> lcs(Lz);
-    for (uint64_t j = 0; j < Lz; ++j) {
-        Fr u = j < mcols ? ucol[j] : Fr::zero();
-        lcs[j] = mul<P>(add<P>(mul<P>(u, y_gamma), wcol[j]), y_to_minus_alpha);  // :134
-    }
+    parallel_chunks(Lz, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t j = lo; j < hi; ++j) {
+            Fr u = j < mcols ? ucol[j] : Fr::zero();
+            lcs[j] = mul<P>(add<P>(mul<P>(u, y_gamma), wcol[j]), y_to_minus_alpha);  // :134
+        }
+    });
     // per-vector scale of the x-power vectors (generator.rs:82-109)
     Fr scale[PM_NUM_BASE_VECS];
     scale[PM_X_POWERS] = one;

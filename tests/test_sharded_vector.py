@@ -269,3 +269,54 @@ def test_config_2p22_eight_ranks_vector_sharded():
     assert sum(pk.msm_plan(2)[0] for pk in pks) == 10 * (1 << 23) + 22          # the quotient's pairs, each exactly once
     for pk in pks:
         pk.free()
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_launch_path_with_a_world_of_one():
+    """What a one-GPU box can check of the driver's multi-GPU launch: bench.py under torch.distributed.run with the `nccl`
+    (RCCL) process group, BENCH_FORCE_VECTOR=1 -- the library's own RCCL communicator (dlopen, ncclCommInitRank from the id
+    broadcast over torch.distributed) next to torch's, a PM_SHARD_VECTOR key, ncclAllToAll / ncclAllGather inside the phases.
+    Same proof bytes as the plain single-GPU run, and the JSON line says the native communicator was used."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "1", "--warmup", "0", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", ""]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    env = dict(os.environ, BENCH_FORCE_VECTOR="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29546", os.path.join(root, "bench.py"), "--gpus", "1"] + common,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["proof_bytes"] == j2["proof_bytes"]
+    assert "rccl (native" in j2["config"]["parallelism"], j2["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_config_2p24_eight_ranks_vector_sharded(monkeypatch):
+    """BASELINE configs[3] as named: the 2^24-100-gate circuit (n = 2^25, 470 M MSM pairs), "NTT domain + MSM both 8-way
+    partitioned" -- 8 ranks (threads on the one GPU of the box) each holding 1/8 of the key (5.6 GB of bases), 2^22 rows,
+    2^22 coefficients in 8 blocks of 2^19, 42 M quotient pairs; local transforms of 2^22 points, four all-to-alls of 16 MB
+    blocks per rank.  Byte-identical to the single-GPU proof (which test_gpu_configs.py::test_config_2p24_one_gpu_piece_split
+    checks with the pairing verifier).  The ranks' keys are built without window tables: eight ranks' tables do not fit ONE
+    GPU's 288 GB (on eight GPUs they do); the table pipeline is covered at the smaller sizes."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    curve, N = "bls12_381", 8
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, (1 << 24) - 100)
+    g = PC.SplitMix64(0x2424)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    ref_pm = Polymath(curve, "merlin", device=0)
+    ref_pk = ref_pm.setup(lc, x, z)
+    ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+    ref_pk.free()
+    ref_pm.ctx.close()
+    monkeypatch.setenv("PM_TABLES", "0")
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    assert all(p == ref for p in proofs)
+    for pk in pks:
+        pk.free()
+    for pm in pms:
+        pm.ctx.close()
