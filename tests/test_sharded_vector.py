@@ -52,6 +52,18 @@ def test_layout_four_step_equals_direct_transform(oracle, N):
     assert _four_step_intt(oracle, curve, evals, n, N) == direct
 
 
+def test_layout_selftest_native(tmp_path):
+    """tests/native/layout_selftest.cpp: the index maps are bijections, every rank's quotient segments tile the numerator
+    index space exactly once, the MSM piece lists cover every pair once (plus [c]'s N^2 - 1 shared block-end bases), and the
+    per-rank counts the sharded prover assumes hold -- n = 4 ... 2^16, N = 1 ... 16, two sub-segment sizes."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "layout_selftest")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "native", "layout_selftest.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "0 failures" in out.stdout, out.stdout
+
+
 def test_layout_rejects_bad_shapes():
     from polymath_amd import api
     with pytest.raises(api.PolymathError):
@@ -320,3 +332,37 @@ def test_config_2p24_eight_ranks_vector_sharded(monkeypatch):
         pk.free()
     for pm in pms:
         pm.ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_vector_sharded_tiny_domains_and_ragged_shapes(curve):
+    """The smallest shapes the layout admits: the reference's dummy circuit (tests/dummy.rs: n = 8, N = 2, blocks of B = 2),
+    5 gates on n = 16 with N = 4 (B = 1: every block is one coefficient, rank 3's h block is empty), the reference's bench
+    shape with unused witnesses (bases at infinity) and 7 gates, and a domain with a ragged tail of zero rows (nr = 9 -> 22 rows
+    of 32).  Byte-identical to the unsharded proof each time."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Field, LimbCircuit, Polymath, _csr
+    c = CURVES[curve]
+    f = Field(curve)
+    g = PC.SplitMix64(0x717)
+
+    def limb_circuit(r1cs, inst, wit):
+        return LimbCircuit(f, r1cs.m0, r1cs.mw, r1cs.nr, (_csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)), f.fr_limbs(inst), f.fr_limbs(wit))
+    pm0 = Polymath(curve, "keccak256", device=0)
+    cases = []
+    cases.append((limb_circuit(*pm0._synthesize(PC.DummyCircuit(g.fr(c.r), g.fr(c.r)))), [2]))
+    cases.append((limb_circuit(*PC.synthetic_r1cs(c.r, 5)), [2, 4]))
+    cases.append((limb_circuit(*pm0._synthesize(PC.BenchCircuit(g.fr(c.r), g.fr(c.r), 9, 7))), [2, 4]))
+    cases.append((limb_circuit(*PC.synthetic_r1cs(c.r, 9)), [2, 4]))
+    for lc, ranks in cases:
+        x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+        ref_pk = pm0.setup(lc, x, z)
+        ref = pm0.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+        for N in ranks:
+            assert ref_pk.n % (N * N) == 0
+            pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, transcript="keccak256")
+            assert all(p == ref for p in proofs), (lc.nr, N)
+            for pk in pks:
+                pk.free()
+        ref_pk.free()
