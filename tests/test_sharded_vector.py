@@ -366,3 +366,46 @@ def test_vector_sharded_tiny_domains_and_ragged_shapes(curve):
             for pk in pks:
                 pk.free()
         ref_pk.free()
+
+
+@pytest.mark.gpu
+def test_vector_sharded_keys_loaded_from_an_existing_key():
+    """pm_pk_load_sharded(layout = PM_SHARD_VECTOR): every rank uploads only ITS pieces of an existing ProvingKey given in
+    arkworks' 104-byte G1Affine layout (x, y, infinity flag) -- the path a Rust host takes -- and the
+    4 ranks' proof equals the proof of the key generated on one GPU.  Exported bases of a shard match the whole key's."""
+    from polymath_amd import api, circuits as PC
+    from polymath_amd.polymath import Polymath
+    curve, N = "bls12_381", 4
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, 1000)
+    g = PC.SplitMix64(0x10AD)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    pm0 = Polymath(curve, "merlin", device=0)
+    whole = pm0.setup(lc, x, z)
+    ref = pm0.prove_native(whole, lc.inst_limbs, lc.wit_limbs, r_a)
+    arrays = []
+    for i in range(6):
+        b = whole.export_bases(i)
+        wide = np.zeros((b.shape[0], 13), dtype=np.uint64)
+        wide[:, :12] = b
+        wide[:, 12] = (~b.any(axis=1)).astype(np.uint64)
+        arrays.append(wide)
+    comms = api.Comm.local_group(N)
+    pms = [Polymath(curve, "merlin", device=0) for _ in range(N)]
+    pks = []
+    for r in range(N):
+        pms[r].ctx.set_comm(comms[r])
+        pk = api.ProvingKey.load(pms[r].ctx, curve, whole.n, lc.m0, lc.mw, lc.nr, whole.sigma, *lc.csrs, arrays, shard_rank=r,
+                                 shard_count=N, layout="vector")
+        pk.omega = whole.omega
+        pks.append(pk)
+    assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a)))
+    # a shard can export exactly the bases it holds: piece (cat_lo, count) of MSM [a] <-> x_powers[...]
+    off_xp = 2 * lc.m0 + lc.mw + lc.nr + (whole.n - 1)
+    lo, cnt = pks[1].msm_pieces(0)[0]
+    assert np.array_equal(pks[1].export_bases(api.X_POWERS, lo - off_xp, cnt), arrays[api.X_POWERS][lo - off_xp:lo - off_xp + cnt, :12])
+    with pytest.raises(api.PolymathError):
+        pks[1].export_bases(api.X_POWERS, 0, 4)            # not resident on rank 1
+    for pk in pks:
+        pk.free()
+    whole.free()
