@@ -182,6 +182,161 @@ __global__ __launch_bounds__(256) void k_ntt_first_pass(const Fp<P> *src, Fp<P> 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round-2 pass kernels: the tile lives in LDS on 28-BIT LIMBS (10 x u32 per element, limb-major planes -- one bank per
+// lane for every access), so a butterfly is one carry-free product (fq28.cuh) plus lazy limb-wise add / sub and a carry
+// propagation: no dense <-> reduced-radix conversion of the data and no modular correction per stage (~400 instead of
+// 608 instructions per butterfly).  Fr has 280 - 255 = 25 spare bits: values grow by at most 4p per stage (x + yw < V + 2,
+// x + 4p - yw < V + 4), 37p after nine stages, far below the 2^25 p the product tolerates; they are brought back to the
+// canonical range once, on the way out (conditional subtractions of 32p ... p; in the last pass of an inverse transform the
+// n^-1 product does it).  Elements enter and leave in the dense canonical form: the results are bit-identical.
+// 256 threads and one 80 KiB tile per workgroup: exactly two workgroups share a CU's 160 KiB (tools/lds_occupancy.hip: 80 KiB -> 2,
+// 81 KiB -> 1) = 2 waves per SIMD, and one workgroup's barriers and loads hide under the other's butterflies.
+constexpr unsigned L28_THREADS = 256;
+
+template <class RR>
+__device__ __forceinline__ F28<RR> l28_load(const uint32_t *t, unsigned tile, unsigned e) {
+    F28<RR> r;
+#pragma unroll
+    for (int l = 0; l < RR::N; ++l) r.l[l] = t[l * tile + e];
+    return r;
+}
+template <class RR>
+__device__ __forceinline__ void l28_store(uint32_t *t, unsigned tile, unsigned e, const F28<RR> &v) {
+#pragma unroll
+    for (int l = 0; l < RR::N; ++l) t[l * tile + e] = v.l[l];
+}
+// tight limbs, value < 64 p  ->  canonical (< p): conditional subtraction of 32p, 16p, ..., p (limbs of p << j by constant shifts)
+template <class RR>
+__device__ __forceinline__ F28<RR> l28_canonical(F28<RR> x) {
+#pragma unroll
+    for (int j = 5; j >= 0; --j) {
+        uint32_t t[RR::N];
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < RR::N; ++i) {
+            uint32_t m = (RR::MOD[i] << j) & RR::MASK;
+            if (i > 0 && j > 0) m |= RR::MOD[i - 1] >> (RR::W - j);
+            const uint32_t v = x.l[i] - m - borrow;       // the top limb of p << j (j <= 5) stays below 2^28 for both scalar fields
+            borrow = v >> 31;
+            t[i] = v & RR::MASK;
+        }
+        if (!borrow) {
+#pragma unroll
+            for (int i = 0; i < RR::N; ++i) x.l[i] = t[i];
+        }
+    }
+    return x;
+}
+template <class RR>
+__device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d) {   // canonical 28-bit limbs -> dense 32-bit limbs
+#pragma unroll
+    for (int w = 0; w < RR::N32; ++w) {
+        const int bit = 32 * w, i = bit / RR::W, s = bit % RR::W;
+        uint64_t v = (uint64_t)c.l[i] >> s;
+        if (i + 1 < RR::N) v |= (uint64_t)c.l[i + 1] << (RR::W - s);
+        if (i + 2 < RR::N && 2 * RR::W - s < 32) v |= (uint64_t)c.l[i + 2] << (2 * RR::W - s);
+        d[w] = (uint32_t)v;
+    }
+}
+
+// the ns butterfly stages on the tile; element (r, c) sits at slot r * cols + (FIRST ? (c + r) & (cols - 1) : c)
+template <class P, class RR, bool FIRST>
+__device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Fp<P> *tw, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols,
+                                           size_t lo0) {
+    const unsigned cols = 1u << log_cols, cm = cols - 1, rows = 1u << ns, nbf = (rows >> 1) * cols, tid = threadIdx.x;
+    for (unsigned st = 0; st < ns; ++st) {
+        const unsigned s = s0 + st + 1, half = 1u << st;
+        auto slots = [&](unsigned e, unsigned &e0, unsigned &e1, size_t &j) {
+            const unsigned c = e & cm, k = e >> log_cols;
+            const unsigned r0 = ((k >> st) << (st + 1)) | (k & (half - 1)), r1 = r0 + half;
+            j = FIRST ? (size_t)(r0 & (half - 1)) : ((size_t)(r0 & (half - 1)) << s0) + lo0 + c;
+            e0 = r0 * cols + (FIRST ? ((c + r0) & cm) : c);
+            e1 = r1 * cols + (FIRST ? ((c + r1) & cm) : c);
+        };
+        auto bfly = [&](unsigned e0, unsigned e1, const Fp<P> &wd) {
+            const F28<RR> x = l28_load<RR>(t, tile, e0), y = l28_load<RR>(t, tile, e1);
+            const F28<RR> yw = f28_mul<RR>(y, f28_unpack<RR>(wd.l));                 // tight, < 2p
+            l28_store<RR>(t, tile, e0, f28_weak_norm<RR>(f28_add<RR>(x, yw)));       // < V + 2
+            l28_store<RR>(t, tile, e1, f28_weak_norm<RR>(f28_sub_k4<RR>(x, yw)));    // x + 4p - yw < V + 4
+        };
+        if (nbf == 4 * L28_THREADS) {   // full tile: the four twiddle loads of this lane's butterflies are issued before the arithmetic
+            Fp<P> w[4];
+            unsigned e0v[4], e1v[4];
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) {
+                size_t j;
+                slots(tid + q * L28_THREADS, e0v[q], e1v[q], j);
+                w[q] = tw[j << (log_n - s)];
+            }
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) bfly(e0v[q], e1v[q], w[q]);
+        } else {
+            for (unsigned e = tid; e < nbf; e += L28_THREADS) {
+                unsigned e0, e1;
+                size_t j;
+                slots(e, e0, e1, j);
+                bfly(e0, e1, tw[j << (log_n - s)]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <class P, class RR>
+__device__ __forceinline__ void l28_emit(const F28<RR> &v, Fp<P> *dst, const F28<RR> &scale28, int do_scale) {
+    const F28<RR> c = do_scale ? f28_mul<RR>(v, scale28) : v;    // the product's output is < 2p: the subtraction chain then ends at once
+    Fp<P> out;
+    l28_pack_canonical<RR>(l28_canonical<RR>(c), out.l);
+    *dst = out;
+}
+
+// general pass: stages [s0, s0 + ns), tile of 2^ns rows x 2^log_cols contiguous columns, src -> dst at the same positions
+template <class P, class RR>
+__global__ __launch_bounds__(L28_THREADS) void k_ntt_pass28(const Fp<P> *a, Fp<P> *dst, const Fp<P> *tw, unsigned log_n, unsigned s0, unsigned ns,
+                                                             unsigned log_cols, Fp<P> scale_int, int do_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *t = (uint32_t *)smem_raw;
+    const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols;
+    const size_t lo_groups = ((size_t)1 << s0) >> log_cols, g = blockIdx.x;
+    const size_t hi = g / lo_groups, lo0 = (g % lo_groups) << log_cols, base = (hi << (s0 + ns)) + lo0;
+    for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
+        const unsigned r = e >> log_cols, c = e & (cols - 1);
+        const Fp<P> v = a[base + ((size_t)r << s0) + c];
+        l28_store<RR>(t, tile, e, f28_unpack<RR>(v.l));
+    }
+    __syncthreads();
+    l28_stages<P, RR, false>(t, tile, tw, log_n, s0, ns, log_cols, lo0);
+    const F28<RR> sc = f28_unpack<RR>(scale_int.l);
+    for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
+        const unsigned r = e >> log_cols, c = e & (cols - 1);
+        l28_emit<P, RR>(l28_load<RR>(t, tile, e), &dst[base + ((size_t)r << s0) + c], sc, do_scale);
+    }
+}
+
+// first pass with the bit reversal folded into its loads (see k_ntt_first_pass), src -> dst
+template <class P, class RR>
+__global__ __launch_bounds__(L28_THREADS) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Fp<P> *tw, unsigned log_n, unsigned ns,
+                                                                   unsigned log_cols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *t = (uint32_t *)smem_raw;
+    const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols, H = log_n - ns, cm = cols - 1;
+    const size_t g = blockIdx.x;
+    for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
+        const unsigned rb = e >> log_cols, c = e & cm, r = __brev(rb) >> (32 - ns);
+        const Fp<P> v = src[((size_t)rb << H) + (g << log_cols) + c];
+        l28_store<RR>(t, tile, r * cols + ((c + r) & cm), f28_unpack<RR>(v.l));
+    }
+    __syncthreads();
+    l28_stages<P, RR, true>(t, tile, tw, log_n, 0, ns, log_cols, 0);
+    const F28<RR> none = f28_zero<RR>();
+    for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
+        const unsigned c = e >> ns, r = e & (rows - 1);
+        const size_t hi = __brevll((unsigned long long)((g << log_cols) + c)) >> (64 - H);
+        l28_emit<P, RR>(l28_load<RR>(t, tile, r * cols + ((c + r) & cm)), &dst[(hi << ns) + r], none, 0);
+    }
+}
+
 template <class P>
 __global__ void k_scale(Fp<P> *a, size_t n, Fp<P> s) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,6 +403,42 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     const unsigned tile_log = log_n > 24 ? (unsigned)LOG_TILE + 1 : (unsigned)LOG_TILE;
     const Fr ninv = inv_dir ? inverse<P>(from_u64<P>((uint64_t)n)) : Fr::one();
     static const bool fused = [] { const char *e = getenv("PM_NTT_FUSED"); return !(e && e[0] == '0'); }();
+    static const bool l28 = [] { const char *e = getenv("PM_NTT_L28"); return !(e && e[0] == '0'); }();
+    if (fused && l28 && log_n >= tile_log + 3) {
+        // the same pass structure on the 28-bit-limb tiles (k_ntt_pass28): 2^11 elements x 40 B = 80 KiB of LDS per workgroup
+        PM_HIP(ctx, ctx->ntt_tmp.reserve(n * sizeof(Fr)));
+        Fr *tmp = ctx->ntt_tmp.as<Fr>();
+        typedef typename C::FrRR RR;
+        const size_t lds28 = ((size_t)1 << 11) * RR::N * 4;
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[C::ID]) {
+            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_pass28<P, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds28));
+            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_first_pass28<P, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds28));
+            attr_set[C::ID] = true;
+        }
+        Fr scale_int;
+        for (int i = 0; i < P::N; ++i) scale_int.l[i] = RR::STD2INT[i];
+        scale_int = mul<P>(ninv, scale_int);                      // n^-1 2^280 as a plain integer: the product with it scales AND reduces
+        {
+            const unsigned ns = tile_log, log_cols = 11 - ns;
+            hipLaunchKernelGGL((k_ntt_first_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
+                               ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)d, tmp, tw, log_n, ns, log_cols);
+            PM_HIP(ctx, hipGetLastError());
+        }
+        unsigned s0 = tile_log;
+        while (s0 < log_n) {
+            const unsigned ns = log_n - s0 < tile_log ? log_n - s0 : tile_log;
+            unsigned log_cols = 11 - ns < 3 ? 11 - ns : 3;
+            if (s0 < log_cols) log_cols = s0;
+            const bool last = s0 + ns == log_n;
+            hipLaunchKernelGGL((k_ntt_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
+                               ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)tmp, last ? d : tmp, tw, log_n, s0, ns, log_cols,
+                               scale_int, last && inv_dir ? 1 : 0);
+            PM_HIP(ctx, hipGetLastError());
+            s0 += ns;
+        }
+        return PM_OK;
+    }
     if (fused && log_n >= tile_log + 3) {
         // >= 2 passes: d -> tmp (bit reversal folded into the first pass's loads), middle passes in place on tmp,
         // tmp -> d (n^-1 folded into the last pass's stores): no k_bitrev and no k_scale round trip through HBM
