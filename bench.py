@@ -73,6 +73,45 @@ def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
             "seconds": dt, "proof_identical_to_gpu": same, "msm_pairs_per_sec": pairs / dt}
 
 
+def live_traffic(args, timeout_s=200):
+    """HBM traffic of k_accumulate measured NOW, by this run: two child processes of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md's HBM section
+    prescribes), PM_MSM_OVERLAP=0 so that every launch runs alone; per-launch bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B
+    requests at 64 B; calibrated on this access pattern by tools/pmc_gather_calib.hip) + WRITE_SIZE, both in KB.
+    -> (bytes per launch, description) or (None, reason): the caller then falls back to the committed profile."""
+    import csv, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled"
+    totals = {}
+    launches = None
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pm_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic",
+               "--log-constraints", str(args.log_constraints), "--curve", args.curve, "--transcript", args.transcript]
+        env = dict(os.environ, PM_MSM_OVERLAP="0", TMPDIR="/tmp")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            path = None
+            for root_, _dirs, files in os.walk(d):
+                if "run_counter_collection.csv" in files:
+                    path = os.path.join(root_, "run_counter_collection.csv")
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "k_accumulate" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if not vals:
+                return None, "no k_accumulate rows in the %s pass" % ctr
+            totals[ctr] = sum(vals) / len(vals)
+            launches = len(vals)
+        except Exception as e:       # noqa: BLE001 -- a missing profiler must not cost the bench line
+            return None, "%s pass failed: %s" % (ctr, type(e).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"]) * 1024.0, \
+        "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes (PM_MSM_OVERLAP=0, %d launches each); bytes = 2 x FETCH_SIZE + WRITE_SIZE" % launches
+
+
 def msm_micro(ctx, curve, logs, reps=3):
     """The second half of the metric (SURVEY.md §8d: "G1 MSM pairs/s = L / time of pm_msm_g1, bases resident";
     benches/bench.rs:82-91 is the reference's only analogue): standalone resident MSM, bases P_i = (i+1) G built on the
@@ -114,6 +153,7 @@ def main():
     ap.add_argument("--cpu-baseline-log", type=int, default=0, help="0 = the headline workload itself when this box has >= 32 host threads, else 2^16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-micro", default="20,22,24,26", help="log2 lengths of the standalone resident MSM legs ('' = none)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure `roofline.traffic`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -275,7 +315,7 @@ def main():
         achieved = (bpp * pairs_rank / acc_s / 1e9) if acc_s > 0 else 0.0
         mads_rank = float(MADS_PER_MIXED_ADD[curve]) * sum(p[0] * p[1] for p in plans)
         msm_windows = plans[2][1]
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
@@ -305,7 +345,7 @@ def main():
                                 "msm_total": avg(msm_ms), "phase3_total": avg(phase_ms)},
             "roofline": {"bound": "hbm", "kernel": "k_accumulate (MSM bucket accumulation; %d launches per proof: [a], [c], [d])" % launches,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured by this run)",
+                         "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
                          "launches_per_step": launches, "avg_launch_ms": acc_s * 1e3 / launches,
                          "timing": "HIP events on the library's stream around each launch of one PM_MSM_OVERLAP=0 proof outside the timed region "
                                    "(launches run alone); in the timed proofs [a] overlaps other kernels: %.3f ms per proof there" % (acc_overlapped_s * 1e3),
@@ -323,6 +363,15 @@ def main():
             "proof_bytes": proof_b.hex(),
         }
         if world == 1 and shard_count == 1 and not multi:
+            if not args.no_live_traffic:
+                pk_bytes_note = "(the parent's key stays resident: the children build their own)"
+                log(rank, "measuring k_accumulate's HBM traffic: two rocprofv3 --pmc child passes %s ..." % pk_bytes_note)
+                live, how = live_traffic(args)
+                if live is not None:
+                    out["roofline"]["traffic_committed_profile"] = out["roofline"]["traffic"]
+                    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = live, how
+                else:
+                    out["roofline"]["traffic_source"] += "; live measurement unavailable (%s)" % how
             if not args.no_cpu_baseline:
                 cores = os.cpu_count() or 1
                 cb_log = args.cpu_baseline_log or (args.log_constraints if cores >= 32 and args.log_constraints <= 20 else 16)

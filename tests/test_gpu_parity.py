@@ -482,7 +482,7 @@ def test_bench_two_ranks_one_gpu_same_proof():
     proof bytes as the single-rank run."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "1", "--warmup", "0", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", ""]
+    common = ["--steps", "1", "--warmup", "0", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0")
