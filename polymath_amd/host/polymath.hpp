@@ -1,8 +1,9 @@
 // C++ host mirror of the reference's prover-side API above the C ABI (include/polymath_hip.h):
 //
 //   reference (Rust)                                   here
-//   Polymath<E, T>::setup(circuit, rng)   lib.rs:63    Polymath<Curve, T>::setup(circuit, x, z)      trapdoors = the two rng draws
-//   Polymath<E, T>::prove(pk, circuit, rng) lib.rs:72  Polymath<Curve, T>::prove(pk, circuit, r_a)   r_a = the two F::rand of prover.rs:110
+//   Polymath<E, T>::setup(circuit, rng)   lib.rs:63    Polymath<Curve, T>::setup(circuit, rng)  or  setup(circuit, x, z)      trapdoors = the two rng draws
+//   Polymath<E, T>::prove(pk, circuit, rng) lib.rs:72  Polymath<Curve, T>::prove(pk, circuit, rng)  or  prove(pk, circuit, r_a)   r_a = the two F::rand of prover.rs:110
+//   rand::rngs::StdRng, ark_std::test_rng, F::rand     StdRng (rng.hpp), FrOps<Curve>::rand
 //   trait ConstraintSynthesizer::generate_constraints  struct with generate_constraints(ConstraintSystem&)
 //   trait Transcript {new, append_message, challenge}  MerlinFieldTranscript / Keccak256Transcript / Blake3Transcript
 //   Proof { a_g1, c_g1, a_at_x1, d_g1 } + CanonicalSerialize (compressed)   Proof::to_bytes()
@@ -22,6 +23,7 @@
 #include "../csrc/ec.cuh"
 #include "hashes.hpp"
 #include "pairing.hpp"
+#include "rng.hpp"
 
 namespace pmhost {
 
@@ -44,6 +46,8 @@ struct FrOps {
     static Fr inv(const Fr &a) { return pm::inverse<P>(a); }
     static Fr pow(const Fr &a, uint64_t e) { return pm::pow_u64<P>(a, e); }
     static Fr neg(const Fr &a) { return pm::neg<P>(a); }
+    template <class Rng>
+    static Fr rand(Rng &rng) { return fr_rand<P, Fr>(rng); }   // F::rand(rng) (ark-ff UniformRand)
     // canonical little-endian 32 bytes (ark-serialize Fp)
     static void to_le_bytes(const Fr &a, uint8_t out[32]) {
         Fr c = pm::from_mont<P>(a);
@@ -264,6 +268,37 @@ public:
         return pk;
     }
 
+    // the reference's own signature: the two trapdoors are drawn from `rng` exactly as generate_proving_key does
+    // (generator.rs:72,77: sample_element_outside_domain twice, x then z)
+    template <class Circuit, class Rng, class = decltype(std::declval<Rng &>().next_u64())>
+    ProvingKey<C> setup(const Circuit &circuit, Rng &rng) {
+        ConstraintSystem<C> cs;
+        circuit.generate_constraints(cs);
+        uint64_t n = 1;
+        while (n < 2 * (cs.instance.size() + cs.a.size())) n <<= 1;          // Radix2EvaluationDomain::new, generator.rs:60
+        auto outside = [&] {
+            for (;;) {
+                Fr t = F::rand(rng);
+                if (!F::pow(t, n).eq(Fr::one())) return t;                    // evaluate_vanishing_polynomial(t) != 0
+            }
+        };
+        const Fr x = outside(), z = outside();
+        last_trapdoors_[0] = x;
+        last_trapdoors_[1] = z;
+        return setup(circuit, x, z);
+    }
+    // the trapdoors the rng form of setup drew (the reference returns the vk instead; make_vk needs them here)
+    const Fr *last_trapdoors() const { return last_trapdoors_; }
+
+    // prove (lib.rs:72-78) with the reference's signature: r_a = two F::rand draws (prover.rs:110), constant term first
+    template <class Circuit, class Rng, class = decltype(std::declval<Rng &>().next_u64())>
+    Proof<C> prove(const ProvingKey<C> &pk, const Circuit &circuit, Rng &rng) {
+        ConstraintSystem<C> cs;
+        circuit.generate_constraints(cs);                          // prover.rs:44 (synthesis draws nothing)
+        const Fr r_a[2] = {F::rand(rng), F::rand(rng)};
+        return prove_with_assignment(pk, cs.instance, cs.witness, r_a);
+    }
+
     // prove (lib.rs:72-78) -> create_proof (prover.rs:27-64) -> create_proof_with_assignment (:66-237)
     template <class Circuit>
     Proof<C> prove(const ProvingKey<C> &pk, const Circuit &circuit, const Fr r_a[2]) {
@@ -417,6 +452,7 @@ public:
 
 private:
     Context &ctx_;
+    Fr last_trapdoors_[2];
     static CsrHost to_csr(const ConstraintSystem<C> &cs, const std::vector<typename ConstraintSystem<C>::LC> &rows) {
         CsrHost m;
         for (const auto &row : rows) {

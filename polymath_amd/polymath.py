@@ -319,8 +319,21 @@ class Polymath:
         self.collect_timings, self.phase_timings = False, []    # per-phase stage timings (pm_last_timings), opt-in
 
     # circuit_specific_setup (lib.rs:63-70) -> generate_proving_key (generator.rs:24-167)
-    def setup(self, circuit, x_trapdoor, z_trapdoor, shard_rank=0, shard_count=1, layout="pairs"):
+    def setup(self, circuit, x_trapdoor, z_trapdoor=None, shard_rank=0, shard_count=1, layout="pairs"):
+        """setup(circuit, rng): the reference's signature (lib.rs:63-70) -- the two trapdoors are drawn from `rng` exactly as
+        generate_proving_key does (generator.rs:72,77: sample_element_outside_domain twice, x then z; polymath_amd.rng).
+        setup(circuit, x, z): the draws supplied by the caller."""
         f = self.field
+        if z_trapdoor is None and hasattr(x_trapdoor, "next_u64"):
+            from . import rng as RNG
+            rng = x_trapdoor
+            shape = circuit if isinstance(circuit, LimbCircuit) else self._synthesize(circuit)[0]
+            n = 1
+            while n < 2 * (shape.m0 + shape.nr):
+                n <<= 1
+            x_trapdoor = RNG.sample_element_outside_domain(rng, f.r, n)
+            z_trapdoor = RNG.sample_element_outside_domain(rng, f.r, n)
+            self.last_trapdoors = (x_trapdoor, z_trapdoor)
         if isinstance(circuit, LimbCircuit):
             r1cs, (A, B, C) = circuit, circuit.csrs
         else:
@@ -340,8 +353,13 @@ class Polymath:
 
     # prove (lib.rs:72-78) -> create_proof (prover.rs:27-64) -> create_proof_with_assignment (:66-237)
     def prove(self, pk, circuit, r_a, combine=None):
-        """`combine(xy, inf) -> (xy, inf)` merges per-shard partial points across ranks (RCCL
+        """prove(pk, circuit, rng): the reference's signature (lib.rs:72-78): r_a = two F::rand(rng) draws, constant term first
+        (prover.rs:110).  prove(pk, circuit, [r0, r1]): the draws supplied by the caller.
+        `combine(xy, inf) -> (xy, inf)` merges per-shard partial points across ranks (RCCL
         all-gather + pm_g1_sum, polymath_amd.distributed); None for a whole key."""
+        if hasattr(r_a, "next_u64"):
+            from . import rng as RNG
+            r_a = [RNG.fr_rand(r_a, self.field.r), RNG.fr_rand(r_a, self.field.r)]
         if isinstance(circuit, LimbCircuit):
             return self.prove_limbs(pk, circuit.instance, circuit.inst_limbs, circuit.wit_limbs, r_a, combine)
         _, instance, witness = self._synthesize(circuit)

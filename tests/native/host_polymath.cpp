@@ -93,6 +93,24 @@ static void run_dummy(Context &ctx, const char *tag, const char *tname, uint64_t
     printf("verify%s %s accept=%d tampered=%d wrong_input=%d\n", tag, tname, ok, ok_bad, ok_wrong_input);
 }
 
+// tests/dummy.rs:37-80 draw for draw, on the reference's own random sources: rng = StdRng::seed_from_u64(test_rng().next_u64())
+// (:44), setup(c, &mut rng) (:52), a, b = rand (:56-57), prove(&pk, circuit, &mut rng) (:67), verify (:69-72)
+template <class T>
+static void run_dummy_reference_rng(Context &ctx, const char *tname) {
+    StdRng seed_source = StdRng::test_rng();
+    StdRng rng = StdRng::seed_from_u64(seed_source.next_u64());
+    Polymath<Curve, T> pm(ctx);
+    DummyCircuitT<Curve> shape{Fr::zero(), Fr::zero()};                  // `DummyCircuit { a: None, b: None }`: shape only
+    ProvingKey<Curve> pk = pm.setup(shape, rng);
+    const Fr x = pm.last_trapdoors()[0], z = pm.last_trapdoors()[1];
+    Fr a = F::rand(rng), b = F::rand(rng);
+    DummyCircuitT<Curve> c{a, b};
+    Proof<Curve> proof = pm.prove(pk, c, rng);
+    VerifyingKey vk = Polymath<Curve, T>::make_vk(pk, x, z);
+    std::vector<Fr> pub{F::mul(a, b)};
+    printf("dummyrng %s %s accept=%d\n", tname, to_hex(proof.to_bytes()).c_str(), (int)Polymath<Curve, T>::verify(vk, pub, proof));
+}
+
 int main(int argc, char **argv) {
     int rounds = argc > 1 ? atoi(argv[1]) : 322, samples = argc > 2 ? atoi(argv[2]) : 3;
     try {
@@ -133,6 +151,9 @@ int main(int argc, char **argv) {
         } catch (const PolymathError &e) {
             printf("bad-witness rejected phase=%d status=%d\n", e.phase, e.status);
         }
+        run_dummy_reference_rng<MerlinFieldTranscript<Curve>>(ctx, "merlin");
+        run_dummy_reference_rng<Keccak256Transcript<Curve>>(ctx, "keccak256");
+        run_dummy_reference_rng<Blake3Transcript<Curve>>(ctx, "blake3");
         // the same dummy test on the second pairing engine (BN254: 254-bit limb path, its own optimal-ate verifier)
         run_dummy<pm::BnCurve, MerlinFieldTranscript<pm::BnCurve>>(ctx, "_bn254", "merlin", 201);
         run_dummy<pm::BnCurve, Keccak256Transcript<pm::BnCurve>>(ctx, "_bn254", "keccak256", 202);

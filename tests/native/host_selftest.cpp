@@ -3,6 +3,7 @@
 #include "../../polymath_amd/host/hashes.hpp"
 #include "../../polymath_amd/csrc/field.cuh"
 #include "../../polymath_amd/host/pairing.hpp"
+#include "../../polymath_amd/host/rng.hpp"
 using namespace pmhost;
 int main() {
     int fails = 0;
@@ -73,6 +74,28 @@ int main() {
         B::G2 wrong = B::g2_mul(g2, kab, 2);
         if (B::product_is_one({{aP, false, bQ}, {negP, false, wrong}})) { fails++; printf("BN254 pairing false accept\n"); }
         if (B::product_is_one({{g1, false, g2}})) { fails++; printf("BN254 pairing degenerate\n"); }
+    }
+    {   // random sources (rng.hpp): the ChaCha block function against RFC 7539 section 2.3.2 (20 rounds), then the streams the
+        // Python twin (polymath_amd/rng.py) must reproduce word for word (tests/test_host_mirror.py)
+        uint32_t key[8], out[16];
+        for (int i = 0; i < 8; ++i) key[i] = (uint32_t)(4 * i) | ((uint32_t)(4 * i + 1) << 8) | ((uint32_t)(4 * i + 2) << 16) | ((uint32_t)(4 * i + 3) << 24);
+        const uint32_t tail[4] = {1u, 0x09000000u, 0x4a000000u, 0u};
+        chacha_block(key, tail, 20, out);
+        Bytes ob(64);
+        for (int i = 0; i < 16; ++i) for (int b = 0; b < 4; ++b) ob[4 * i + b] = (uint8_t)(out[i] >> (8 * b));
+        if (hex(ob) != "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4ed2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e") { fails++; printf("chacha20 RFC 7539 KAT\n"); }
+        StdRng t = StdRng::test_rng();
+        const unsigned long long t0 = t.next_u64();
+        StdRng r = StdRng::seed_from_u64(t0);
+        printf("rng test_rng_first=%016llx seeded:", t0);
+        for (int i = 0; i < 20; ++i) printf(" %016llx", (unsigned long long)r.next_u64());
+        pm::Fp<pm::BlsFrP> f = fr_rand<pm::BlsFrP, pm::Fp<pm::BlsFrP>>(r);
+        pm::Fp<pm::BnFrP> g = fr_rand<pm::BnFrP, pm::Fp<pm::BnFrP>>(r);
+        printf(" fr_bls=");
+        for (int i = 7; i >= 0; --i) printf("%08x", f.l[i]);
+        printf(" fr_bn=");
+        for (int i = 7; i >= 0; --i) printf("%08x", g.l[i]);
+        printf("\n");
     }
     printf("host selftest: %d failures\n", fails);
     return fails ? 1 : 0;

@@ -593,3 +593,30 @@ def test_phase1_device_resident_assignment_equals_host(gpu_ctx, oracle, api):
     assert rc == rc2 == 0 and np.array_equal(a, a2) and np.array_equal(cc, cc2) and (ai, ci) == (ai2, ci2)
     hip.hipFree(dx)
     hip.hipFree(dw)
+
+
+def test_setup_and_prove_with_the_reference_rng_signature(oracle):
+    """Polymath.setup(circuit, rng) / .prove(pk, circuit, rng) -- the reference's own signatures (lib.rs:63-78) on its own random
+    sources (polymath_amd/rng.py: StdRng = ChaCha12, seed_from_u64, Fp::rand, sample_element_outside_domain): the draws happen in
+    the reference's order (generator.rs:72,77: x then z; prover.rs:110: r_a constant term first), so an independent replay of
+    the stream feeds the CPU oracle the same values and the proofs are byte-identical.  benches/bench.rs:65 shape: seed 0."""
+    from polymath_amd import circuits as PC, rng as R
+    from polymath_amd.polymath import Polymath
+    c = CURVES["bls12_381"]
+    rng = R.StdRng.seed_from_u64(0)
+    a, b = R.fr_rand(rng, c.r), R.fr_rand(rng, c.r)                  # bench.rs:67-68
+    circuit = PC.BenchCircuit(a, b, 40, 37)
+    pm = Polymath("bls12_381", "merlin", device=0)
+    pk = pm.setup(circuit, rng)                                      # bench.rs:74
+    proof = pm.prove(pk, circuit, rng)                               # bench.rs:79
+    replay = R.StdRng.seed_from_u64(0)
+    a2, b2 = R.fr_rand(replay, c.r), R.fr_rand(replay, c.r)
+    x, z = R.sample_element_outside_domain(replay, c.r, pk.n), R.sample_element_outside_domain(replay, c.r, pk.n)
+    r_a = [R.fr_rand(replay, c.r), R.fr_rand(replay, c.r)]
+    assert (a2, b2) == (a, b) and pm.last_trapdoors == (x, z)
+    q, inst, wit = CI.bench_circuit(c, a, b, 40, 37)
+    opk = oracle.OraclePk("bls12_381", q, x, z, 2)
+    omega = oracle.fr_from_mont_limbs("bls12_381", opk.omega_limbs)[0]
+    ref = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, T.make_transcripts(c)["merlin"])
+    assert proof.as_dict() == ref
+    pk.free()

@@ -26,6 +26,19 @@ def _build(tmp_path, src, link=False):
 def test_host_hash_known_answers(tmp_path):
     out = subprocess.run([_build(tmp_path, "host_selftest.cpp")], capture_output=True, text=True)
     assert out.returncode == 0 and "0 failures" in out.stdout, out.stdout
+    # the random sources: C++ (host/rng.hpp) and Python (polymath_amd/rng.py) twins agree word for word
+    import struct
+    from polymath_amd import rng as R
+    from polymath_amd.polymath import FIELDS
+    key = list(struct.unpack("<8I", bytes(range(32))))                      # RFC 7539 section 2.3.2 (20 rounds)
+    assert struct.pack("<16I", *R.chacha_block(key, [1, 0x09000000, 0x4A000000, 0], 20)).hex().startswith("10f1e7e4d13b5915500fdd1fa32071c4")
+    line = [l for l in out.stdout.splitlines() if l.startswith("rng ")][0].split()
+    t0 = R.StdRng.test_rng().next_u64()
+    assert line[1] == "test_rng_first=%016x" % t0
+    r = R.StdRng.seed_from_u64(t0)
+    assert line[3:23] == ["%016x" % r.next_u64() for _ in range(20)]
+    assert line[23] == "fr_bls=%064x" % R.fr_rand_mont(r, FIELDS["bls12_381"]["r"])
+    assert line[24] == "fr_bn=%064x" % R.fr_rand_mont(r, FIELDS["bn254"]["r"])
 
 
 @pytest.mark.gpu
@@ -44,7 +57,24 @@ def test_cpp_dummy_and_mimc_match_oracle(tmp_path, oracle):
                         "verify_bn254 merlin accept=1 tampered=0 wrong_input=0", "verify_bn254 keccak256 accept=1 tampered=0 wrong_input=0",
                         "verify_bn254 blake3 accept=1 tampered=0 wrong_input=0"], verdicts
     bn_lines = [l for l in all_lines if l.startswith("dummy_bn254")]
-    lines = [l for l in all_lines if not l.startswith("verify") and not l.startswith("dummy_bn254")]
+    rng_lines = [l for l in all_lines if l.startswith("dummyrng")]
+    lines = [l for l in all_lines if not l.startswith("verify") and not l.startswith("dummy_bn254") and not l.startswith("dummyrng")]
+    # tests/dummy.rs:37-80 draw for draw on the reference's random sources (StdRng::seed_from_u64(test_rng().next_u64()), setup(c, rng),
+    # a, b = rand, prove(pk, c, rng)): the Python twin of the RNG feeds the CPU oracle the same draws -> the same 176 bytes, accepted
+    from polymath_amd import rng as R
+    assert len(rng_lines) == 3
+    for line, tname in zip(rng_lines, ["merlin", "keccak256", "blake3"]):
+        rng = R.StdRng.seed_from_u64(R.StdRng.test_rng().next_u64())
+        x, z = R.sample_element_outside_domain(rng, c.r, 8), R.sample_element_outside_domain(rng, c.r, 8)
+        a, b = R.fr_rand(rng, c.r), R.fr_rand(rng, c.r)
+        r_a = [R.fr_rand(rng, c.r), R.fr_rand(rng, c.r)]
+        q, inst, wit = CI.dummy_circuit(c, a, b)
+        opk = oracle.OraclePk("bls12_381", q, x, z, 1)
+        assert opk.n == 8
+        omega = oracle.fr_from_mont_limbs("bls12_381", opk.omega_limbs)[0]
+        ref = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, T.make_transcripts(c)[tname])
+        kind, name, hx, acc = line.split()
+        assert (kind, name, acc) == ("dummyrng", tname, "accept=1") and hx == SE.ser_proof(c, ref).hex()
     # tests/dummy.rs on BN254: same proof bytes as the CPU oracle
     from oracle.pyref.fields import BN254 as cb
     TRB = T.make_transcripts(cb)
