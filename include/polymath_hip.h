@@ -208,6 +208,18 @@ int pm_host_prove_sharded(pm_ctx *ctx, const pm_pk *pk, int transcript, const ui
                           const uint64_t *w, int assignment_on_device, const uint64_t *r_a, pm_combine_fn combine, void *user,
                           uint8_t *proof_bytes, size_t capacity, size_t *proof_len);
 
+/* Polymath::verify (lib.rs:80-90 -> verify_proof, verifier.rs:19-62) and the VerifyingKey of a key made from the trapdoors
+ * (generator.rs:139-157), for hosts without a pairing implementation of their own.  HOST code (the verifier is O(1): two
+ * Miller loops and a final exponentiation on the CPU, ~0.3 s): needs no GPU and no context.  Both pairing engines.
+ * vk_bytes: VerifyingKey::serialize_compressed (data_structures.rs:25-52): one_g1, one_g2, x_g2, z_g2, n, m0, sigma, omega --
+ * 392 bytes on BLS12-381 (zcash point encoding), 280 on BN254 (ark-serialize's default short-Weierstrass form).
+ * public_inputs: n_inputs Fr, Montgomery, WITHOUT the leading one (verifier.rs:26); proof_bytes: Proof::serialize_compressed.
+ * Malformed bytes return PM_ERR_INVALID_ARG; otherwise PM_OK with *accepted = 0 / 1. */
+int pm_host_make_vk(int curve, uint64_t n, uint64_t m0, uint64_t sigma, const uint64_t *omega, const uint64_t *x_trapdoor,
+                    const uint64_t *z_trapdoor, uint8_t *vk_bytes, size_t capacity, size_t *vk_len);
+int pm_host_verify(int curve, int transcript, const uint8_t *vk_bytes, size_t vk_len, const uint64_t *public_inputs, size_t n_inputs,
+                   const uint8_t *proof_bytes, size_t proof_len, int *accepted);
+
 /* Host helper: Keccak-f[1600] on 25 little-endian lanes, shared by the host mirrors' Merlin / Keccak256
  * transcripts (the reference's transcripts are host code too: src/transcript/ *.rs). */
 void pm_host_keccak_f1600(uint64_t state[25]);

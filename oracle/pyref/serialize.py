@@ -67,6 +67,16 @@ def _fq2_gt(a, b):
 
 
 def ser_g2(c, Q):
+    if c.name == "bn254":
+        # ark-serialize's default short-Weierstrass compressed form: x.c0 || x.c1 little-endian, flags in the LAST byte
+        # (0x80: y > -y in the Fq2 order, 0x40: infinity)                                     [ark, from memory]
+        if Q is None:
+            return bytes(63) + bytes([0x40])
+        (x0, x1), (y0, y1) = Q
+        b = bytearray(x0.to_bytes(32, "little") + x1.to_bytes(32, "little"))
+        if _fq2_gt((y0, y1), ((-y0) % c.p, (-y1) % c.p)):
+            b[63] |= 0x80
+        return bytes(b)
     assert c.name == "bls12_381"
     if Q is None:
         return bytes([0xC0]) + bytes(95)

@@ -54,7 +54,7 @@ EXPORTS = [
     "pm_prove_tap", "pm_host_keccak_f1600", "pm_synth_r1cs",
     "pm_pk_load_sharded", "pm_pk_generate_sharded", "pm_layout_indices", "pm_pk_msm_pieces",
     "pm_comm_rccl_unique_id", "pm_comm_rccl_create", "pm_comm_local_create", "pm_comm_from_callbacks", "pm_comm_destroy", "pm_comm_rank",
-    "pm_comm_world", "pm_comm_last_error", "pm_comm_busy_ms", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
+    "pm_comm_world", "pm_comm_last_error", "pm_comm_busy_ms", "pm_host_make_vk", "pm_host_verify", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
 ]
 SHARD_PAIRS, SHARD_VECTOR = 0, 1
 LAYOUTS = {"pairs": SHARD_PAIRS, "vector": SHARD_VECTOR, 0: 0, 1: 1}
@@ -128,6 +128,8 @@ def load_library():
     L.pm_comm_world.argtypes = [vp]
     L.pm_comm_last_error.argtypes = [vp]
     L.pm_comm_last_error.restype = ct.c_char_p
+    L.pm_host_make_vk.argtypes = [i, u64, u64, u64, u64p, u64p, u64p, ct.c_char_p, sz, ct.POINTER(sz)]
+    L.pm_host_verify.argtypes = [i, i, ct.c_char_p, sz, u64p, sz, ct.c_char_p, sz, intp]
     L.pm_comm_busy_ms.argtypes = [vp, i]
     L.pm_comm_busy_ms.restype = ct.c_double
     L.pm_comm_all_gather.argtypes = [vp, vp, vp, sz]
@@ -158,6 +160,34 @@ def g1_sum(curve, pts, infs=None):
     if st:
         raise PolymathError(st, "pm_g1_sum")
     return out, inf.value
+
+
+TRANSCRIPT_IDS = {"merlin": 0, "keccak256": 1, "blake3": 2}
+
+
+def make_vk(curve, n, m0, sigma, omega_limbs, x_trapdoor_limbs, z_trapdoor_limbs):
+    """pm_host_make_vk: VerifyingKey::serialize_compressed bytes of the key the two trapdoors define (host code, no GPU)."""
+    L = load_library()
+    buf = ct.create_string_buffer(512)
+    n_out = ct.c_size_t(0)
+    st = L.pm_host_make_vk(CURVE_IDS[curve], n, m0, sigma, _p(_c(omega_limbs)), _p(_c(x_trapdoor_limbs)), _p(_c(z_trapdoor_limbs)), buf, len(buf),
+                           ct.byref(n_out))
+    if st:
+        raise PolymathError(st, "pm_host_make_vk")
+    return buf.raw[:n_out.value]
+
+
+def verify(curve, transcript, vk_bytes, public_input_limbs, proof_bytes):
+    """pm_host_verify: Polymath::verify (verifier.rs:19-62) on the CPU with the library's own pairing.  public inputs WITHOUT the
+    leading one, Montgomery limbs [k, 4].  Malformed bytes raise; -> bool."""
+    L = load_library()
+    pub = _c(public_input_limbs).reshape(-1, 4) if len(public_input_limbs) else np.zeros((0, 4), dtype=np.uint64)
+    acc = ct.c_int(0)
+    st = L.pm_host_verify(CURVE_IDS[curve], TRANSCRIPT_IDS[transcript], bytes(vk_bytes), len(vk_bytes), _p(pub) if len(pub) else None, len(pub),
+                          bytes(proof_bytes), len(proof_bytes), ct.byref(acc))
+    if st:
+        raise PolymathError(st, "pm_host_verify")
+    return bool(acc.value)
 
 
 def synth_r1cs(curve, nr, seed):

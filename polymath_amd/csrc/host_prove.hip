@@ -4,6 +4,7 @@
 // caller's context.  The three phases stay the boundary; this is their caller, compiled once.
 #include "internal.h"
 #include "../host/polymath.hpp"
+#include "../host/wire.hpp"
 
 namespace {
 
@@ -87,4 +88,77 @@ extern "C" int pm_host_prove(pm_ctx *ctx, const pm_pk *pk, int transcript, const
     if (pk && pk->shard_count != 1) return PM_ERR_INVALID_ARG;
     return pm_host_prove_sharded(ctx, pk, transcript, instance_host, x, w, assignment_on_device, r_a, nullptr, nullptr, proof_bytes, capacity,
                                  proof_len);
+}
+
+// ---- verify (lib.rs:80-90 -> verifier.rs:19-62) and the verifying key (generator.rs:139-157): host code, no GPU --------------
+namespace {
+
+template <class C>
+int make_vk_impl(uint64_t n, uint64_t m0, uint64_t sigma, const uint64_t *omega, const uint64_t *x_trap, const uint64_t *z_trap, uint8_t *out,
+                 size_t cap, size_t *len) {
+    typedef typename pmhost::FrOps<C>::Fr Fr;
+    pmhost::ProvingKey<C> shape;           // carries n / m0 / sigma / omega only (no device handle)
+    shape.n = n; shape.m0 = m0; shape.sigma = sigma;
+    memcpy(shape.omega.l, omega, 32);
+    Fr x, z;
+    memcpy(x.l, x_trap, 32);
+    memcpy(z.l, z_trap, 32);
+    const pmhost::VerifyingKeyT<C> vk = pmhost::Polymath<C, pmhost::MerlinFieldTranscript<C>>::make_vk(shape, x, z);
+    pmhost::Bytes b;
+    pmhost::ser_vk_c<C>(vk, b);
+    if (len) *len = b.size();
+    if (b.size() > cap) return PM_ERR_INVALID_ARG;
+    memcpy(out, b.data(), b.size());
+    return PM_OK;
+}
+
+template <class C, class T>
+int verify_impl(const uint8_t *vk_bytes, size_t vk_len, const uint64_t *inputs, size_t n_inputs, const uint8_t *proof_bytes, size_t proof_len,
+                int *accepted) {
+    typedef typename pmhost::FrOps<C>::Fr Fr;
+    pmhost::Reader rd(vk_bytes, vk_len);
+    const pmhost::VerifyingKeyT<C> vk = pmhost::read_vk_c<C>(rd);
+    if (rd.off != vk_len) return PM_ERR_INVALID_ARG;
+    const pmhost::Proof<C> proof = pmhost::read_proof<C>(proof_bytes, proof_len);
+    std::vector<Fr> pub(n_inputs);
+    if (n_inputs) memcpy((void *)pub.data(), inputs, n_inputs * sizeof(Fr));
+    *accepted = pmhost::Polymath<C, T>::verify(vk, pub, proof) ? 1 : 0;
+    return PM_OK;
+}
+
+template <class C>
+int verify_curve(int transcript, const uint8_t *vk, size_t vk_len, const uint64_t *in, size_t n_in, const uint8_t *pr, size_t pr_len, int *acc) {
+    switch (transcript) {
+        case PM_TRANSCRIPT_MERLIN: return verify_impl<C, pmhost::MerlinFieldTranscript<C>>(vk, vk_len, in, n_in, pr, pr_len, acc);
+        case PM_TRANSCRIPT_KECCAK256: return verify_impl<C, pmhost::Keccak256Transcript<C>>(vk, vk_len, in, n_in, pr, pr_len, acc);
+        case PM_TRANSCRIPT_BLAKE3: return verify_impl<C, pmhost::Blake3Transcript<C>>(vk, vk_len, in, n_in, pr, pr_len, acc);
+        default: return PM_ERR_INVALID_ARG;
+    }
+}
+
+}  // namespace
+
+extern "C" int pm_host_make_vk(int curve, uint64_t n, uint64_t m0, uint64_t sigma, const uint64_t *omega, const uint64_t *x_trapdoor,
+                               const uint64_t *z_trapdoor, uint8_t *vk_bytes, size_t capacity, size_t *vk_len) {
+    if (!omega || !x_trapdoor || !z_trapdoor || !vk_bytes) return PM_ERR_INVALID_ARG;
+    try {
+        if (curve == PM_BLS12_381) return make_vk_impl<pm::BlsCurve>(n, m0, sigma, omega, x_trapdoor, z_trapdoor, vk_bytes, capacity, vk_len);
+        if (curve == PM_BN254) return make_vk_impl<pm::BnCurve>(n, m0, sigma, omega, x_trapdoor, z_trapdoor, vk_bytes, capacity, vk_len);
+    } catch (const std::exception &) {
+        return PM_ERR_STATE;
+    }
+    return PM_ERR_INVALID_ARG;
+}
+
+extern "C" int pm_host_verify(int curve, int transcript, const uint8_t *vk_bytes, size_t vk_len, const uint64_t *public_inputs, size_t n_inputs,
+                              const uint8_t *proof_bytes, size_t proof_len, int *accepted) {
+    if (!vk_bytes || !proof_bytes || !accepted || (n_inputs && !public_inputs)) return PM_ERR_INVALID_ARG;
+    *accepted = 0;
+    try {
+        if (curve == PM_BLS12_381) return verify_curve<pm::BlsCurve>(transcript, vk_bytes, vk_len, public_inputs, n_inputs, proof_bytes, proof_len, accepted);
+        if (curve == PM_BN254) return verify_curve<pm::BnCurve>(transcript, vk_bytes, vk_len, public_inputs, n_inputs, proof_bytes, proof_len, accepted);
+    } catch (const std::exception &) {      // malformed vk / proof bytes (off-curve points, non-canonical scalars, truncation)
+        return PM_ERR_INVALID_ARG;
+    }
+    return PM_ERR_INVALID_ARG;
 }

@@ -98,13 +98,15 @@ struct PairingT {
             }
         return out;
     }
-    static bool g2_on_curve(const G2 &A) {
-        if (A.inf) return true;
+    static Fq2 twist_b() {   // b' of the twist y^2 = x^3 + b': b / xi (D-type, BN254) or b xi (M-type, BLS12-381)
         const Fq2 xi{small(PP::SHIFT), Fq::one()};          // SHIFT + u: 1 + u (BLS12-381), 9 + i (BN254)
         Fq2 cb{Fq::zero(), Fq::zero()};
         for (int i = 0; i < Q::N; ++i) cb.c0.l[i] = Curve::B_MONT[i];
-        const Fq2 b = PP::TWIST_MUL ? mul2(cb, inv2(xi)) : mul2(cb, xi);   // b' = b / xi (D-type) or b xi (M-type)
-        return mul2(A.y, A.y).eq(add2(mul2(mul2(A.x, A.x), A.x), b));
+        return PP::TWIST_MUL ? mul2(cb, inv2(xi)) : mul2(cb, xi);
+    }
+    static bool g2_on_curve(const G2 &A) {
+        if (A.inf) return true;
+        return mul2(A.y, A.y).eq(add2(mul2(mul2(A.x, A.x), A.x), twist_b()));
     }
     static G2 g2_generator() {
         auto H = [](const char *hex) {

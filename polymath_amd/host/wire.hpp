@@ -74,11 +74,12 @@ int fq_cmp(const pm::Fp<Q> &a, const pm::Fp<Q> &b) {
     return 0;
 }
 
-struct Fq2Ops {   // BLS12-381 Fq2 = Fq[u]/(u^2+1)
-    typedef Bls12Pairing B;
-    typedef B::Fq Fq;
-    typedef B::Fq2 Fq2;
-    typedef pm::BlsFqP Q;
+template <class C>
+struct Fq2OpsT {   // Fq2 = Fq[u]/(u^2+1) of either pairing engine
+    typedef typename PairingOf<C>::type B;
+    typedef typename B::Fq Fq;
+    typedef typename B::Fq2 Fq2;
+    typedef typename C::FqP Q;
     static bool sqrt(const Fq2 &a, Fq2 &out) {   // complex method
         Fq s;
         if (a.c1.is_zero()) {
@@ -100,21 +101,33 @@ struct Fq2Ops {   // BLS12-381 Fq2 = Fq[u]/(u^2+1)
         return c ? c > 0 : fq_cmp<Q>(a.c0, b.c0) > 0;
     }
 };
+typedef Fq2OpsT<pm::BlsCurve> Fq2Ops;
 
 // ---------------------------------------------------------------------------- point codecs
-inline void put_fq_be(const pm::Fp<pm::BlsFqP> &mont, Bytes &out) {
-    pm::Fp<pm::BlsFqP> x = pm::from_mont<pm::BlsFqP>(mont);
-    uint8_t le[48];
-    memcpy(le, x.l, 48);
-    for (int i = 47; i >= 0; --i) out.push_back(le[i]);
+// BLS12-381: the zcash encoding (big-endian, x.c1 || x.c0, flags 0x80 compressed / 0x40 infinity / 0x20 y > -y in the FIRST byte);
+// BN254: ark-serialize's default short-Weierstrass form (little-endian, x.c0 || x.c1, flags 0x80 y > -y / 0x40 infinity in the
+// LAST byte)                                                                                          [ark, from memory]
+template <class Q>
+inline void put_fq_be(const pm::Fp<Q> &mont, Bytes &out) {
+    pm::Fp<Q> x = pm::from_mont<Q>(mont);
+    uint8_t le[4 * Q::N];
+    memcpy(le, x.l, sizeof(le));
+    for (int i = 4 * Q::N - 1; i >= 0; --i) out.push_back(le[i]);
 }
-inline bool get_fq_be(const uint8_t *b, uint8_t top_mask, pm::Fp<pm::BlsFqP> &mont) {
-    typedef pm::BlsFqP Q;
-    uint8_t le[48];
-    for (int i = 0; i < 48; ++i) le[i] = b[47 - i];
-    le[47] &= top_mask;
+template <class Q>
+inline void put_fq_le(const pm::Fp<Q> &mont, Bytes &out) {
+    pm::Fp<Q> x = pm::from_mont<Q>(mont);
+    const uint8_t *le = (const uint8_t *)x.l;
+    out.insert(out.end(), le, le + 4 * Q::N);
+}
+template <class Q>
+inline bool get_fq(const uint8_t *b, bool big_endian, uint8_t top_mask, pm::Fp<Q> &mont) {
+    const int NB = 4 * Q::N;
+    uint8_t le[4 * Q::N];
+    for (int i = 0; i < NB; ++i) le[i] = big_endian ? b[NB - 1 - i] : b[i];
+    le[NB - 1] &= top_mask;
     pm::Fp<Q> x;
-    memcpy(x.l, le, 48);
+    memcpy(x.l, le, NB);
     for (int i = Q::N - 1; i >= 0; --i) {      // x < p
         if (x.l[i] < Q::MOD[i]) break;
         if (x.l[i] > Q::MOD[i] || i == 0) return false;
@@ -123,27 +136,52 @@ inline bool get_fq_be(const uint8_t *b, uint8_t top_mask, pm::Fp<pm::BlsFqP> &mo
     return true;
 }
 
-inline void ser_g2(const Bls12Pairing::G2 &g, Bytes &out) {
-    if (g.inf) { out.push_back(0xC0); out.insert(out.end(), 95, 0); return; }
+template <class C>
+inline void ser_g2_c(const typename PairingOf<C>::type::G2 &g, Bytes &out) {
+    typedef typename PairingOf<C>::type B;
+    typedef typename C::FqP Q;
+    const int NB = 4 * Q::N;
     const size_t at = out.size();
-    put_fq_be(g.x.c1, out);
-    put_fq_be(g.x.c0, out);
-    out[at] |= 0x80 | (Fq2Ops::gt(g.y, Bls12Pairing::neg2(g.y)) ? 0x20 : 0);
+    if (C::ID == 0) {
+        if (g.inf) { out.push_back(0xC0); out.insert(out.end(), 2 * NB - 1, 0); return; }
+        put_fq_be<Q>(g.x.c1, out);
+        put_fq_be<Q>(g.x.c0, out);
+        out[at] |= 0x80 | (Fq2OpsT<C>::gt(g.y, B::neg2(g.y)) ? 0x20 : 0);
+    } else {
+        if (g.inf) { out.insert(out.end(), 2 * NB - 1, 0); out.push_back(0x40); return; }
+        put_fq_le<Q>(g.x.c0, out);
+        put_fq_le<Q>(g.x.c1, out);
+        if (Fq2OpsT<C>::gt(g.y, B::neg2(g.y))) out[at + 2 * NB - 1] |= 0x80;
+    }
 }
 
-inline Bls12Pairing::G2 deser_g2(Reader &rd) {
-    typedef Bls12Pairing B;
-    const uint8_t *b = rd.take(96);
-    if (!(b[0] & 0x80)) throw WireError("G2: not a compressed point");
-    B::G2 g;
-    g.inf = (b[0] & 0x40) != 0;
-    if (g.inf) { g.x = g.y = B::Fq2{B::Fq::zero(), B::Fq::zero()}; return g; }
-    if (!get_fq_be(b, 0x1F, g.x.c1) || !get_fq_be(b + 48, 0xFF, g.x.c0)) throw WireError("G2: coordinate >= p");
-    B::Fq2 rhs = B::add2(B::mul2(B::mul2(g.x, g.x), g.x), B::Fq2{B::small(4), B::small(4)});
-    if (!Fq2Ops::sqrt(rhs, g.y)) throw WireError("G2: not on the twist");
-    if (Fq2Ops::gt(g.y, B::neg2(g.y)) != ((b[0] & 0x20) != 0)) g.y = B::neg2(g.y);
+template <class C>
+inline typename PairingOf<C>::type::G2 deser_g2_c(Reader &rd) {
+    typedef typename PairingOf<C>::type B;
+    typedef typename C::FqP Q;
+    const int NB = 4 * Q::N;
+    const uint8_t *b = rd.take(2 * NB);
+    typename B::G2 g;
+    bool larger;
+    if (C::ID == 0) {
+        if (!(b[0] & 0x80)) throw WireError("G2: not a compressed point");
+        g.inf = (b[0] & 0x40) != 0;
+        larger = (b[0] & 0x20) != 0;
+    } else {
+        g.inf = (b[2 * NB - 1] & 0x40) != 0;
+        larger = (b[2 * NB - 1] & 0x80) != 0;
+    }
+    if (g.inf) { g.x = g.y = typename B::Fq2{B::Fq::zero(), B::Fq::zero()}; return g; }
+    const bool ok = C::ID == 0 ? (get_fq<Q>(b, true, 0x1F, g.x.c1) && get_fq<Q>(b + NB, true, 0xFF, g.x.c0))
+                               : (get_fq<Q>(b, false, 0xFF, g.x.c0) && get_fq<Q>(b + NB, false, 0x3F, g.x.c1));
+    if (!ok) throw WireError("G2: coordinate >= p");
+    typename B::Fq2 rhs = B::add2(B::mul2(B::mul2(g.x, g.x), g.x), B::twist_b());
+    if (!Fq2OpsT<C>::sqrt(rhs, g.y)) throw WireError("G2: not on the twist");
+    if (Fq2OpsT<C>::gt(g.y, B::neg2(g.y)) != larger) g.y = B::neg2(g.y);
     return g;
 }
+inline void ser_g2(const Bls12Pairing::G2 &g, Bytes &out) { ser_g2_c<pm::BlsCurve>(g, out); }
+inline Bls12Pairing::G2 deser_g2(Reader &rd) { return deser_g2_c<pm::BlsCurve>(rd); }
 
 template <class C>
 G1Point<C> deser_g1(Reader &rd) {
@@ -184,30 +222,44 @@ G1Point<C> deser_g1(Reader &rd) {
 }
 
 // ------------------------------------------------------------------------------------ keys
-inline void ser_vk(const VerifyingKey &vk, Bytes &out) {
-    typedef pm::BlsCurve C;
+template <class C>
+inline void ser_vk_c(const VerifyingKeyT<C> &vk, Bytes &out) {
     ser_g1<C>(vk.one_g1, out);
-    ser_g2(vk.one_g2, out);
-    ser_g2(vk.x_g2, out);
-    ser_g2(vk.z_g2, out);
+    ser_g2_c<C>(vk.one_g2, out);
+    ser_g2_c<C>(vk.x_g2, out);
+    ser_g2_c<C>(vk.z_g2, out);
     ser_u64(vk.n, out);
     ser_u64(vk.m0, out);
     ser_u64(vk.sigma, out);
     ser_fr<C>(vk.omega, out);
 }
-
-inline VerifyingKey read_vk(Reader &rd) {
-    typedef pm::BlsCurve C;
-    VerifyingKey vk;
+template <class C>
+inline VerifyingKeyT<C> read_vk_c(Reader &rd) {
+    VerifyingKeyT<C> vk;
     vk.one_g1 = deser_g1<C>(rd);
-    vk.one_g2 = deser_g2(rd);
-    vk.x_g2 = deser_g2(rd);
-    vk.z_g2 = deser_g2(rd);
+    vk.one_g2 = deser_g2_c<C>(rd);
+    vk.x_g2 = deser_g2_c<C>(rd);
+    vk.z_g2 = deser_g2_c<C>(rd);
     vk.n = rd.u64();
     vk.m0 = rd.u64();
     vk.sigma = rd.u64();
     vk.omega = FrOps<C>::from_le_bytes_canonical(rd.take(32));
     return vk;
+}
+inline void ser_vk(const VerifyingKey &vk, Bytes &out) { ser_vk_c<pm::BlsCurve>(vk, out); }
+inline VerifyingKey read_vk(Reader &rd) { return read_vk_c<pm::BlsCurve>(rd); }
+
+// Proof::deserialize_compressed (data_structures.rs:10-19): a_g1, c_g1, a_at_x1, d_g1
+template <class C>
+inline Proof<C> read_proof(const uint8_t *data, size_t len) {
+    Reader rd(data, len);
+    Proof<C> p;
+    p.a_g1 = deser_g1<C>(rd);
+    p.c_g1 = deser_g1<C>(rd);
+    p.a_at_x1 = FrOps<C>::from_le_bytes_canonical(rd.take(32));
+    p.d_g1 = deser_g1<C>(rd);
+    if (rd.off != len) throw WireError("trailing bytes after the proof");
+    return p;
 }
 
 // pm_base_vec ids in the struct's declaration order (data_structures.rs:60-72)

@@ -428,6 +428,20 @@ class Polymath:
             d_xy, d_inf = combine(d_xy, d_inf)
         return Proof(f, a_g1, c_g1, a_at_x1, f.g1_affine(d_xy, d_inf))           # :231-236
 
+    # ---- verify (lib.rs:80-90) and the verifying key (generator.rs:139-157): host code of the library, both pairing engines
+    def make_vk(self, pk, x_trapdoor, z_trapdoor):
+        """VerifyingKey::serialize_compressed bytes of the key made from the two trapdoors."""
+        f = self.field
+        return api.make_vk(self.curve, pk.n, pk.m0, pk.sigma, pk.omega_limbs, f.fr_limbs([x_trapdoor])[0], f.fr_limbs([z_trapdoor])[0])
+
+    def verify(self, vk_bytes, public_inputs, proof):
+        """Polymath::verify(vk, public_inputs, proof): public_inputs WITHOUT the leading one (verifier.rs:26); proof: a Proof or its
+        serialize_compressed bytes.  Runs the library's own CPU verifier (pairing.hpp)."""
+        if self.transcript_name is None:
+            raise ValueError("verify needs one of the reference's transcripts: " + ", ".join(TRANSCRIPTS))
+        pb = proof.to_bytes() if isinstance(proof, Proof) else bytes(proof)
+        return api.verify(self.curve, self.transcript_name, vk_bytes, self.field.fr_limbs(list(public_inputs)), pb)
+
     # ---- ProvingKey wire format (§8 f-4)
     def pk_to_bytes(self, pk, r1cs, vk):
         """ProvingKey { vk, sap_matrices, six Vec<G1Affine> } (data_structures.rs:56-73).  `r1cs` carries the
