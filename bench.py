@@ -361,6 +361,8 @@ def main():
                      "note": "the real bound of this kernel: mads are 76 % of its instruction stream (3 542 of 4 682 per mixed add); "
                              "SQ counters (profiles/r02_pmc_valu_k_accumulate.json): 0.95 of the VALU issue slots, clock 1.98 GHz under this load"},
             "proof_bytes": proof_b.hex(),
+            # Polymath::verify (verifier.rs:19-62) on the timed proof, by the library's own CPU verifier (pm_host_verify)
+            "proof_verified": bool(pm.verify(pm.make_vk(pk, x_trap, z_trap), inst[1:], proof_b)),
         }
         if world == 1 and shard_count == 1 and not multi:
             if not args.no_live_traffic:

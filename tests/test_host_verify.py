@@ -31,9 +31,14 @@ def test_product_verifier_accepts_every_golden_proof(name):
         ovk = E.make_vk_from_trapdoors(fx["n"], fx["r1cs"]["m0"], fx["sigma"], I(fx["omega"]), I(fx["x_trapdoor"]), I(fx["z_trapdoor"]))
         assert vk == SE.ser_vk(c, ovk), fx["name"]
         pub = CO.fr_to_mont_limbs(curve, [I(v) for v in fx["instance"][1:]])
+        first = fx is load_golden(name)[0] or fx["name"] == load_golden(name)[0]["name"]
         for tname, ref in fx["proofs"].items():
+            if not first and tname != "merlin":       # every fixture with Merlin, the first one with all three (a check is ~2 s of CPU)
+                continue
             proof = bytes.fromhex(ref["bytes"])
             assert api.verify(curve, tname, vk, pub, proof), (fx["name"], tname)
+        if not first:
+            continue
         # tampering: a_at_x1 + 1 (bytes 2 x |G1| ..), a wrong public input, another transcript
         g1 = 48 if curve == "bls12_381" else 32
         bad = bytearray(proof)
