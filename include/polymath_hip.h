@@ -229,7 +229,10 @@ void pm_host_keccak_f1600(uint64_t state[25]);
  * the four-step NTT, prover.rs:239-243 / 315-328 split over ranks) and an all-gather of small HOST payloads (partial
  * points, status flags, scan carries).  RCCL form: rank 0 calls pm_comm_rccl_unique_id and ships the 128 bytes to the
  * other ranks by any means (the Rust host's own channel, torch.distributed's store, MPI ...); every rank then calls
- * pm_comm_rccl_create (collective: ncclCommInitRank).  librccl is loaded at first use (dlopen): no link-time dependency. */
+ * pm_comm_rccl_create (collective: ncclCommInitRank).  librccl is loaded at first use (dlopen): no link-time dependency.
+ * Contract: collectives are matched by program order on every rank; a rank that fails (any non-zero status of a phase) must
+ * take the whole job down -- its peers are waiting for it in the next collective, as with any NCCL / MPI program.  The status
+ * checks of the prover itself (unsatisfied witness, degree bounds) are exchanged first and fail on ALL ranks together. */
 typedef struct pm_comm pm_comm;
 int pm_comm_rccl_unique_id(void *out_128_bytes);
 int pm_comm_rccl_create(const void *unique_id_128_bytes, int rank, int world, int device, pm_comm **out);

@@ -269,6 +269,7 @@ class Comm:
         return out
 
     def close(self):
+        """pm_comm_destroy.  Detach it from its contexts first (Context.set_comm(None)): a context does not own its comm."""
         if getattr(self, "h", None):
             self.L.pm_comm_destroy(self.h)
             self.h = None

@@ -5,8 +5,10 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
+#include <thread>
 
 #include "internal.h"
 #include "comm.h"
@@ -18,7 +20,8 @@ using namespace pm;
 extern "C" void pm_host_keccak_f1600(uint64_t state[25]) { pmhost::keccak_f1600(state); }
 
 // ------------------------------------------------------------------------------ helpers
-// body(lo, hi, thread) over [0, count) in contiguous chunks on up to 32 host threads (one below 2^16 items)
+// body(lo, hi, thread) over [0, count) in contiguous chunks on up to 32 host threads (one below 2^16 items).  An exception in a
+// worker (bad_alloc) is caught there and re-thrown on the calling thread after the join -- never a std::terminate.
 template <class F>
 static void parallel_chunks(uint64_t count, F body) {
     unsigned T = std::thread::hardware_concurrency();
@@ -27,9 +30,21 @@ static void parallel_chunks(uint64_t count, F body) {
     if (const char *e = getenv("PM_HOST_THREADS")) T = (unsigned)std::max(1, atoi(e));
     if (T == 1) { body((uint64_t)0, count, 0u); return; }
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; ++t) th.emplace_back([=, &body] { body(count * t / T, count * (t + 1) / T, t); });
-    body((uint64_t)0, count / T, 0u);
+    std::vector<std::exception_ptr> errs(T);
+    auto guarded_body = [&](uint64_t lo, uint64_t hi, unsigned t) {
+        try { body(lo, hi, t); } catch (...) { errs[t] = std::current_exception(); }
+    };
+    for (unsigned t = 1; t < T; ++t) {
+        try {
+            th.emplace_back([=, &guarded_body] { guarded_body(count * t / T, count * (t + 1) / T, t); });
+        } catch (const std::system_error &) {            // no more threads: this chunk runs here
+            guarded_body(count * t / T, count * (t + 1) / T, t);
+        }
+    }
+    guarded_body((uint64_t)0, count / T, 0u);
     for (auto &x : th) x.join();
+    for (auto &e : errs)
+        if (e) std::rethrow_exception(e);
 }
 
 template <class C>
@@ -743,8 +758,13 @@ extern "C" int pm_pk_generate_sharded(pm_ctx *ctx, int curve, uint64_t m0, uint6
                                       int shard_rank, int shard_count, int layout, pm_pk **out) {
     if (!ctx || !a || !b || !c || !x_trapdoor || !z_trapdoor || !out) return PM_ERR_INVALID_ARG;
     PM_TRY(set_device(ctx));
-    return PM_DISPATCH(curve, pk_generate_impl<BlsCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, layout, out),
-                       pk_generate_impl<BnCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, layout, out));
+    try {
+        return PM_DISPATCH(curve, pk_generate_impl<BlsCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, layout, out),
+                           pk_generate_impl<BnCurve>(ctx, m0, mw, nr, a, b, c, x_trapdoor, z_trapdoor, shard_rank, shard_count, layout, out));
+    } catch (const std::exception &e) {       // host allocation failure in the O(n) setup vectors: a status, never an abort
+        ctx->err = e.what();
+        return PM_ERR_STATE;
+    }
 }
 
 extern "C" int pm_pk_generate(pm_ctx *ctx, int curve, uint64_t m0, uint64_t mw, uint64_t nr, const pm_csr *a,

@@ -12,6 +12,7 @@
 //   callbacks (pm_comm_from_callbacks) -- the host brings its own transport (torch.distributed in tests).
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -34,7 +35,7 @@ struct LocalGroup {
     uint64_t generation = 0;
     std::vector<const void *> send;
     std::vector<void *> recv;
-    bool failed = false;
+    std::atomic<bool> failed{false};   // sticky: once a rank failed a collective, every later one reports it
     // PM_LOCAL_COMM_SERIALIZE=1: between collectives only ONE rank runs at a time (a turnstile), so that N ranks emulated on
     // one GPU do not time-slice it: each rank's kernels then take what they would take alone (bench.py's emulation).
     bool serialize = false;
