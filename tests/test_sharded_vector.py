@@ -303,6 +303,14 @@ def test_bench_multi_gpu_launch_path_with_a_world_of_one():
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["proof_bytes"] == j2["proof_bytes"]
     assert "rccl (native" in j2["config"]["parallelism"], j2["config"]["parallelism"]
+    # the collective fallback when RCCL cannot be used inside the library: pm_comm callbacks over the same nccl process group
+    env["BENCH_NO_RCCL"] = "1"
+    three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                            "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1"] + common,
+                           capture_output=True, text=True, timeout=600, env=env)
+    assert three.returncode == 0, three.stderr[-3000:]
+    j3 = json.loads([l for l in three.stdout.splitlines() if l.startswith("{")][-1])
+    assert j3["proof_bytes"] == j1["proof_bytes"] and "torch.distributed callbacks (nccl)" in j3["config"]["parallelism"]
 
 
 @pytest.mark.gpu
