@@ -417,3 +417,29 @@ def test_vector_sharded_keys_loaded_from_an_existing_key():
     for pk in pks:
         pk.free()
     whole.free()
+
+
+@pytest.mark.gpu
+def test_vector_sharded_reference_bench_circuit_skew():
+    """The reference's own bench circuit (benches/bench.rs:38-61: every padding witness carries the same value, so one bucket per
+    window of the [c] MSM is hot) at 2^14 - 100 constraints on 4 vector-sharded ranks: the z_tail slices are pure repetitions, the
+    hot buckets go through the parallel fold on every rank; same proof as on one GPU."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Field, LimbCircuit, Polymath, _csr
+    curve, N = "bls12_381", 4
+    c = CURVES[curve]
+    f = Field(curve)
+    g = PC.SplitMix64(0xBEAC4)
+    nc = (1 << 14) - 100
+    pm0 = Polymath(curve, "merlin", device=0)
+    r1cs, inst, wit = pm0._synthesize(PC.BenchCircuit(g.fr(c.r), g.fr(c.r), nc, nc))
+    assert len(set(wit[2:])) == 1
+    lc = LimbCircuit(f, r1cs.m0, r1cs.mw, r1cs.nr, (_csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)), f.fr_limbs(inst), f.fr_limbs(wit))
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    ref_pk = pm0.setup(lc, x, z)
+    ref = pm0.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    assert all(p == ref for p in proofs)
+    for pk in pks:
+        pk.free()
+    ref_pk.free()
