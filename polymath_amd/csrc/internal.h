@@ -104,7 +104,8 @@ struct TwiddleCache {
     unsigned log_n = 0;
     unsigned long long stamp = 0;   // last use (LRU eviction)
     DevBuf fwd, inv;          // n/2 twiddles each, standard Montgomery form
-    DevBuf fwd_int, inv_int;  // the same powers in the reduced-radix internal form (ntt.hip butterflies)
+    DevBuf fwd_int, inv_int;  // the same powers in the reduced-radix internal form (ntt.hip butterflies): dense 8 x u32 for the
+                              // 32-bit-limb tile kernels, 10 x u32 28-bit-limb records for the 28-bit ones (ntt_l28_domain)
 };
 
 }  // namespace pm
@@ -252,7 +253,7 @@ template <class C>
 int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d_data, unsigned log_n, bool inverse);
 // device table of omega_{2^log_n}^j (or its inverse), j < 2^(log_n - 1); cached per context
 template <class C>
-int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out, bool internal = false);
+int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out);
 
 // tables == nullptr (or c == 0): d_bases points at the MSM's first base.  Otherwise d_bases is unused, the
 // points come from tables->table and tables->base_index locates the MSM's first base inside window 0.

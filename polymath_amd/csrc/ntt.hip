@@ -11,6 +11,7 @@
 // instead of 22.  Twiddles come from one n/2-entry table per (curve, log n, direction), built
 // once per context and L2/MALL resident across passes.
 #include <cstring>
+#include <type_traits>
 
 #include "internal.h"
 #include "fq28.cuh"
@@ -25,8 +26,15 @@ struct PowTable {
 // out[j] = omega^j in the standard Montgomery form; out_int[j] = the same power as the plain integer
 // omega^j 2^(28 N) mod r ("internal" form of fq28.cuh): a reduced-radix product of a standard-form value with
 // it stays in the standard form, so the butterflies need no conversion of the data.
+// The internal form is kept either dense (out_int, 8 x u32: the 32-bit-limb tile kernels unpack it per butterfly) or already on
+// 28-bit limbs (out28, Tw28 records of 10 x u32: the 28-bit tile kernels load it ready for the product).
+template <class RR>
+struct alignas(8) Tw28 {
+    uint32_t l[RR::N];
+};
+
 template <class P, class RR>
-__global__ void k_twiddles(Fp<P> *out, Fp<P> *out_int, size_t count, PowTable<P> tab, unsigned nbits) {
+__global__ void k_twiddles(Fp<P> *out, Fp<P> *out_int, Tw28<RR> *out28, size_t count, PowTable<P> tab, unsigned nbits) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     Fp<P> acc = Fp<P>::one();
@@ -35,7 +43,15 @@ __global__ void k_twiddles(Fp<P> *out, Fp<P> *out_int, size_t count, PowTable<P>
     out[j] = acc;
     Fp<P> c;
     for (int i = 0; i < P::N; ++i) c.l[i] = RR::STD2INT[i];
-    out_int[j] = mul<P>(acc, c);
+    const Fp<P> wi = mul<P>(acc, c);
+    if (out_int) out_int[j] = wi;
+    if (out28) {
+        const F28<RR> u = f28_unpack<RR>(wi.l);
+        Tw28<RR> r;
+#pragma unroll
+        for (int i = 0; i < RR::N; ++i) r.l[i] = u.l[i];
+        out28[j] = r;
+    }
 }
 
 template <class P>
@@ -183,15 +199,18 @@ __global__ __launch_bounds__(256) void k_ntt_first_pass(const Fp<P> *src, Fp<P> 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Round-2 pass kernels: the tile lives in LDS on 28-BIT LIMBS (10 x u32 per element, limb-major planes -- one bank per
-// lane for every access), so a butterfly is one carry-free product (fq28.cuh) plus lazy limb-wise add / sub and a carry
-// propagation: no dense <-> reduced-radix conversion of the data and no modular correction per stage (~400 instead of
-// 608 instructions per butterfly).  Fr has 280 - 255 = 25 spare bits: values grow by at most 4p per stage (x + yw < V + 2,
-// x + 4p - yw < V + 4), 37p after nine stages, far below the 2^25 p the product tolerates; they are brought back to the
-// canonical range once, on the way out (conditional subtractions of 32p ... p; in the last pass of an inverse transform the
-// n^-1 product does it).  Elements enter and leave in the dense canonical form: the results are bit-identical.
-// 256 threads and one 80 KiB tile per workgroup: exactly two workgroups share a CU's 160 KiB (tools/lds_occupancy.hip: 80 KiB -> 2,
-// 81 KiB -> 1) = 2 waves per SIMD, and one workgroup's barriers and loads hide under the other's butterflies.
+// Round-2 pass kernels: the tile lives in LDS in REDUCED RADIX (C::FrNttRR: 9 x u32 limbs of 29 bits per element, limb-major
+// planes -- one bank per lane for every access), so a butterfly is one carry-free product (fq28.cuh) plus lazy limb-wise add / sub:
+// no dense <-> reduced-radix conversion of the data and no modular correction per stage.  What the kernels are bound by is the
+// multiplier: A/B runs on one box showed that removing 10 % of the instructions -- all of them cheap ones: masks,
+// shifts, adds, the twiddle unpack -- or batching the tile's loads changes nothing, so the lever is the number of v_mad_u64_u32:
+// 2 N^2 per product, 162 on 9 limbs of 29 bits against 200 on 10 limbs of 28.  A 255-bit field leaves 261 - 255 = 6 spare bits:
+// values grow by at most 4p per stage (x + yw < V + 2, x + 4p - yw < V + 4), 37p after nine stages, below the 64p the radix holds
+// and the 2^6 p the product tolerates; they are brought back to the canonical range once, on the way out (conditional subtractions
+// of 32p ... p; in the last pass of an inverse transform the n^-1 product does it).  Elements enter and leave in the dense
+// canonical form: the results are bit-identical.
+// 256 threads and one 72 KiB tile per workgroup: two workgroups share a CU's 160 KiB (tools/lds_occupancy.hip) = 2 waves per SIMD,
+// and one workgroup's barriers and loads hide under the other's butterflies.
 constexpr unsigned L28_THREADS = 256;
 
 template <class RR>
@@ -240,13 +259,18 @@ __device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d
     }
 }
 
-// the ns butterfly stages on the tile; element (r, c) sits at slot r * cols + (FIRST ? (c + r) & (cols - 1) : c)
+// the ns butterfly stages on the tile; element (r, c) sits at slot r * cols + (FIRST ? (c + r) & (cols - 1) : c).
+// Carries are propagated after every second stage only: a stage adds at most 2^(W+1) to a limb (x + yw: + 2^W; x + K4 - yw: K4's
+// limbs are < 2^(W+1)), so a limb entering a product is below 2^W + 2^(W+1) and the column sums stay in 64 bits
+// (W = 29, N = 9: 9 * 1.5 * 2^30 * 2^29 + 9 * 2^58 < 2^63 against a tight twiddle; the n^-1 product of l28_emit sees at most
+// 2.5 * 2^30: < 2^63.8).  The stage that ends the pass leaves its carries to l28_emit.
 template <class P, class RR, bool FIRST>
-__device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Fp<P> *tw, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols,
+__device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols,
                                            size_t lo0) {
     const unsigned cols = 1u << log_cols, cm = cols - 1, rows = 1u << ns, nbf = (rows >> 1) * cols, tid = threadIdx.x;
     for (unsigned st = 0; st < ns; ++st) {
         const unsigned s = s0 + st + 1, half = 1u << st;
+        const bool norm = (st & 1) == 1 && st + 1 != ns;
         auto slots = [&](unsigned e, unsigned &e0, unsigned &e1, size_t &j) {
             const unsigned c = e & cm, k = e >> log_cols;
             const unsigned r0 = ((k >> st) << (st + 1)) | (k & (half - 1)), r1 = r0 + half;
@@ -254,38 +278,58 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Fp<
             e0 = r0 * cols + (FIRST ? ((c + r0) & cm) : c);
             e1 = r1 * cols + (FIRST ? ((c + r1) & cm) : c);
         };
-        auto bfly = [&](unsigned e0, unsigned e1, const Fp<P> &wd) {
-            const F28<RR> x = l28_load<RR>(t, tile, e0), y = l28_load<RR>(t, tile, e1);
-            const F28<RR> yw = f28_mul<RR>(y, f28_unpack<RR>(wd.l));                 // tight, < 2p
-            l28_store<RR>(t, tile, e0, f28_weak_norm<RR>(f28_add<RR>(x, yw)));       // < V + 2
-            l28_store<RR>(t, tile, e1, f28_weak_norm<RR>(f28_sub_k4<RR>(x, yw)));    // x + 4p - yw < V + 4
+        // NORM is a compile-time flag of the stage body (two instantiations behind one uniform branch): as a run-time select the
+        // compiler computes the carry chain in every stage and picks afterwards
+        auto stage = [&](auto norm_tag) {
+            constexpr bool NORM = decltype(norm_tag)::value;
+            auto bfly = [&](unsigned e0, unsigned e1, const Tw28<RR> &wd) {
+                const F28<RR> x = l28_load<RR>(t, tile, e0), y = l28_load<RR>(t, tile, e1);
+                F28<RR> w;
+#pragma unroll
+                for (int i = 0; i < RR::N; ++i) w.l[i] = wd.l[i];
+                const F28<RR> yw = f28_mul<RR>(y, w);                                    // tight, < 2p
+                const F28<RR> lo = f28_add<RR>(x, yw), hi = f28_sub_k4<RR>(x, yw);       // values < V + 2, < V + 4
+                if (NORM) {
+                    l28_store<RR>(t, tile, e0, f28_weak_norm<RR>(lo));
+                    l28_store<RR>(t, tile, e1, f28_weak_norm<RR>(hi));
+                } else {
+                    l28_store<RR>(t, tile, e0, lo);
+                    l28_store<RR>(t, tile, e1, hi);
+                }
+            };
+            if (nbf == 4 * L28_THREADS) {   // full tile: the four twiddle loads of this lane's butterflies are issued before the arithmetic
+                Tw28<RR> w[4];
+                unsigned e0v[4], e1v[4];
+#pragma unroll
+                for (unsigned q = 0; q < 4; ++q) {
+                    size_t j;
+                    slots(tid + q * L28_THREADS, e0v[q], e1v[q], j);
+                    w[q] = tw[j << (log_n - s)];
+                }
+#pragma unroll
+                for (unsigned q = 0; q < 4; ++q) bfly(e0v[q], e1v[q], w[q]);
+            } else {
+                for (unsigned e = tid; e < nbf; e += L28_THREADS) {
+                    unsigned e0, e1;
+                    size_t j;
+                    slots(e, e0, e1, j);
+                    bfly(e0, e1, tw[j << (log_n - s)]);
+                }
+            }
         };
-        if (nbf == 4 * L28_THREADS) {   // full tile: the four twiddle loads of this lane's butterflies are issued before the arithmetic
-            Fp<P> w[4];
-            unsigned e0v[4], e1v[4];
-#pragma unroll
-            for (unsigned q = 0; q < 4; ++q) {
-                size_t j;
-                slots(tid + q * L28_THREADS, e0v[q], e1v[q], j);
-                w[q] = tw[j << (log_n - s)];
-            }
-#pragma unroll
-            for (unsigned q = 0; q < 4; ++q) bfly(e0v[q], e1v[q], w[q]);
-        } else {
-            for (unsigned e = tid; e < nbf; e += L28_THREADS) {
-                unsigned e0, e1;
-                size_t j;
-                slots(e, e0, e1, j);
-                bfly(e0, e1, tw[j << (log_n - s)]);
-            }
-        }
+        if (norm)
+            stage(std::true_type{});
+        else
+            stage(std::false_type{});
         __syncthreads();
     }
 }
 
 template <class P, class RR>
 __device__ __forceinline__ void l28_emit(const F28<RR> &v, Fp<P> *dst, const F28<RR> &scale28, int do_scale) {
-    const F28<RR> c = do_scale ? f28_mul<RR>(v, scale28) : v;    // the product's output is < 2p: the subtraction chain then ends at once
+    // v: limbs < 2^32 (the last stages' carries are still pending).  The product takes it as it is and returns < 2p, so the
+    // subtraction chain ends at once; otherwise the carries are propagated here, once per element and pass.
+    const F28<RR> c = do_scale ? f28_mul<RR>(v, scale28) : f28_weak_norm<RR>(v);
     Fp<P> out;
     l28_pack_canonical<RR>(l28_canonical<RR>(c), out.l);
     *dst = out;
@@ -293,17 +337,27 @@ __device__ __forceinline__ void l28_emit(const F28<RR> &v, Fp<P> *dst, const F28
 
 // general pass: stages [s0, s0 + ns), tile of 2^ns rows x 2^log_cols contiguous columns, src -> dst at the same positions
 template <class P, class RR>
-__global__ __launch_bounds__(L28_THREADS) void k_ntt_pass28(const Fp<P> *a, Fp<P> *dst, const Fp<P> *tw, unsigned log_n, unsigned s0, unsigned ns,
+__global__ __launch_bounds__(L28_THREADS) void k_ntt_pass28(const Fp<P> *a, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns,
                                                              unsigned log_cols, Fp<P> scale_int, int do_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
     const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols;
     const size_t lo_groups = ((size_t)1 << s0) >> log_cols, g = blockIdx.x;
     const size_t hi = g / lo_groups, lo0 = (g % lo_groups) << log_cols, base = (hi << (s0 + ns)) + lo0;
-    for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
-        const unsigned r = e >> log_cols, c = e & (cols - 1);
-        const Fp<P> v = a[base + ((size_t)r << s0) + c];
-        l28_store<RR>(t, tile, e, f28_unpack<RR>(v.l));
+    // every load of the tile is in flight before the first one is unpacked (a 2^11-element tile is 8 per lane = 64 VGPRs):
+    // with one load per loop trip the workgroup paid eight HBM round trips in sequence, a quarter of its time
+    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += 8 * L28_THREADS) {
+        Fp<P> v[8];
+#pragma unroll
+        for (unsigned q = 0; q < 8; ++q) {
+            const unsigned e = e8 + q * L28_THREADS, r = e >> log_cols, c = e & (cols - 1);
+            if (e < tile) v[q] = a[base + ((size_t)r << s0) + c];
+        }
+#pragma unroll
+        for (unsigned q = 0; q < 8; ++q) {
+            const unsigned e = e8 + q * L28_THREADS;
+            if (e < tile) l28_store<RR>(t, tile, e, f28_unpack<RR>(v[q].l));
+        }
     }
     __syncthreads();
     l28_stages<P, RR, false>(t, tile, tw, log_n, s0, ns, log_cols, lo0);
@@ -316,16 +370,24 @@ __global__ __launch_bounds__(L28_THREADS) void k_ntt_pass28(const Fp<P> *a, Fp<P
 
 // first pass with the bit reversal folded into its loads (see k_ntt_first_pass), src -> dst
 template <class P, class RR>
-__global__ __launch_bounds__(L28_THREADS) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Fp<P> *tw, unsigned log_n, unsigned ns,
+__global__ __launch_bounds__(L28_THREADS) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned ns,
                                                                    unsigned log_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
     const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols, H = log_n - ns, cm = cols - 1;
     const size_t g = blockIdx.x;
-    for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
-        const unsigned rb = e >> log_cols, c = e & cm, r = __brev(rb) >> (32 - ns);
-        const Fp<P> v = src[((size_t)rb << H) + (g << log_cols) + c];
-        l28_store<RR>(t, tile, r * cols + ((c + r) & cm), f28_unpack<RR>(v.l));
+    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += 8 * L28_THREADS) {      // loads batched as in k_ntt_pass28
+        Fp<P> v[8];
+#pragma unroll
+        for (unsigned q = 0; q < 8; ++q) {
+            const unsigned e = e8 + q * L28_THREADS, rb = e >> log_cols, c = e & cm;
+            if (e < tile) v[q] = src[((size_t)rb << H) + (g << log_cols) + c];
+        }
+#pragma unroll
+        for (unsigned q = 0; q < 8; ++q) {
+            const unsigned e = e8 + q * L28_THREADS, rb = e >> log_cols, c = e & cm, r = __brev(rb) >> (32 - ns);
+            if (e < tile) l28_store<RR>(t, tile, r * cols + ((c + r) & cm), f28_unpack<RR>(v[q].l));
+        }
     }
     __syncthreads();
     l28_stages<P, RR, true>(t, tile, tw, log_n, 0, ns, log_cols, 0);
@@ -343,9 +405,22 @@ __global__ void k_scale(Fp<P> *a, size_t n, Fp<P> s) {
     if (i < n) a[i] = mul<P>(a[i], s);
 }
 
+static bool ntt_fused_enabled() {
+    static const bool v = [] { const char *e = getenv("PM_NTT_FUSED"); return !(e && e[0] == '0'); }();
+    return v;
+}
+// domains transformed by the 28-bit-limb tile kernels (their twiddle records are then kept on 28-bit limbs too)
+static bool ntt_l28_domain(unsigned log_n) {
+    static const bool l28 = [] { const char *e = getenv("PM_NTT_L28"); return !(e && e[0] == '0'); }();
+    const unsigned tile_log = log_n > 24 ? (unsigned)LOG_TILE + 1 : (unsigned)LOG_TILE;
+    return ntt_fused_enabled() && l28 && log_n >= tile_log + 3;
+}
+
 template <class C>
-int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out, bool internal) {
+static int twiddles_slot(pm_ctx *ctx, unsigned log_n, TwiddleCache **out) {
     typedef typename C::FrP P;
+    typedef typename C::FrRR RR;
+    typedef typename C::FrNttRR NttRR;
     typedef Fp<P> Fr;
     const int cid = C::ID;
     TwiddleCache *slot = nullptr;
@@ -360,11 +435,13 @@ int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C:
         slot->stamp = ++ctx->tw_clock;
         slot->curve = cid;
         slot->log_n = log_n;
+        const bool l28 = ntt_l28_domain(log_n);
         size_t half = log_n ? ((size_t)1 << (log_n - 1)) : 1;
+        const size_t int_bytes = half * (l28 ? sizeof(Tw28<NttRR>) : sizeof(Fr));
         PM_HIP(ctx, slot->fwd.reserve(half * sizeof(Fr)));
         PM_HIP(ctx, slot->inv.reserve(half * sizeof(Fr)));
-        PM_HIP(ctx, slot->fwd_int.reserve(half * sizeof(Fr)));
-        PM_HIP(ctx, slot->inv_int.reserve(half * sizeof(Fr)));
+        PM_HIP(ctx, slot->fwd_int.reserve(int_bytes));
+        PM_HIP(ctx, slot->inv_int.reserve(int_bytes));
         Fr root;
         for (int i = 0; i < P::N; ++i) root.l[i] = C::ROOT_MONT[i];
         for (unsigned i = log_n; i < (unsigned)C::TWO_ADICITY; ++i) root = sqr<P>(root);
@@ -377,14 +454,26 @@ int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C:
                 w = sqr<P>(w);
             }
             Fr *dst = dir ? slot->inv.as<Fr>() : slot->fwd.as<Fr>();
-            Fr *dst_int = dir ? slot->inv_int.as<Fr>() : slot->fwd_int.as<Fr>();
+            DevBuf &ib = dir ? slot->inv_int : slot->fwd_int;
             unsigned blocks = (unsigned)((half + 255) / 256);
-            hipLaunchKernelGGL((k_twiddles<P, typename C::FrRR>), dim3(blocks), dim3(256), 0, ctx->stream, dst, dst_int, half, tab,
-                               log_n ? log_n - 1 : 0);
+            if (l28)
+                hipLaunchKernelGGL((k_twiddles<P, NttRR>), dim3(blocks), dim3(256), 0, ctx->stream, dst, (Fr *)nullptr, ib.as<Tw28<NttRR>>(), half,
+                                   tab, log_n ? log_n - 1 : 0);
+            else
+                hipLaunchKernelGGL((k_twiddles<P, RR>), dim3(blocks), dim3(256), 0, ctx->stream, dst, ib.as<Fr>(), (Tw28<RR> *)nullptr, half, tab,
+                                   log_n ? log_n - 1 : 0);
             PM_HIP(ctx, hipGetLastError());
         }
     }
-    *out = internal ? (inv_dir ? slot->inv_int.as<Fr>() : slot->fwd_int.as<Fr>()) : (inv_dir ? slot->inv.as<Fr>() : slot->fwd.as<Fr>());
+    *out = slot;
+    return PM_OK;
+}
+
+template <class C>
+int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C::FrP> **out) {
+    TwiddleCache *slot = nullptr;
+    PM_TRY(twiddles_slot<C>(ctx, log_n, &slot));
+    *out = inv_dir ? slot->inv.as<Fp<typename C::FrP>>() : slot->fwd.as<Fp<typename C::FrP>>();
     return PM_OK;
 }
 
@@ -396,19 +485,21 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     if (log_n == 0) return PM_OK;
     StageTimer timer(ctx, T_NTT);
     const size_t n = (size_t)1 << log_n;
-    const Fr *tw = nullptr;
-    PM_TRY(twiddles_get<C>(ctx, log_n, inv_dir, &tw, true));
+    TwiddleCache *slot = nullptr;
+    PM_TRY(twiddles_slot<C>(ctx, log_n, &slot));
+    const DevBuf &twb = inv_dir ? slot->inv_int : slot->fwd_int;
+    const Fr *tw = twb.as<Fr>();                                  // dense internal form, unless ntt_l28_domain(log_n)
     // passes of LOG_TILE = 8 stages on 256-row x 8-column tiles; domains above 2^24 take 9 stages per pass
     // (512 rows x 4 columns, the same 64 KiB of LDS) so that 2^25..2^27 points still need only three passes
     const unsigned tile_log = log_n > 24 ? (unsigned)LOG_TILE + 1 : (unsigned)LOG_TILE;
     const Fr ninv = inv_dir ? inverse<P>(from_u64<P>((uint64_t)n)) : Fr::one();
-    static const bool fused = [] { const char *e = getenv("PM_NTT_FUSED"); return !(e && e[0] == '0'); }();
-    static const bool l28 = [] { const char *e = getenv("PM_NTT_L28"); return !(e && e[0] == '0'); }();
-    if (fused && l28 && log_n >= tile_log + 3) {
-        // the same pass structure on the 28-bit-limb tiles (k_ntt_pass28): 2^11 elements x 40 B = 80 KiB of LDS per workgroup
+    const bool fused = ntt_fused_enabled();
+    if (ntt_l28_domain(log_n)) {
+        // the same pass structure on the reduced-radix tiles (k_ntt_pass28, 9 limbs of 29 bits): 2^11 elements x 36 B = 72 KiB of LDS per workgroup
         PM_HIP(ctx, ctx->ntt_tmp.reserve(n * sizeof(Fr)));
         Fr *tmp = ctx->ntt_tmp.as<Fr>();
-        typedef typename C::FrRR RR;
+        typedef typename C::FrNttRR RR;
+        const Tw28<RR> *tw28 = twb.as<Tw28<RR>>();
         const size_t lds28 = ((size_t)1 << 11) * RR::N * 4;
         static bool attr_set[2] = {false, false};
         if (!attr_set[C::ID]) {
@@ -418,22 +509,24 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         }
         Fr scale_int;
         for (int i = 0; i < P::N; ++i) scale_int.l[i] = RR::STD2INT[i];
-        scale_int = mul<P>(ninv, scale_int);                      // n^-1 2^280 as a plain integer: the product with it scales AND reduces
-        {
-            const unsigned ns = tile_log, log_cols = 11 - ns;
-            hipLaunchKernelGGL((k_ntt_first_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
-                               ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)d, tmp, tw, log_n, ns, log_cols);
-            PM_HIP(ctx, hipGetLastError());
-        }
-        unsigned s0 = tile_log;
-        while (s0 < log_n) {
-            const unsigned ns = log_n - s0 < tile_log ? log_n - s0 : tile_log;
-            unsigned log_cols = 11 - ns < 3 ? 11 - ns : 3;
-            if (s0 < log_cols) log_cols = s0;
+        scale_int = mul<P>(ninv, scale_int);                      // n^-1 2^(W N) as a plain integer: the product with it scales AND reduces
+        // passes balanced over the stages, every tile 2^11 elements (21 = 7 + 7 + 7 with 16-column tiles, not 8 + 8 + 5 with a
+        // last pass whose workgroups hold 2^8 elements; 17 and 18 take two 9-stage passes instead of three)
+        const unsigned p8 = (log_n + 7) / 8, p9 = (log_n + 8) / 9, npass = p9 < p8 ? p9 : p8;
+        unsigned s0 = 0;
+        for (unsigned k = 0; k < npass; ++k) {
+            const unsigned ns = log_n / npass + (k < log_n % npass ? 1 : 0);
+            unsigned log_cols = 11 - ns;
             const bool last = s0 + ns == log_n;
-            hipLaunchKernelGGL((k_ntt_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
-                               ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)tmp, last ? d : tmp, tw, log_n, s0, ns, log_cols,
-                               scale_int, last && inv_dir ? 1 : 0);
+            if (k == 0) {
+                hipLaunchKernelGGL((k_ntt_first_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
+                                   ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)d, tmp, tw28, log_n, ns, log_cols);
+            } else {
+                if (s0 < log_cols) log_cols = s0;
+                hipLaunchKernelGGL((k_ntt_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
+                                   ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)tmp, last ? d : tmp, tw28, log_n, s0, ns,
+                                   log_cols, scale_int, last && inv_dir ? 1 : 0);
+            }
             PM_HIP(ctx, hipGetLastError());
             s0 += ns;
         }
@@ -486,8 +579,8 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     return PM_OK;
 }
 
-template int twiddles_get<BlsCurve>(pm_ctx *, unsigned, bool, const Fp<BlsFrP> **, bool);
-template int twiddles_get<BnCurve>(pm_ctx *, unsigned, bool, const Fp<BnFrP> **, bool);
+template int twiddles_get<BlsCurve>(pm_ctx *, unsigned, bool, const Fp<BlsFrP> **);
+template int twiddles_get<BnCurve>(pm_ctx *, unsigned, bool, const Fp<BnFrP> **);
 template int ntt_run<BlsCurve>(pm_ctx *, Fp<BlsFrP> *, unsigned, bool);
 template int ntt_run<BnCurve>(pm_ctx *, Fp<BnFrP> *, unsigned, bool);
 

@@ -31,7 +31,7 @@ def test_ntt_golden(gpu_ctx, oracle, curve):
 
 
 @pytest.mark.parametrize("curve", CURVE_LIST)
-@pytest.mark.parametrize("log_n", [1, 4, 7, 8, 9, 11, 13, 16, 17])
+@pytest.mark.parametrize("log_n", [1, 4, 7, 8, 9, 11, 12, 13, 16, 17, 18, 19, 20])
 def test_ntt_vs_oracle(gpu_ctx, oracle, curve, log_n):
     a = rand_fr_limbs(curve, 1 << log_n, 100 + log_n)
     for inverse in (False, True):
