@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_ntt_first_pass(const Fp<P> *src, Fp<P> 
 // canonical form: the results are bit-identical.
 // 256 threads and one 72 KiB tile per workgroup: two workgroups share a CU's 160 KiB (tools/lds_occupancy.hip) = 2 waves per SIMD,
 // and one workgroup's barriers and loads hide under the other's butterflies.
-constexpr unsigned L28_THREADS = 256;
+constexpr unsigned L28_THREADS = 512;
+constexpr unsigned L28_BPL = 1024 / L28_THREADS;   // butterflies per lane and stage of a full 2^11-element tile
+constexpr unsigned L28_EPL = 2048 / L28_THREADS;   // elements per lane of a full tile
 
 template <class RR>
 __device__ __forceinline__ F28<RR> l28_load(const uint32_t *t, unsigned tile, unsigned e) {
@@ -297,17 +299,17 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
                     l28_store<RR>(t, tile, e1, hi);
                 }
             };
-            if (nbf == 4 * L28_THREADS) {   // full tile: the four twiddle loads of this lane's butterflies are issued before the arithmetic
-                Tw28<RR> w[4];
-                unsigned e0v[4], e1v[4];
+            if (nbf == L28_BPL * L28_THREADS) {   // full tile: the twiddle loads of this lane's butterflies are issued before the arithmetic
+                Tw28<RR> w[L28_BPL];
+                unsigned e0v[L28_BPL], e1v[L28_BPL];
 #pragma unroll
-                for (unsigned q = 0; q < 4; ++q) {
+                for (unsigned q = 0; q < L28_BPL; ++q) {
                     size_t j;
                     slots(tid + q * L28_THREADS, e0v[q], e1v[q], j);
                     w[q] = tw[j << (log_n - s)];
                 }
 #pragma unroll
-                for (unsigned q = 0; q < 4; ++q) bfly(e0v[q], e1v[q], w[q]);
+                for (unsigned q = 0; q < L28_BPL; ++q) bfly(e0v[q], e1v[q], w[q]);
             } else {
                 for (unsigned e = tid; e < nbf; e += L28_THREADS) {
                     unsigned e0, e1;
@@ -337,7 +339,7 @@ __device__ __forceinline__ void l28_emit(const F28<RR> &v, Fp<P> *dst, const F28
 
 // general pass: stages [s0, s0 + ns), tile of 2^ns rows x 2^log_cols contiguous columns, src -> dst at the same positions
 template <class P, class RR>
-__global__ __launch_bounds__(L28_THREADS) void k_ntt_pass28(const Fp<P> *a, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns,
+__global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_pass28(const Fp<P> *a, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns,
                                                              unsigned log_cols, Fp<P> scale_int, int do_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
@@ -346,15 +348,15 @@ __global__ __launch_bounds__(L28_THREADS) void k_ntt_pass28(const Fp<P> *a, Fp<P
     const size_t hi = g / lo_groups, lo0 = (g % lo_groups) << log_cols, base = (hi << (s0 + ns)) + lo0;
     // every load of the tile is in flight before the first one is unpacked (a 2^11-element tile is 8 per lane = 64 VGPRs):
     // with one load per loop trip the workgroup paid eight HBM round trips in sequence, a quarter of its time
-    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += 8 * L28_THREADS) {
-        Fp<P> v[8];
+    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * L28_THREADS) {
+        Fp<P> v[L28_EPL];
 #pragma unroll
-        for (unsigned q = 0; q < 8; ++q) {
+        for (unsigned q = 0; q < L28_EPL; ++q) {
             const unsigned e = e8 + q * L28_THREADS, r = e >> log_cols, c = e & (cols - 1);
             if (e < tile) v[q] = a[base + ((size_t)r << s0) + c];
         }
 #pragma unroll
-        for (unsigned q = 0; q < 8; ++q) {
+        for (unsigned q = 0; q < L28_EPL; ++q) {
             const unsigned e = e8 + q * L28_THREADS;
             if (e < tile) l28_store<RR>(t, tile, e, f28_unpack<RR>(v[q].l));
         }
@@ -370,21 +372,21 @@ __global__ __launch_bounds__(L28_THREADS) void k_ntt_pass28(const Fp<P> *a, Fp<P
 
 // first pass with the bit reversal folded into its loads (see k_ntt_first_pass), src -> dst
 template <class P, class RR>
-__global__ __launch_bounds__(L28_THREADS) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned ns,
+__global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned ns,
                                                                    unsigned log_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
     const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols, H = log_n - ns, cm = cols - 1;
     const size_t g = blockIdx.x;
-    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += 8 * L28_THREADS) {      // loads batched as in k_ntt_pass28
-        Fp<P> v[8];
+    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * L28_THREADS) {      // loads batched as in k_ntt_pass28
+        Fp<P> v[L28_EPL];
 #pragma unroll
-        for (unsigned q = 0; q < 8; ++q) {
+        for (unsigned q = 0; q < L28_EPL; ++q) {
             const unsigned e = e8 + q * L28_THREADS, rb = e >> log_cols, c = e & cm;
             if (e < tile) v[q] = src[((size_t)rb << H) + (g << log_cols) + c];
         }
 #pragma unroll
-        for (unsigned q = 0; q < 8; ++q) {
+        for (unsigned q = 0; q < L28_EPL; ++q) {
             const unsigned e = e8 + q * L28_THREADS, rb = e >> log_cols, c = e & cm, r = __brev(rb) >> (32 - ns);
             if (e < tile) l28_store<RR>(t, tile, r * cols + ((c + r) & cm), f28_unpack<RR>(v[q].l));
         }
