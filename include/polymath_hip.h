@@ -271,6 +271,12 @@ int pm_ctx_set_comm(pm_ctx *ctx, pm_comm *comm);
 int pm_synth_r1cs(int curve, uint64_t nr, uint64_t seed, uint64_t *a_val, uint32_t *a_col, uint64_t *b_val, uint32_t *b_col,
                   uint64_t *c_val, uint32_t *c_col, uint64_t *instance, uint64_t *witness);
 
+/* Diagnostic: `products_per_field` seeded products a*b and squares a*a per field (plus p-1, 0, 1 operands), computed on the
+ * device the way the kernels do -- the dense reduced-radix product of field.cuh and the internal-radix product of fq28.cuh --
+ * and compared word for word with the host's 32-bit CIOS.  mismatches[k]: k = 0 BLS12-381 Fr, 1 BN254 Fr, 2 BLS12-381 Fq,
+ * 3 BN254 Fq; all zero on a healthy build.  No reference counterpart: ark-ff's `Fp::mul_assign` is the thing restated. */
+int pm_selftest_field(pm_ctx *ctx, size_t products_per_field, uint64_t seed, uint64_t mismatches[4]);
+
 /* Debug / parity taps: copy an intermediate vector of the proof in flight back to the host.
  * which: 0 u_evals(n) 1 w_evals(n) 2 u coeffs(n) 3 w coeffs(n) 4 h coeffs(n) 5 witness-u coeffs(n)
  *        6 z_tail(M-m0) 7 quotient (10n+23) */

@@ -51,7 +51,7 @@ EXPORTS = [
     "pm_ntt_device", "pm_msm_g1", "pm_bases_upload", "pm_bases_generate_multiples", "pm_bases_download",
     "pm_bases_precompute", "pm_bases_len", "pm_bases_free", "pm_msm_g1_resident", "pm_g1_sum", "pm_pk_load", "pm_pk_generate",
     "pm_pk_info", "pm_pk_msm_plan", "pm_pk_export_bases", "pm_pk_free", "pm_prove_phase1", "pm_prove_phase1_device", "pm_prove_phase2", "pm_prove_phase3", "pm_host_prove", "pm_host_prove_sharded",
-    "pm_prove_tap", "pm_host_keccak_f1600", "pm_synth_r1cs",
+    "pm_prove_tap", "pm_host_keccak_f1600", "pm_synth_r1cs", "pm_selftest_field",
     "pm_pk_load_sharded", "pm_pk_generate_sharded", "pm_layout_indices", "pm_pk_msm_pieces",
     "pm_comm_rccl_unique_id", "pm_comm_rccl_create", "pm_comm_local_create", "pm_comm_from_callbacks", "pm_comm_destroy", "pm_comm_rank",
     "pm_comm_world", "pm_comm_last_error", "pm_comm_busy_ms", "pm_host_make_vk", "pm_host_verify", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
@@ -112,6 +112,7 @@ def load_library():
     L.pm_host_keccak_f1600.argtypes = [u64p]
     L.pm_host_keccak_f1600.restype = None
     L.pm_synth_r1cs.argtypes = [i, u64, u64, u64p, u32p, u64p, u32p, u64p, u32p, u64p, u64p]
+    L.pm_selftest_field.argtypes = [vp, sz, u64, u64p]
     L.pm_pk_load_sharded.argtypes = [vp, i, u64, u64, u64, u64, u64, ct.POINTER(PmCsr), ct.POINTER(PmCsr), ct.POINTER(PmCsr),
                                      ct.POINTER(PmBaseArray), i, i, i, ct.POINTER(vp)]
     L.pm_pk_generate_sharded.argtypes = [vp, i, u64, u64, u64, ct.POINTER(PmCsr), ct.POINTER(PmCsr), ct.POINTER(PmCsr), u64p,
@@ -306,6 +307,12 @@ class Context:
         """Join this context to its rank's communicator (needed by PM_SHARD_VECTOR keys)."""
         self.comm = comm
         self.check(self.L.pm_ctx_set_comm(self.h, comm.h if comm is not None else None))
+
+    def selftest_field(self, products_per_field=4096, seed=1):
+        """pm_selftest_field: the device's field products vs the host's CIOS -> mismatch counts {field: n} (all zero when healthy)."""
+        bad = (ct.c_uint64 * 4)()
+        self.check(self.L.pm_selftest_field(self.h, products_per_field, seed, bad))
+        return dict(zip(("bls12_381_fr", "bn254_fr", "bls12_381_fq", "bn254_fq"), (int(v) for v in bad)))
 
     def timings(self):
         arr = (ct.c_double * len(TIMING_SLOTS))()

@@ -170,16 +170,16 @@ PM_HD Fp<P> mul_cios(const Fp<P> &a, const Fp<P> &b) {
     return r;
 }
 
-// The same product a b 2^(-32 N) mod p, same canonical result, computed on 28-bit limbs: a 64-bit accumulator of
-// v_mad_u64_u32 absorbs a whole column of 28 x 28-bit products, so there is no carry chain inside the loop
-// (fq28.cuh uses the idea with its own radix; here the radix stays the dense one, 2^(32 N)).  L = ceil(32 N / 28)
-// limbs; L - 1 full Montgomery steps of 28 bits and one partial step of TAIL = 32 N - 28 (L - 1) bits (4 for the
-// 256-bit fields, 20 for BLS12-381 Fq), then a TAIL-bit right shift.  8 limbs: ~385 instructions instead of ~600.
+// The same product a b 2^(-32 N) mod p, same canonical result, computed on W-bit limbs (Radix28<P>::RR: W = 28, or 29 for the
+// 254/255-bit scalar fields = 9 limbs): a 64-bit accumulator of v_mad_u64_u32 absorbs a whole column of W x W-bit products
+// (2 L 2^(2W) < 2^64), so there is no carry chain inside the loop (fq28.cuh uses the idea with its own radix; here the radix
+// stays the dense one, 2^(32 N)).  L - 1 full Montgomery steps of W bits and one partial step of TAIL = 32 N - W (L - 1) bits
+// (24 for the scalar fields, 20 for BLS12-381 Fq), then a TAIL-bit right shift.
 template <class P>
 PM_HD Fp<P> mul_r28(const Fp<P> &a, const Fp<P> &b) {
     typedef typename Radix28<P>::RR RR;
-    constexpr int N = P::N, L = RR::N, W = 28, TAIL = 32 * N - W * (L - 1);
-    static_assert(TAIL > 0 && TAIL <= W && RR::W == W, "28-bit limb layout");
+    constexpr int N = P::N, L = RR::N, W = RR::W, TAIL = 32 * N - W * (L - 1);
+    static_assert(TAIL > 0 && TAIL <= W && 2 * W + 5 <= 63 && 2 * L <= 32, "limb layout: 2 L products of 2 W bits per 64-bit column");
     constexpr uint32_t MASK = RR::MASK;
     uint32_t A[L], B[L];
 #pragma unroll
@@ -194,7 +194,7 @@ PM_HD Fp<P> mul_r28(const Fp<P> &a, const Fp<P> &b) {
 #pragma unroll
     for (int j = 0; j < L; ++j) acc[j] = 0;
 #pragma unroll
-    for (int i = 0; i < L - 1; ++i) {   // full steps: divide by 2^28 each
+    for (int i = 0; i < L - 1; ++i) {   // full steps: divide by 2^W each
         const uint32_t bi = B[i];
 #pragma unroll
         for (int j = 0; j < L; ++j) acc[j] += (uint64_t)A[j] * bi;
@@ -211,7 +211,14 @@ PM_HD Fp<P> mul_r28(const Fp<P> &a, const Fp<P> &b) {
         const uint32_t bi = B[L - 1];
 #pragma unroll
         for (int j = 0; j < L; ++j) acc[j] += (uint64_t)A[j] * bi;
-        const uint32_t m = ((uint32_t)acc[0] * RR::INV) & ((1u << TAIL) - 1u);
+        uint32_t m = ((uint32_t)acc[0] * RR::INV) & ((1u << TAIL) - 1u);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // TAIL = 24 (9 limbs of 29 bits) makes m a known-24-bit value: hipcc (ROCm 7.2) then forms a 24-bit multiply with the top
+        // limb of p, drops the mask as redundant for it, and fuses the product into v_mad_u64_u32 -- which does not truncate its
+        // operands (seen in the ISA: the unmasked -acc[0] times MOD[8]; 4 081 of 4 096 random products wrong on the device, none
+        // on the host).  Keeping the masked value opaque makes the compiler multiply the register it was given.
+        asm volatile("" : "+v"(m));
+#endif
 #pragma unroll
         for (int j = 0; j < L; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
     }
@@ -237,7 +244,7 @@ PM_HD Fp<P> mul_r28(const Fp<P> &a, const Fp<P> &b) {
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         const uint32_t v = r28[j] - RR::MOD[j] - borrow;
-        borrow = v >> 31;               // limbs < 2^28 (top: < 2^29): a negative difference sets bit 31
+        borrow = v >> 31;               // limbs < 2^W <= 2^29: a negative difference sets bit 31
         d28[j] = v & MASK;
     }
 #pragma unroll

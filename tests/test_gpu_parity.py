@@ -620,3 +620,11 @@ def test_setup_and_prove_with_the_reference_rng_signature(oracle):
     ref = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, T.make_transcripts(c)["merlin"])
     assert proof.as_dict() == ref
     pk.free()
+
+
+def test_device_field_products_match_host_cios(gpu_ctx):
+    """pm_selftest_field: 2 x 4096 + edge products and squares per field on the device -- the dense reduced-radix product every
+    kernel multiplies with (field.cuh: mul_r28, 9 x 29-bit limbs for the scalar fields) and the internal-radix product of the MSM /
+    NTT inner loops (fq28.cuh) -- against the host's 32-bit CIOS, word for word.  (The arithmetic the reference takes from
+    ark-ff, Cargo.toml:14; a compiler that drops a digit mask shows up here and not only as a wrong proof.)"""
+    assert gpu_ctx.selftest_field(4096, seed=20260101) == {"bls12_381_fr": 0, "bn254_fr": 0, "bls12_381_fq": 0, "bn254_fq": 0}
