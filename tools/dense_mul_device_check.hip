@@ -1,6 +1,6 @@
 #include <cstdio>
 #include <hip/hip_runtime.h>
-#include "../polymath_amd/csrc/field.cuh"
+#include "../polymath_amd/csrc/field.cuh"   // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -o tools/dense_mul_device_check tools/dense_mul_device_check.hip
 using namespace pm;
 template <class P>
 __global__ void k_only(const Fp<P> *a, const Fp<P> *b, Fp<P> *r1, int n) {
