@@ -628,3 +628,50 @@ def test_device_field_products_match_host_cios(gpu_ctx):
     NTT inner loops (fq28.cuh) -- against the host's 32-bit CIOS, word for word.  (The arithmetic the reference takes from
     ark-ff, Cargo.toml:14; a compiler that drops a digit mask shows up here and not only as a wrong proof.)"""
     assert gpu_ctx.selftest_field(4096, seed=20260101) == {"bls12_381_fr": 0, "bn254_fr": 0, "bls12_381_fq": 0, "bn254_fq": 0}
+
+
+@pytest.mark.parametrize("curve", CURVE_LIST)
+@pytest.mark.parametrize("log_n", [11, 13, 18, 19])
+def test_ntt_extreme_inputs_vs_oracle(gpu_ctx, oracle, curve, log_n):
+    """The reduced-radix tile kernels carry lazily (ntt.hip: values up to 37p, limbs up to 2^29 + 2^30 between carry
+    propagations): inputs that push every butterfly to the top of its range -- all p - 1, p - 1 / 0 / 1 patterns, one spike --
+    must still come out canonical and equal to the oracle's transform (prover.rs:241,319,325 call sites), both directions.
+    11 = one 6- and one 5-stage pass, 13 = 7 + 6, 18 = two 9-stage passes, 19 = 7 + 6 + 6."""
+    r = CURVES[curve].r
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    pats = [
+        [r - 1] * n,
+        [(r - 1) if (i & 1) else 0 for i in range(n)],
+        [(r - 1) if (i % 3 == 0) else 1 for i in range(n)],
+        [r - 1 - int(v) for v in rng.integers(0, 4, size=n)],
+        [0] * (n - 1) + [r - 1],
+    ]
+    for vals in pats:
+        a = oracle.fr_to_mont_limbs(curve, vals)
+        for inverse in (False, True):
+            assert np.array_equal(gpu_ctx.ntt(curve, a, log_n, inverse), oracle.ntt(curve, a, log_n, inverse, 8)), (log_n, inverse)
+
+
+@pytest.mark.parametrize("curve", CURVE_LIST)
+def test_msm_extreme_scalar_patterns(gpu_ctx, oracle, api, curve):
+    """Scalars that sit on the signed-digit boundaries of every window layout (digit = 2^(c-1), 2^(c-1) + 1, all ones, carries
+    rippling through every window, p - 1, (p +- 1) / 2, powers of two and their predecessors), on the per-window pipeline and
+    on the window tables: the same point as the CPU oracle's MSM (prover.rs:380-384 call site)."""
+    r = CURVES[curve].r
+    pats = [r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, 1, 2, 0]
+    pats += [int("5" * 64, 16) % r, int("a" * 64, 16) % r, int("7f" * 32, 16) % r, int("80" * 32, 16) % r, int("f" * 63, 16) % r]
+    for c in (15, 16, 20, 21, 22):                         # every digit exactly half / half + 1 for window width c
+        pats += [sum(1 << (c * w + c - 1) for w in range(256 // c)) % r, sum((1 << (c - 1)) + 1 << (c * w) for w in range(256 // c)) % r]
+    pats += [(1 << k) % r for k in range(0, 255, 7)] + [((1 << k) - 1) % r for k in range(1, 255, 7)]
+    n = 4096
+    vals = [pats[i % len(pats)] for i in range(n)]
+    bases = api.Bases.multiples(gpu_ctx, curve, n)
+    hb = bases.download()
+    sc = oracle.fr_to_mont_limbs(curve, vals)
+    ref, rinf = oracle.msm(curve, hb, sc, 8)
+    plain, inf = bases.msm(sc)
+    assert inf == rinf and np.array_equal(plain, ref)
+    bases.precompute()
+    tabled, inf = bases.msm(sc)
+    assert inf == rinf and np.array_equal(tabled, ref)
