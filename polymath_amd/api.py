@@ -269,6 +269,13 @@ class Comm:
             raise PolymathError(st, self.L.pm_comm_last_error(self.h).decode())
         return out
 
+    def all_to_all_device(self, d_send, d_recv, bytes_per_peer, stream=None):
+        """pm_comm_all_to_all on device pointers: block p of d_send goes to rank p, block r of d_recv comes from rank r
+        (enqueued on `stream`; the caller synchronises)."""
+        st = self.L.pm_comm_all_to_all(self.h, ct.c_void_p(d_send), ct.c_void_p(d_recv), bytes_per_peer, ct.c_void_p(stream or 0))
+        if st:
+            raise PolymathError(st, self.L.pm_comm_last_error(self.h).decode())
+
     def close(self):
         """pm_comm_destroy.  Detach it from its contexts first (Context.set_comm(None)): a context does not own its comm."""
         if getattr(self, "h", None):

@@ -163,6 +163,16 @@ def make_comm(rank, world, device, native=True):
                 comm = api.Comm.rccl(box[0], rank, world, device)
                 probe = comm.all_gather(np.array([rank], dtype=np.int64))
                 ok = probe.reshape(-1).tolist() == list(range(world))
+                if ok:
+                    # the transforms rely on the block order of the all-to-all (block p -> rank p, block r <- rank r): check it
+                    # on this fabric once, with 64-byte blocks tagged (sender, receiver), before a prover depends on it
+                    dev = torch.device("cuda", device)
+                    send = torch.tensor([[rank * world + p] * 8 for p in range(world)], dtype=torch.int64, device=dev).reshape(-1)
+                    recv = torch.full_like(send, -1)
+                    torch.cuda.synchronize(dev)
+                    comm.all_to_all_device(send.data_ptr(), recv.data_ptr(), 64, torch.cuda.current_stream(dev).cuda_stream)
+                    torch.cuda.synchronize(dev)
+                    ok = recv.cpu().reshape(world, 8)[:, 0].tolist() == [r * world + rank for r in range(world)]
             except Exception:   # noqa: BLE001
                 ok = False
             if all_ok(ok):

@@ -229,6 +229,36 @@ def test_vector_sharded_mid_size_and_pairs_layout_agree():
     assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a)))
 
 
+
+class _Hip:
+    """Device buffers for the exchange tests through the HIP runtime the library itself runs on (ctypes).  Not torch: torch ships
+    its own HIP runtime and librccl, and bringing its GPU side up AFTER the library has used the system runtime in the same
+    process fails ("No HIP GPUs are available"); bench.py and the tools initialise torch first, a test process cannot."""
+
+    def __init__(self):
+        import ctypes as ct
+        self.ct = ct
+        self.lib = ct.CDLL("libamdhip64.so")
+        self.lib.hipMalloc.argtypes = [ct.POINTER(ct.c_void_p), ct.c_size_t]
+        self.lib.hipFree.argtypes = [ct.c_void_p]
+        self.lib.hipMemcpy.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int]
+
+    def upload(self, arr):
+        p = self.ct.c_void_p()
+        assert self.lib.hipMalloc(self.ct.byref(p), arr.nbytes) == 0
+        assert self.lib.hipMemcpy(p, arr.ctypes.data_as(self.ct.c_void_p), arr.nbytes, 1) == 0
+        return p
+
+    def download(self, p, like):
+        out = np.empty_like(like)
+        assert self.lib.hipDeviceSynchronize() == 0
+        assert self.lib.hipMemcpy(out.ctypes.data_as(self.ct.c_void_p), p, out.nbytes, 2) == 0
+        return out
+
+    def free(self, *ps):
+        for p in ps:
+            self.lib.hipFree(p)
+
 @pytest.mark.gpu
 def test_rccl_comm_world_of_one():
     """The RCCL implementation of pm_comm (librccl dlopen'ed by the library, ncclCommInitRank / ncclAllToAll / ncclAllGather)
@@ -241,6 +271,12 @@ def test_rccl_comm_world_of_one():
     comm = api.Comm.rccl(api.Comm.rccl_unique_id(), 0, 1, 0)
     assert (comm.rank, comm.world) == (0, 1)
     assert comm.all_gather(np.arange(5, dtype=np.int64)).tolist() == [[0, 1, 2, 3, 4]]
+    hip = _Hip()
+    src = np.arange(64, dtype=np.int64)
+    d_send, d_recv = hip.upload(src), hip.upload(np.full(64, -1, dtype=np.int64))
+    comm.all_to_all_device(d_send.value, d_recv.value, src.nbytes)       # ncclAllToAll with one peer: block 0 -> rank 0
+    assert np.array_equal(hip.download(d_recv, src), src)
+    hip.free(d_send, d_recv)
     lc = PC.synthetic_r1cs_native(curve, 3000)
     ref_pm = Polymath(curve, "merlin", device=0)
     ref_pk = ref_pm.setup(lc, 11, 13)
@@ -443,3 +479,35 @@ def test_vector_sharded_reference_bench_circuit_skew():
     for pk in pks:
         pk.free()
     ref_pk.free()
+
+
+@pytest.mark.gpu
+def test_all_to_all_block_order_local_group():
+    """The block order every pm_comm implementation must have, and the one distributed.make_comm probes an RCCL communicator
+    for before a prover depends on it: block p of the send buffer goes to rank p, block r of the receive buffer comes from
+    rank r.  Here: the in-process group (4 rank threads on one GPU), 64-byte blocks tagged (sender, receiver)."""
+    import threading
+    from polymath_amd import api
+    N = 4
+    comms = api.Comm.local_group(N)
+    hip = _Hip()
+    got, errs = [None] * N, []
+
+    def rank_main(r):
+        try:
+            src = np.repeat(np.arange(r * N, r * N + N, dtype=np.int64), 8)
+            d_send, d_recv = hip.upload(src), hip.upload(np.full(8 * N, -1, dtype=np.int64))
+            comms[r].all_to_all_device(d_send.value, d_recv.value, 64)
+            got[r] = hip.download(d_recv, src).reshape(N, 8)[:, 0].tolist()
+            hip.free(d_send, d_recv)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(N)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    assert got == [[q * N + r for q in range(N)] for r in range(N)]
+    for c in comms:
+        c.close()
