@@ -974,6 +974,176 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
 }
 
+// ---------------------------------------------------------------------------------- lane pairs
+// Levels 1 and the final sum are chains of DEPENDENT point operations on a chip that is at most a quarter full, so what counts is
+// the latency of one operation, and a point addition is 12 products + 2 squares of which only the critical path of 5 has to be
+// sequential.  Here lanes 2k and 2k + 1 hold the SAME point and each computes half of the products (role = lane & 1), swapping
+// field elements through DPP (quad_perm [1, 0, 3, 2]: a register move, no LDS):
+//   add:  role 0  U1, U2 | P, PP | PPP, Q       | X3, R QX, S1 (4p - PPP) -> Y3          6 M + 1 S per lane instead of 12 M + 2 S
+//         role 1  S1, S2 | R, RR | ZZ1 ZZ2, ZZZ1 ZZZ2 | ZZ3, ZZZ3
+//   dbl:  role 0  V = (2Y)^2 | W = 2Y V, S = X V | ZZ3 = V ZZ, ZZZ3 = W ZZZ               4 M + 1 S instead of 4.5 M + 3 S
+//         role 1  X^2 -> M   | M^2               | X3, M (S - X3), Y (4p - W) -> Y3
+// Both lanes run ONE instruction stream: operands are picked per role with v_cndmask, the role-specific limb arithmetic is executed
+// by both (on don't-care values in the other role).  Same formulas, bounds and invariants as xyzz28_add / xyzz28_dbl (X: W < 14p,
+// Y: W < 6p, ZZ, ZZZ: T); Y3 is the sum of two products here (tight + tight, then a carry propagation) instead of one fused one.
+template <class RR>
+__device__ __forceinline__ F28<RR> f28_partner(const F28<RR> &a) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xF, 0xF, true);
+    return r;
+}
+template <class RR>
+__device__ __forceinline__ F28<RR> f28_pick(bool c, const F28<RR> &a, const F28<RR> &b) {   // c ? a : b
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+__device__ __forceinline__ int pair_or(int v) { return v | __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+
+// a += b, both lanes of the pair hold (a, b); false: the exceptional case (same x), a untouched
+template <class C>
+__device__ __forceinline__ bool xyzz28_add_pair(XYZZ28<C> &a, const XYZZ28<C> &b, bool r1) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(b.ZZ)) return true;
+    if (f28_all_zero<RR>(a.ZZ)) { a = b; return true; }
+    const F T1 = f28_mul<RR>(f28_pick<RR>(r1, a.Y, a.X), f28_pick<RR>(r1, b.ZZZ, b.ZZ));     // U1 | S1          W x T -> T
+    const F T2 = f28_mul<RR>(f28_pick<RR>(r1, b.Y, b.X), f28_pick<RR>(r1, a.ZZZ, a.ZZ));     // U2 | S2
+    const F D = f28_sub_k4<RR>(T2, T1);                                                      // P  | R           L e<=1.6, < 6p
+    const F DD = f28_sqr<RR>(D);                                                             // PP | RR
+    if (pair_or(!r1 && f28_is_zero_mod_p<RR>(DD))) return false;
+    const F V1 = f28_mul<RR>(f28_pick<RR>(r1, a.ZZ, D), f28_pick<RR>(r1, b.ZZ, DD));         // PPP | ZZ1 ZZ2
+    const F V2 = f28_mul<RR>(f28_pick<RR>(r1, a.ZZZ, T1), f28_pick<RR>(r1, b.ZZZ, DD));      // Q = U1 PP | ZZZ1 ZZZ2
+    const F xD = f28_partner<RR>(D), xDD = f28_partner<RR>(DD), xV1 = f28_partner<RR>(V1), xT1 = f28_partner<RR>(T1);
+    // role 0 (role 1 runs it on don't-care values): X3 = RR - PPP - 2Q, QX = Q - X3, 4p - PPP
+    F X3 = f28_sub_k4<RR>(xDD, V1);
+    X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(X3, f28_add<RR>(V2, V2)));                         // W, < 14p
+    const F QX = f28_sub_k16<RR>(V2, X3);                                                    // L e<=1.6, < 18p
+    const F nPPP = f28_sub_k4<RR>(f28_zero<RR>(), V1);                                       // limbs < 2^29, < 4p
+    const F W1 = f28_mul<RR>(f28_pick<RR>(r1, V1, xD), f28_pick<RR>(r1, xDD, QX));           // R QX | ZZ3 = (ZZ1 ZZ2) PP
+    const F W2 = f28_mul<RR>(f28_pick<RR>(r1, V2, xT1), f28_pick<RR>(r1, xV1, nPPP));        // S1 (4p - PPP) | ZZZ3 = (ZZZ1 ZZZ2) PPP
+    const F Y3 = f28_weak_norm<RR>(f28_add<RR>(W1, W2));                                     // W, < 4p
+    const F pX = f28_partner<RR>(X3), pY = f28_partner<RR>(Y3), pW1 = f28_partner<RR>(W1), pW2 = f28_partner<RR>(W2);
+    a.X = f28_pick<RR>(r1, pX, X3);
+    a.Y = f28_pick<RR>(r1, pY, Y3);
+    a.ZZ = f28_pick<RR>(r1, W1, pW1);
+    a.ZZZ = f28_pick<RR>(r1, W2, pW2);
+    return true;
+}
+template <class C>
+__device__ __forceinline__ void xyzz28_add_pair_full(XYZZ28<C> &a, const XYZZ28<C> &b, bool r1) {
+    if (!xyzz28_add_pair<C>(a, b, r1)) a = xyzz28_add_exceptional<C>(a, b);     // both lanes, the same result
+}
+template <class C>
+__device__ __forceinline__ void xyzz28_dbl_pair(XYZZ28<C> &a, bool r1) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(a.ZZ)) return;
+    const F U = f28_add<RR>(a.Y, a.Y);                                          // limbs < 2^29, < 12p
+    const F A = f28_sqr<RR>(f28_pick<RR>(r1, a.X, U));                          // V = U^2 | X^2
+    const F M = f28_add<RR>(f28_add<RR>(A, A), A);                              // role 1: 3 X^2, limbs < 3 2^28, < 6p
+    const F B1 = f28_mul<RR>(f28_pick<RR>(r1, M, U), f28_pick<RR>(r1, M, A));   // W = U V | M^2
+    const F B2 = f28_mul<RR>(a.X, A);                                           // S = X V | (unused)
+    const F S = f28_partner<RR>(B2), Wv = f28_partner<RR>(B1);                  // role 1 receives S and W
+    // role 1: X3 = M^2 - 2S, SX = S - X3, 4p - W
+    const F X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(B1, f28_add<RR>(S, S)));      // W, < 10p
+    const F SX = f28_sub_k16<RR>(S, X3);                                        // L e<=1.6, < 18p
+    const F nW = f28_sub_k4<RR>(f28_zero<RR>(), Wv);
+    const F C1 = f28_mul<RR>(f28_pick<RR>(r1, M, A), f28_pick<RR>(r1, SX, a.ZZ));      // ZZ3 = V ZZ | M (S - X3)
+    const F C2 = f28_mul<RR>(f28_pick<RR>(r1, a.Y, B1), f28_pick<RR>(r1, nW, a.ZZZ));  // ZZZ3 = W ZZZ | Y (4p - W)
+    const F Y3 = f28_weak_norm<RR>(f28_add<RR>(C1, C2));                        // role 1: W, < 4p
+    const F pX = f28_partner<RR>(X3), pY = f28_partner<RR>(Y3), pC1 = f28_partner<RR>(C1), pC2 = f28_partner<RR>(C2);
+    a.X = f28_pick<RR>(r1, X3, pX);
+    a.Y = f28_pick<RR>(r1, Y3, pY);
+    a.ZZ = f28_pick<RR>(r1, pC1, C1);
+    a.ZZZ = f28_pick<RR>(r1, pC2, C2);
+}
+
+// sh[k], k < blockDim.x / 2: the value of lane pair k on entry (written by its role-0 lane); on exit sh[0] = the workgroup sum
+template <class C>
+__device__ __forceinline__ void lds_tree_sum_pair(XYZZ28<C> *sh) {
+    const unsigned k = threadIdx.x >> 1;
+    const bool r1 = threadIdx.x & 1;
+    __syncthreads();
+    for (unsigned off = blockDim.x >> 2; off > 0; off >>= 1) {
+        if (k < off) {
+            XYZZ28<C> a = sh[k];
+            xyzz28_add_pair_full<C>(a, sh[k + off], r1);
+            if (!r1) sh[k] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// k_reduce_level1 on lane pairs: pair j owns R level-0 outputs; t0 * run goes through the non-adjacent form of t0 (digits
+// +-1, no two adjacent: the lanes of a wave cover every pattern of the low bits, so what a wave pays is the weight of the HIGH
+// bits it shares -- at most half of them in this form -- plus one addition per low position).
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1_pair(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0,
+                                                                                                         unsigned K0, unsigned R, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1, t0 = j * R;
+    const bool r1 = threadIdx.x & 1;
+    XYZZ28<C> acc;
+    acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
+    if (t0 < lanes0) {
+        XYZZ28<C> run = acc;
+        for (int i = (int)R - 1; i >= 0; --i) {
+            if (t0 + i >= lanes0) continue;
+            xyzz28_add_pair_full<C>(run, xyzz28_load<C>(A[t0 + i]), r1);
+            if (i > 0) xyzz28_add_pair_full<C>(acc, run, r1);          // weight i
+        }
+        if (t0 && !f28_all_zero<RR>(run.ZZ)) {                         // acc += t0 * run
+            uint32_t pos = 0, neg = 0;
+            {
+                uint64_t x = t0;
+                for (unsigned b = 0; x; ++b, x >>= 1)
+                    if (x & 1) {
+                        if ((x & 3) == 3) { neg |= 1u << b; x += 1; } else { pos |= 1u << b; x -= 1; }
+                    }
+            }
+            XYZZ28<C> nrun = run;                                      // -run, Y back below 2p (one product by the radix)
+            nrun.Y = f28_mul<RR>(f28_sub_k16<RR>(f28_zero<RR>(), run.Y), f28_one<RR>());
+            XYZZ28<C> m = run;                                         // the leading digit of a positive number is +1
+            for (int b = 30 - __clz((int)(pos | neg)); b >= 0; --b) {
+                xyzz28_dbl_pair<C>(m, r1);
+                if (((pos | neg) >> b) & 1) {
+                    const bool ng = (neg >> b) & 1;
+                    XYZZ28<C> t = run;
+                    t.Y = f28_pick<RR>(ng, nrun.Y, run.Y);
+                    xyzz28_add_pair_full<C>(m, t, r1);
+                }
+            }
+            xyzz28_add_pair_full<C>(acc, m, r1);
+        }
+        for (unsigned k = 1; k < K0; k <<= 1) xyzz28_dbl_pair<C>(acc, r1);   // K0 is a power of two
+        for (unsigned i = 0; i < R; ++i)
+            if (t0 + i < lanes0) xyzz28_add_pair_full<C>(acc, xyzz28_load<C>(Acc[t0 + i]), r1);
+    }
+    if (!r1) sh[threadIdx.x >> 1] = acc;
+    lds_tree_sum_pair<C>(sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
+}
+
+// out[0] = sum of parts[0 .. count) by one workgroup of 128 lane pairs
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_sum_final_pair(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    const bool r1 = threadIdx.x & 1;
+    XYZZ28<C> acc;
+    acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
+    for (unsigned i = threadIdx.x >> 1; i < count; i += 128) xyzz28_add_pair_full<C>(acc, xyzz28_load<C>(parts[i]), r1);
+    if (!r1) sh[threadIdx.x >> 1] = acc;
+    lds_tree_sum_pair<C>(sh);
+    if (threadIdx.x == 0) out[0] = xyzz28_store<C>(sh[0]);
+}
+
 // out[0] = sum of parts[0 .. count) by one 256-lane workgroup
 template <class C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sum_final(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
@@ -1155,9 +1325,15 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     while (NB / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;   // (a lone wave issues a mad every ~11 cycles, two interleave at ~5.6;
                                                                //  swept in profiles/r02_levers.jsonl: K0 = 2 doubles level 1's work and loses)
     if (const char *e = getenv("PM_RED_K0")) K0 = (unsigned)atoi(e);        // developer knobs (powers of two)
-    unsigned R1 = 2;                                   // swept on MI355X (tools/sweep_reduce.sh): K0 = 16, R = 2 at 2^21 buckets
+    // levels 1 and final on lane PAIRS (two lanes per point, half the products each): 128 points per workgroup, and R = 4 keeps
+    // level 1 at 2^16 lanes = one wave per SIMD (its register budget).  PM_RED_PAIR=0: the one-lane kernels.
+    bool pair = true;
+    if (const char *e = getenv("PM_RED_PAIR")) pair = e[0] != '0';
+    unsigned R1 = pair ? 4 : 2;                        // swept on MI355X (tools/sweep_reduce.sh): K0 = 16, R = 2 at 2^21 buckets (one lane per point)
     if (const char *e = getenv("PM_RED_R")) R1 = (unsigned)atoi(e);
-    const size_t lanes0 = (NB + K0 - 1) / K0, lanes1 = (lanes0 + R1 - 1) / R1, blocks0 = (lanes0 + 255) / 256, blocks1 = (lanes1 + 255) / 256;
+    const unsigned per_block1 = pair ? 128 : 256;      // points per level-1 workgroup
+    const size_t lanes0 = (NB + K0 - 1) / K0, lanes1 = (lanes0 + R1 - 1) / R1, blocks0 = (lanes0 + 255) / 256,
+                 blocks1 = (lanes1 + per_block1 - 1) / per_block1;
     const unsigned red_lanes = (unsigned)((NB + RED_K - 1) / RED_K);              // single-level path (small NB)
     unsigned red_block = 64;
     while (red_block < red_lanes && red_block < 256) red_block <<= 1;
@@ -1276,10 +1452,17 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
                                ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), NB, lanes0, K0, A, Acc);
             PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_reduce_level1<C>, dim3((unsigned)blocks1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, A, Acc, lanes0,
-                               K0, R1, parts);
-            PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_sum_final<C>, dim3(1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+            if (pair) {
+                hipLaunchKernelGGL(k_reduce_level1_pair<C>, dim3((unsigned)blocks1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
+                                   lanes0, K0, R1, parts);
+                PM_HIP(ctx, hipGetLastError());
+                hipLaunchKernelGGL(k_sum_final_pair<C>, dim3(1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+            } else {
+                hipLaunchKernelGGL(k_reduce_level1<C>, dim3((unsigned)blocks1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, A, Acc, lanes0,
+                                   K0, R1, parts);
+                PM_HIP(ctx, hipGetLastError());
+                hipLaunchKernelGGL(k_sum_final<C>, dim3(1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+            }
         } else {
             hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
                                ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), (unsigned)NB, red_lanes, bpw, parts);
