@@ -1061,41 +1061,121 @@ __device__ __forceinline__ void xyzz28_dbl_pair(XYZZ28<C> &a, bool r1) {
     a.ZZZ = f28_pick<RR>(r1, pC2, C2);
 }
 
-// sh[k], k < blockDim.x / 2: the value of lane pair k on entry (written by its role-0 lane); on exit sh[0] = the workgroup sum
+// ---- four lanes per point: the critical path of an addition is 3M + 1S (U/S products | P^2, R^2 | PPP, Q, ZZ1 ZZ2, ZZZ1 ZZZ2 |
+// R QX, S1 (4p - PPP), ZZ3, ZZZ3), one product per lane and step; results travel by DPP quad broadcasts.  The cheap limb arithmetic
+// between the steps (X3, Q - X3, 4p - PPP) is done by all four lanes on broadcast values, so X3 needs no trip back.
+template <int CTRL, class RR>
+__device__ __forceinline__ F28<RR> f28_dpp(const F28<RR> &a) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xF, 0xF, true);
+    return r;
+}
+constexpr int QP_SWAP = 0xB1, QP_B0 = 0x00, QP_B1 = 0x55, QP_B2 = 0xAA, QP_B3 = 0xFF;   // quad_perm [1,0,3,2]; broadcast lane k
+
 template <class C>
-__device__ __forceinline__ void lds_tree_sum_pair(XYZZ28<C> *sh) {
-    const unsigned k = threadIdx.x >> 1;
-    const bool r1 = threadIdx.x & 1;
+__device__ __forceinline__ bool xyzz28_add_quad(XYZZ28<C> &a, const XYZZ28<C> &b, unsigned role) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(b.ZZ)) return true;
+    if (f28_all_zero<RR>(a.ZZ)) { a = b; return true; }
+    const bool b0 = role & 1, b1 = role & 2;
+    // lane 0: U1 = X1 ZZ2, lane 1: U2 = X2 ZZ1, lane 2: S1 = Y1 ZZZ2, lane 3: S2 = Y2 ZZZ1
+    const F T = f28_mul<RR>(f28_pick<RR>(b1, f28_pick<RR>(b0, b.Y, a.Y), f28_pick<RR>(b0, b.X, a.X)),
+                            f28_pick<RR>(b1, f28_pick<RR>(b0, a.ZZZ, b.ZZZ), f28_pick<RR>(b0, a.ZZ, b.ZZ)));
+    const F xT = f28_dpp<QP_SWAP, RR>(T);
+    const F lo = f28_pick<RR>(b0, xT, T);                                   // U1 (lanes 0, 1) | S1 (lanes 2, 3)
+    const F D = f28_sub_k4<RR>(f28_pick<RR>(b0, T, xT), lo);               // P | R                  L e<=1.6, < 6p
+    const F DD = f28_sqr<RR>(D);                                            // PP | RR
+    if (__builtin_amdgcn_update_dpp(0, (int)f28_is_zero_mod_p<RR>(DD), QP_B0, 0xF, 0xF, true)) return false;
+    // lane 0: PPP = P PP, lane 1: Q = U1 PP, lane 2: ZZ1 ZZ2, lane 3: ZZZ1 ZZZ2
+    const F V = f28_mul<RR>(f28_pick<RR>(b1, f28_pick<RR>(b0, a.ZZZ, a.ZZ), f28_pick<RR>(b0, lo, D)),
+                            f28_pick<RR>(b1, f28_pick<RR>(b0, b.ZZZ, b.ZZ), DD));
+    const F PPP = f28_dpp<QP_B0, RR>(V), Q = f28_dpp<QP_B1, RR>(V), PP = f28_dpp<QP_B0, RR>(DD), RR2 = f28_dpp<QP_B2, RR>(DD);
+    const F Rv = f28_dpp<QP_B2, RR>(D), S1 = f28_dpp<QP_B2, RR>(lo);
+    F X3 = f28_sub_k4<RR>(RR2, PPP);
+    X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(X3, f28_add<RR>(Q, Q)));          // W, < 14p
+    const F QX = f28_sub_k16<RR>(Q, X3);                                    // L e<=1.6, < 18p
+    const F nPPP = f28_sub_k4<RR>(f28_zero<RR>(), PPP);                     // limbs < 2^29, < 4p
+    // lane 0: R QX, lane 1: S1 (4p - PPP), lane 2: ZZ3 = (ZZ1 ZZ2) PP, lane 3: ZZZ3 = (ZZZ1 ZZZ2) PPP
+    const F W = f28_mul<RR>(f28_pick<RR>(b1, V, f28_pick<RR>(b0, S1, Rv)),
+                            f28_pick<RR>(b1, f28_pick<RR>(b0, PPP, PP), f28_pick<RR>(b0, nPPP, QX)));
+    a.X = X3;
+    a.Y = f28_weak_norm<RR>(f28_add<RR>(f28_dpp<QP_B0, RR>(W), f28_dpp<QP_B1, RR>(W)));   // W, < 4p
+    a.ZZ = f28_dpp<QP_B2, RR>(W);
+    a.ZZZ = f28_dpp<QP_B3, RR>(W);
+    return true;
+}
+template <class C>
+__device__ __forceinline__ void xyzz28_dbl_quad(XYZZ28<C> &a, unsigned role) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(a.ZZ)) return;
+    const bool b0 = role & 1, b1 = role & 2;
+    const F U = f28_add<RR>(a.Y, a.Y);                                      // limbs < 2^29, < 12p
+    const F A = f28_sqr<RR>(f28_pick<RR>(b0, a.X, U));                      // lanes 0, 2: V = U^2 | lanes 1, 3: X^2
+    const F M = f28_add<RR>(f28_add<RR>(A, A), A);                          // lanes 1, 3: 3 X^2, limbs < 3 2^28, < 6p
+    const F V = f28_dpp<QP_B0, RR>(A);
+    // lane 0: W = U V, lane 1: M^2, lane 2: S = X V, lane 3: M^2 (again)
+    const F B = f28_mul<RR>(f28_pick<RR>(b0, M, f28_pick<RR>(b1, a.X, U)), f28_pick<RR>(b0, M, V));
+    const F Wv = f28_dpp<QP_B0, RR>(B), MM = f28_dpp<QP_B1, RR>(B), S = f28_dpp<QP_B2, RR>(B);
+    const F X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(MM, f28_add<RR>(S, S)));  // W, < 10p
+    const F SX = f28_sub_k16<RR>(S, X3);                                    // L e<=1.6, < 18p
+    const F nW = f28_sub_k4<RR>(f28_zero<RR>(), Wv);
+    // lane 0: ZZ3 = V ZZ, lane 1: M (S - X3), lane 2: ZZZ3 = W ZZZ, lane 3: Y (4p - W)
+    const F Cc = f28_mul<RR>(f28_pick<RR>(b1, f28_pick<RR>(b0, a.Y, Wv), f28_pick<RR>(b0, M, V)),
+                             f28_pick<RR>(b1, f28_pick<RR>(b0, nW, a.ZZZ), f28_pick<RR>(b0, SX, a.ZZ)));
+    a.X = X3;
+    a.Y = f28_weak_norm<RR>(f28_add<RR>(f28_dpp<QP_B1, RR>(Cc), f28_dpp<QP_B3, RR>(Cc)));   // W, < 4p
+    a.ZZ = f28_dpp<QP_B0, RR>(Cc);
+    a.ZZZ = f28_dpp<QP_B2, RR>(Cc);
+}
+
+// one interface for the kernels: LP lanes per point (2 or 4), role = lane % LP
+template <class C, unsigned LP>
+__device__ __forceinline__ void xyzz28_add_coop(XYZZ28<C> &a, const XYZZ28<C> &b, unsigned role) {
+    const bool ok = LP == 2 ? xyzz28_add_pair<C>(a, b, role & 1) : xyzz28_add_quad<C>(a, b, role);
+    if (!ok) a = xyzz28_add_exceptional<C>(a, b);     // every lane of the group, the same result
+}
+template <class C, unsigned LP>
+__device__ __forceinline__ void xyzz28_dbl_coop(XYZZ28<C> &a, unsigned role) {
+    if (LP == 2) xyzz28_dbl_pair<C>(a, role & 1); else xyzz28_dbl_quad<C>(a, role);
+}
+
+// sh[k], k < blockDim.x / LP: the value of lane group k on entry (written by its role-0 lane); on exit sh[0] = the workgroup sum
+template <class C, unsigned LP>
+__device__ __forceinline__ void lds_tree_sum_coop(XYZZ28<C> *sh) {
+    const unsigned k = threadIdx.x / LP, role = threadIdx.x % LP;
     __syncthreads();
-    for (unsigned off = blockDim.x >> 2; off > 0; off >>= 1) {
+    for (unsigned off = blockDim.x / LP / 2; off > 0; off >>= 1) {
         if (k < off) {
             XYZZ28<C> a = sh[k];
-            xyzz28_add_pair_full<C>(a, sh[k + off], r1);
-            if (!r1) sh[k] = a;
+            xyzz28_add_coop<C, LP>(a, sh[k + off], role);
+            if (!role) sh[k] = a;
         }
         __syncthreads();
     }
 }
 
-// k_reduce_level1 on lane pairs: pair j owns R level-0 outputs; t0 * run goes through the non-adjacent form of t0 (digits
+// k_reduce_level1 on lane groups: group j owns R level-0 outputs; t0 * run goes through the non-adjacent form of t0 (digits
 // +-1, no two adjacent: the lanes of a wave cover every pattern of the low bits, so what a wave pays is the weight of the HIGH
 // bits it shares -- at most half of them in this form -- plus one addition per low position).
-template <class C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1_pair(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0,
+template <class C, unsigned LP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1_coop(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0,
                                                                                                          unsigned K0, unsigned R, XYZZ<C> *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
     typedef typename C::FqRR RR;
-    const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1, t0 = j * R;
-    const bool r1 = threadIdx.x & 1;
+    const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LP, t0 = j * R;
+    const unsigned role = threadIdx.x % LP;
     XYZZ28<C> acc;
     acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
     if (t0 < lanes0) {
         XYZZ28<C> run = acc;
         for (int i = (int)R - 1; i >= 0; --i) {
             if (t0 + i >= lanes0) continue;
-            xyzz28_add_pair_full<C>(run, xyzz28_load<C>(A[t0 + i]), r1);
-            if (i > 0) xyzz28_add_pair_full<C>(acc, run, r1);          // weight i
+            xyzz28_add_coop<C, LP>(run, xyzz28_load<C>(A[t0 + i]), role);
+            if (i > 0) xyzz28_add_coop<C, LP>(acc, run, role);          // weight i
         }
         if (t0 && !f28_all_zero<RR>(run.ZZ)) {                         // acc += t0 * run
             uint32_t pos = 0, neg = 0;
@@ -1106,41 +1186,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         if ((x & 3) == 3) { neg |= 1u << b; x += 1; } else { pos |= 1u << b; x -= 1; }
                     }
             }
-            XYZZ28<C> nrun = run;                                      // -run, Y back below 2p (one product by the radix)
-            nrun.Y = f28_mul<RR>(f28_sub_k16<RR>(f28_zero<RR>(), run.Y), f28_one<RR>());
+            // -run: Y back below 2p (one product by the radix)
+            const F28<RR> nY = f28_mul<RR>(f28_sub_k16<RR>(f28_zero<RR>(), run.Y), f28_one<RR>());
             XYZZ28<C> m = run;                                         // the leading digit of a positive number is +1
             for (int b = 30 - __clz((int)(pos | neg)); b >= 0; --b) {
-                xyzz28_dbl_pair<C>(m, r1);
+                xyzz28_dbl_coop<C, LP>(m, role);
                 if (((pos | neg) >> b) & 1) {
-                    const bool ng = (neg >> b) & 1;
                     XYZZ28<C> t = run;
-                    t.Y = f28_pick<RR>(ng, nrun.Y, run.Y);
-                    xyzz28_add_pair_full<C>(m, t, r1);
+                    t.Y = f28_pick<RR>((neg >> b) & 1, nY, run.Y);
+                    xyzz28_add_coop<C, LP>(m, t, role);
                 }
             }
-            xyzz28_add_pair_full<C>(acc, m, r1);
+            xyzz28_add_coop<C, LP>(acc, m, role);
         }
-        for (unsigned k = 1; k < K0; k <<= 1) xyzz28_dbl_pair<C>(acc, r1);   // K0 is a power of two
+        for (unsigned k = 1; k < K0; k <<= 1) xyzz28_dbl_coop<C, LP>(acc, role);   // K0 is a power of two
         for (unsigned i = 0; i < R; ++i)
-            if (t0 + i < lanes0) xyzz28_add_pair_full<C>(acc, xyzz28_load<C>(Acc[t0 + i]), r1);
+            if (t0 + i < lanes0) xyzz28_add_coop<C, LP>(acc, xyzz28_load<C>(Acc[t0 + i]), role);
     }
-    if (!r1) sh[threadIdx.x >> 1] = acc;
-    lds_tree_sum_pair<C>(sh);
+    if (!role) sh[threadIdx.x / LP] = acc;
+    lds_tree_sum_coop<C, LP>(sh);
     if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
 }
 
-// out[0] = sum of parts[0 .. count) by one workgroup of 128 lane pairs
-template <class C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_sum_final_pair(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
+// out[0] = sum of parts[0 .. count) by one workgroup of 256 / LP lane groups
+template <class C, unsigned LP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_sum_final_coop(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
     typedef typename C::FqRR RR;
-    const bool r1 = threadIdx.x & 1;
+    const unsigned role = threadIdx.x % LP;
     XYZZ28<C> acc;
     acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
-    for (unsigned i = threadIdx.x >> 1; i < count; i += 128) xyzz28_add_pair_full<C>(acc, xyzz28_load<C>(parts[i]), r1);
-    if (!r1) sh[threadIdx.x >> 1] = acc;
-    lds_tree_sum_pair<C>(sh);
+    for (unsigned i = threadIdx.x / LP; i < count; i += 256 / LP) xyzz28_add_coop<C, LP>(acc, xyzz28_load<C>(parts[i]), role);
+    if (!role) sh[threadIdx.x / LP] = acc;
+    lds_tree_sum_coop<C, LP>(sh);
     if (threadIdx.x == 0) out[0] = xyzz28_store<C>(sh[0]);
 }
 
@@ -1325,13 +1404,13 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     while (NB / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;   // (a lone wave issues a mad every ~11 cycles, two interleave at ~5.6;
                                                                //  swept in profiles/r02_levers.jsonl: K0 = 2 doubles level 1's work and loses)
     if (const char *e = getenv("PM_RED_K0")) K0 = (unsigned)atoi(e);        // developer knobs (powers of two)
-    // levels 1 and final on lane PAIRS (two lanes per point, half the products each): 128 points per workgroup, and R = 4 keeps
-    // level 1 at 2^16 lanes = one wave per SIMD (its register budget).  PM_RED_PAIR=0: the one-lane kernels.
-    bool pair = true;
-    if (const char *e = getenv("PM_RED_PAIR")) pair = e[0] != '0';
-    unsigned R1 = pair ? 4 : 2;                        // swept on MI355X (tools/sweep_reduce.sh): K0 = 16, R = 2 at 2^21 buckets (one lane per point)
+    // levels 1 and final on lane GROUPS (2 or 4 lanes per point, a share of the products each): 256 / LP points per workgroup, and
+    // R = 2 LP keeps level 1 at 2^16 lanes = one wave per SIMD (its register budget).  PM_RED_PAIR = 0: one lane per point, 2: pairs.
+    unsigned coop = 4;
+    if (const char *e = getenv("PM_RED_PAIR")) coop = e[0] == '0' ? 0u : e[0] == '2' ? 2u : 4u;
+    unsigned R1 = coop ? 2 * coop : 2;                 // swept on MI355X (tools/sweep_reduce.sh, profiles/r02_m_reduce_pair_sweep.txt)
     if (const char *e = getenv("PM_RED_R")) R1 = (unsigned)atoi(e);
-    const unsigned per_block1 = pair ? 128 : 256;      // points per level-1 workgroup
+    const unsigned per_block1 = coop ? 256 / coop : 256;      // points per level-1 workgroup
     const size_t lanes0 = (NB + K0 - 1) / K0, lanes1 = (lanes0 + R1 - 1) / R1, blocks0 = (lanes0 + 255) / 256,
                  blocks1 = (lanes1 + per_block1 - 1) / per_block1;
     const unsigned red_lanes = (unsigned)((NB + RED_K - 1) / RED_K);              // single-level path (small NB)
@@ -1452,11 +1531,16 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
                                ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), NB, lanes0, K0, A, Acc);
             PM_HIP(ctx, hipGetLastError());
-            if (pair) {
-                hipLaunchKernelGGL(k_reduce_level1_pair<C>, dim3((unsigned)blocks1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
+            if (coop == 4) {
+                hipLaunchKernelGGL((k_reduce_level1_coop<C, 4>), dim3((unsigned)blocks1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
                                    lanes0, K0, R1, parts);
                 PM_HIP(ctx, hipGetLastError());
-                hipLaunchKernelGGL(k_sum_final_pair<C>, dim3(1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+                hipLaunchKernelGGL((k_sum_final_coop<C, 4>), dim3(1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+            } else if (coop == 2) {
+                hipLaunchKernelGGL((k_reduce_level1_coop<C, 2>), dim3((unsigned)blocks1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
+                                   lanes0, K0, R1, parts);
+                PM_HIP(ctx, hipGetLastError());
+                hipLaunchKernelGGL((k_sum_final_coop<C, 2>), dim3(1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
             } else {
                 hipLaunchKernelGGL(k_reduce_level1<C>, dim3((unsigned)blocks1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, A, Acc, lanes0,
                                    K0, R1, parts);
