@@ -324,9 +324,9 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
         if ((double)nwin * (double)resident_points >= 2147483648.0) continue;
         const double E = (double)nwin * (double)total_pairs, NB = (double)((size_t)1 << (t.c - 1));
         const double acc = std::max(E, E / NB * 135e3);
-        // bucket reduction + the sort's fixed part, in units of one accumulated entry (0.142 ns): the lane-pair reduction measures
-        // 0.76 ms at 2^19 buckets and 1.50 ms at 2^21 (profiles/r02_m_reduce_pair_sweep.txt) = 3.6e6 + 3.3 NB, plus ~0.4e6 of sort launches
-        double cost = acc + (double)n_msm * (4.0e6 + 3.3 * NB);
+        // bucket reduction + the sort's fixed part, in units of one accumulated entry (0.142 ns): the four-lane reduction measures
+        // 0.66 ms at 2^19 buckets and 1.39 ms at 2^21 (profiles/r02_m_reduce_pair_sweep.txt) = 2.9e6 + 3.3 NB, plus ~0.4e6 of sort launches
+        double cost = acc + (double)n_msm * (3.3e6 + 3.3 * NB);
         if (cost < best) { best = cost; best_t = t; }
     }
     if (const char *e = getenv("PM_TABLE_C")) {   // developer knob for tuning sweeps: widest window
