@@ -675,3 +675,23 @@ def test_msm_extreme_scalar_patterns(gpu_ctx, oracle, api, curve):
     bases.precompute()
     tabled, inf = bases.msm(sc)
     assert inf == rinf and np.array_equal(tabled, ref)
+
+
+@pytest.mark.parametrize("curve", CURVE_LIST)
+def test_msm_equal_bucket_sums_take_the_doubling_paths(gpu_ctx, oracle, api, curve, monkeypatch):
+    """Every base the SAME point and scalars 1 .. NB used equally often: every bucket of the table path holds the same sum, so
+    the reduction adds EQUAL points at every level -- the exceptional (doubling) branch of the one-lane additions of level 0 and
+    of the four-lane cooperative additions of levels 1 / final (msm.hip: xyzz28_add_quad returns false on every lane of the
+    quad, all four take the complete formulas).  Also with one scalar value only (all entries in one bucket: the hot-bucket
+    fold).  Same point as the CPU oracle's MSM."""
+    monkeypatch.setenv("PM_TABLE_C", "16")                 # 2^15 buckets: the two-level reduction (>= 4096 buckets)
+    n, nb = 1 << 17, 1 << 15
+    g = oracle.g1_multiples(curve, 1)
+    hb = np.repeat(g, n, axis=0)
+    bases = api.Bases.upload(gpu_ctx, curve, hb)
+    bases.precompute()
+    for vals in ([(i % nb) + 1 for i in range(n)], [5] * n, [(i % 2) * (nb - 1) + 1 for i in range(n)]):
+        sc = oracle.fr_to_mont_limbs(curve, vals)
+        out, inf = bases.msm(sc)
+        ref, rinf = oracle.msm(curve, hb, sc, 8)
+        assert inf == rinf and np.array_equal(out, ref)
