@@ -261,6 +261,11 @@ template <class C>
 int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len,
             Affine<C> *h_out, int *h_inf, const MsmTables *tables = nullptr);
 
+// msm_reduce.hip: the bucket reduction of the table-mode MSM (one set of NB >= 4096 buckets whose task partials sit in ctx->msm),
+// three launches on ctx->stream; *out = the sum sum_b (b + 1) B_b, internal form, inside the workspace.
+template <class C>
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out);
+
 // One bucket pipeline covers at most this many pairs (sorted-entry positions are u32: windows x pairs < 2^32); longer
 // MSMs run in pieces summed on the host.  2^27 in production; PM_MSM_MAX_PIECE_LOG (developer / test knob) lowers it
 // so that the piece-split path can be exercised at small sizes.

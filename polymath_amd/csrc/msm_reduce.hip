@@ -1,0 +1,397 @@
+// Table-mode bucket reduction (the window-table MSM of msm.hip: ONE set of NB >= 4096 buckets): levels 0 / 1 / final and the
+// lane-group point operations they run on.  A translation unit of its own: it is a third of msm.hip's compile time.
+#include "internal.h"
+#include "fq28.cuh"
+
+namespace pm {
+
+// sh[threadIdx.x] holds each lane's value on entry; on exit sh[0] holds the workgroup sum
+template <class C>
+__device__ __forceinline__ void lds_tree_sum(XYZZ28<C> *sh) {
+    __syncthreads();
+    for (unsigned off = blockDim.x >> 1; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const XYZZ28<C> b = sh[threadIdx.x + off];
+            xyzz28_add_into_full<C>(&sh[threadIdx.x], b);
+        }
+        __syncthreads();
+    }
+}
+
+// Table-mode bucket reduction  S = sum_b (b + 1) B_b  over ONE set of NB buckets.  Every step below is a
+// chain of DEPENDENT point additions (~21 us each on a lone wave), so the layout minimises chain length,
+// not work:
+//   level 0  lane t owns buckets [t K0, t K0 + K0):  A_t = sum B_b,  acc_t = sum (b - t K0 + 1) B_b
+//            (2 K0 adds; K0 is chosen so that NB / K0 ~ 2^17 lanes = one full round of the chip);
+//   level 1  lane j owns R level-0 outputs: running sums, (jR) * sum A by double-and-add, + acc_t; LDS tree
+//            per workgroup (2^15 lanes: a short chain on a quarter-full chip beats a full chip of scalar muls);
+//   final    one workgroup sums the level-1 partials.
+//   S = sum_t acc_t + sum_t (t K0) A_t.
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level0(const XYZZ<C> *partials, const uint32_t *task_off, const uint32_t *task_cnt, size_t nbuckets, size_t lanes,
+                                                       unsigned K0, XYZZ<C> *outA, XYZZ<C> *outAcc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= lanes) return;
+    XYZZ28<C> run;
+    run.X = run.Y = run.ZZ = run.ZZZ = f28_zero<RR>();
+    XYZZ28<C> *acc = &sh[threadIdx.x];     // the weighted accumulator lives in LDS (register pressure)
+    *acc = run;
+    for (int j = (int)K0 - 1; j >= 0; --j) {
+        const size_t g = t * K0 + (size_t)j;
+        if (g >= nbuckets) continue;
+        for (uint32_t q = task_off[g], qe = q + task_cnt[g]; q < qe; ++q) xyzz28_add_full<C>(run, xyzz28_load<C>(partials[q]));
+        xyzz28_add_into_full<C>(acc, run);
+    }
+    outA[t] = xyzz28_store<C>(run);
+    outAcc[t] = xyzz28_store<C>(*acc);
+}
+
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0, unsigned K0,
+                                                       unsigned R, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    // lane j owns level-0 outputs t in [jR, jR + R):  sum_t (t K0) A_t + acc_t
+    //   = K0 * (jR * sum_i A_{jR+i} + sum_i i A_{jR+i}) + sum_i acc_{jR+i}
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t0 = j * R;
+    XYZZ28<C> *acc = &sh[threadIdx.x];
+    acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
+    if (t0 < lanes0) {
+        XYZZ28<C> run = *acc;
+        for (int i = (int)R - 1; i >= 0; --i) {
+            if (t0 + i >= lanes0) continue;
+            xyzz28_add_full<C>(run, xyzz28_load<C>(A[t0 + i]));
+            if (i > 0) xyzz28_add_into_full<C>(acc, run);          // weight i
+        }
+        if (t0) {                                                    // acc += t0 * run
+            XYZZ28<C> m = run;
+            for (int b = 62 - __clzll((long long)t0); b >= 0; --b) {
+                xyzz28_dbl<C>(m);
+                if ((t0 >> b) & 1) xyzz28_add_full<C>(m, run);
+            }
+            xyzz28_add_into_full<C>(acc, m);
+        }
+        run = *acc;
+        for (unsigned k = 1; k < K0; k <<= 1) xyzz28_dbl<C>(run);  // K0 is a power of two
+        for (unsigned i = 0; i < R; ++i)
+            if (t0 + i < lanes0) xyzz28_add_full<C>(run, xyzz28_load<C>(Acc[t0 + i]));
+        *acc = run;
+    }
+    lds_tree_sum<C>(sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
+}
+
+// ---------------------------------------------------------------------------------- lane pairs
+// Levels 1 and the final sum are chains of DEPENDENT point operations on a chip that is at most a quarter full, so what counts is
+// the latency of one operation, and a point addition is 12 products + 2 squares of which only the critical path of 5 has to be
+// sequential.  Here lanes 2k and 2k + 1 hold the SAME point and each computes half of the products (role = lane & 1), swapping
+// field elements through DPP (quad_perm [1, 0, 3, 2]: a register move, no LDS):
+//   add:  role 0  U1, U2 | P, PP | PPP, Q       | X3, R QX, S1 (4p - PPP) -> Y3          6 M + 1 S per lane instead of 12 M + 2 S
+//         role 1  S1, S2 | R, RR | ZZ1 ZZ2, ZZZ1 ZZZ2 | ZZ3, ZZZ3
+//   dbl:  role 0  V = (2Y)^2 | W = 2Y V, S = X V | ZZ3 = V ZZ, ZZZ3 = W ZZZ               4 M + 1 S instead of 4.5 M + 3 S
+//         role 1  X^2 -> M   | M^2               | X3, M (S - X3), Y (4p - W) -> Y3
+// Both lanes run ONE instruction stream: operands are picked per role with v_cndmask, the role-specific limb arithmetic is executed
+// by both (on don't-care values in the other role).  Same formulas, bounds and invariants as xyzz28_add / xyzz28_dbl (X: W < 14p,
+// Y: W < 6p, ZZ, ZZZ: T); Y3 is the sum of two products here (tight + tight, then a carry propagation) instead of one fused one.
+template <class RR>
+__device__ __forceinline__ F28<RR> f28_partner(const F28<RR> &a) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xF, 0xF, true);
+    return r;
+}
+template <class RR>
+__device__ __forceinline__ F28<RR> f28_pick(bool c, const F28<RR> &a, const F28<RR> &b) {   // c ? a : b
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+__device__ __forceinline__ int pair_or(int v) { return v | __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+
+// a += b, both lanes of the pair hold (a, b); false: the exceptional case (same x), a untouched
+template <class C>
+__device__ __forceinline__ bool xyzz28_add_pair(XYZZ28<C> &a, const XYZZ28<C> &b, bool r1) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(b.ZZ)) return true;
+    if (f28_all_zero<RR>(a.ZZ)) { a = b; return true; }
+    const F T1 = f28_mul<RR>(f28_pick<RR>(r1, a.Y, a.X), f28_pick<RR>(r1, b.ZZZ, b.ZZ));     // U1 | S1          W x T -> T
+    const F T2 = f28_mul<RR>(f28_pick<RR>(r1, b.Y, b.X), f28_pick<RR>(r1, a.ZZZ, a.ZZ));     // U2 | S2
+    const F D = f28_sub_k4<RR>(T2, T1);                                                      // P  | R           L e<=1.6, < 6p
+    const F DD = f28_sqr<RR>(D);                                                             // PP | RR
+    if (pair_or(!r1 && f28_is_zero_mod_p<RR>(DD))) return false;
+    const F V1 = f28_mul<RR>(f28_pick<RR>(r1, a.ZZ, D), f28_pick<RR>(r1, b.ZZ, DD));         // PPP | ZZ1 ZZ2
+    const F V2 = f28_mul<RR>(f28_pick<RR>(r1, a.ZZZ, T1), f28_pick<RR>(r1, b.ZZZ, DD));      // Q = U1 PP | ZZZ1 ZZZ2
+    const F xD = f28_partner<RR>(D), xDD = f28_partner<RR>(DD), xV1 = f28_partner<RR>(V1), xT1 = f28_partner<RR>(T1);
+    // role 0 (role 1 runs it on don't-care values): X3 = RR - PPP - 2Q, QX = Q - X3, 4p - PPP
+    F X3 = f28_sub_k4<RR>(xDD, V1);
+    X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(X3, f28_add<RR>(V2, V2)));                         // W, < 14p
+    const F QX = f28_sub_k16<RR>(V2, X3);                                                    // L e<=1.6, < 18p
+    const F nPPP = f28_sub_k4<RR>(f28_zero<RR>(), V1);                                       // limbs < 2^29, < 4p
+    const F W1 = f28_mul<RR>(f28_pick<RR>(r1, V1, xD), f28_pick<RR>(r1, xDD, QX));           // R QX | ZZ3 = (ZZ1 ZZ2) PP
+    const F W2 = f28_mul<RR>(f28_pick<RR>(r1, V2, xT1), f28_pick<RR>(r1, xV1, nPPP));        // S1 (4p - PPP) | ZZZ3 = (ZZZ1 ZZZ2) PPP
+    const F Y3 = f28_weak_norm<RR>(f28_add<RR>(W1, W2));                                     // W, < 4p
+    const F pX = f28_partner<RR>(X3), pY = f28_partner<RR>(Y3), pW1 = f28_partner<RR>(W1), pW2 = f28_partner<RR>(W2);
+    a.X = f28_pick<RR>(r1, pX, X3);
+    a.Y = f28_pick<RR>(r1, pY, Y3);
+    a.ZZ = f28_pick<RR>(r1, W1, pW1);
+    a.ZZZ = f28_pick<RR>(r1, W2, pW2);
+    return true;
+}
+template <class C>
+__device__ __forceinline__ void xyzz28_add_pair_full(XYZZ28<C> &a, const XYZZ28<C> &b, bool r1) {
+    if (!xyzz28_add_pair<C>(a, b, r1)) a = xyzz28_add_exceptional<C>(a, b);     // both lanes, the same result
+}
+template <class C>
+__device__ __forceinline__ void xyzz28_dbl_pair(XYZZ28<C> &a, bool r1) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(a.ZZ)) return;
+    const F U = f28_add<RR>(a.Y, a.Y);                                          // limbs < 2^29, < 12p
+    const F A = f28_sqr<RR>(f28_pick<RR>(r1, a.X, U));                          // V = U^2 | X^2
+    const F M = f28_add<RR>(f28_add<RR>(A, A), A);                              // role 1: 3 X^2, limbs < 3 2^28, < 6p
+    const F B1 = f28_mul<RR>(f28_pick<RR>(r1, M, U), f28_pick<RR>(r1, M, A));   // W = U V | M^2
+    const F B2 = f28_mul<RR>(a.X, A);                                           // S = X V | (unused)
+    const F S = f28_partner<RR>(B2), Wv = f28_partner<RR>(B1);                  // role 1 receives S and W
+    // role 1: X3 = M^2 - 2S, SX = S - X3, 4p - W
+    const F X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(B1, f28_add<RR>(S, S)));      // W, < 10p
+    const F SX = f28_sub_k16<RR>(S, X3);                                        // L e<=1.6, < 18p
+    const F nW = f28_sub_k4<RR>(f28_zero<RR>(), Wv);
+    const F C1 = f28_mul<RR>(f28_pick<RR>(r1, M, A), f28_pick<RR>(r1, SX, a.ZZ));      // ZZ3 = V ZZ | M (S - X3)
+    const F C2 = f28_mul<RR>(f28_pick<RR>(r1, a.Y, B1), f28_pick<RR>(r1, nW, a.ZZZ));  // ZZZ3 = W ZZZ | Y (4p - W)
+    const F Y3 = f28_weak_norm<RR>(f28_add<RR>(C1, C2));                        // role 1: W, < 4p
+    const F pX = f28_partner<RR>(X3), pY = f28_partner<RR>(Y3), pC1 = f28_partner<RR>(C1), pC2 = f28_partner<RR>(C2);
+    a.X = f28_pick<RR>(r1, X3, pX);
+    a.Y = f28_pick<RR>(r1, Y3, pY);
+    a.ZZ = f28_pick<RR>(r1, pC1, C1);
+    a.ZZZ = f28_pick<RR>(r1, pC2, C2);
+}
+
+// ---- four lanes per point: the critical path of an addition is 3M + 1S (U/S products | P^2, R^2 | PPP, Q, ZZ1 ZZ2, ZZZ1 ZZZ2 |
+// R QX, S1 (4p - PPP), ZZ3, ZZZ3), one product per lane and step; results travel by DPP quad broadcasts.  The cheap limb arithmetic
+// between the steps (X3, Q - X3, 4p - PPP) is done by all four lanes on broadcast values, so X3 needs no trip back.
+template <int CTRL, class RR>
+__device__ __forceinline__ F28<RR> f28_dpp(const F28<RR> &a) {
+    F28<RR> r;
+#pragma unroll
+    for (int i = 0; i < RR::N; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xF, 0xF, true);
+    return r;
+}
+constexpr int QP_SWAP = 0xB1, QP_B0 = 0x00, QP_B1 = 0x55, QP_B2 = 0xAA, QP_B3 = 0xFF;   // quad_perm [1,0,3,2]; broadcast lane k
+
+template <class C>
+__device__ __forceinline__ bool xyzz28_add_quad(XYZZ28<C> &a, const XYZZ28<C> &b, unsigned role) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(b.ZZ)) return true;
+    if (f28_all_zero<RR>(a.ZZ)) { a = b; return true; }
+    const bool b0 = role & 1, b1 = role & 2;
+    // lane 0: U1 = X1 ZZ2, lane 1: U2 = X2 ZZ1, lane 2: S1 = Y1 ZZZ2, lane 3: S2 = Y2 ZZZ1
+    const F T = f28_mul<RR>(f28_pick<RR>(b1, f28_pick<RR>(b0, b.Y, a.Y), f28_pick<RR>(b0, b.X, a.X)),
+                            f28_pick<RR>(b1, f28_pick<RR>(b0, a.ZZZ, b.ZZZ), f28_pick<RR>(b0, a.ZZ, b.ZZ)));
+    const F xT = f28_dpp<QP_SWAP, RR>(T);
+    const F lo = f28_pick<RR>(b0, xT, T);                                   // U1 (lanes 0, 1) | S1 (lanes 2, 3)
+    const F D = f28_sub_k4<RR>(f28_pick<RR>(b0, T, xT), lo);               // P | R                  L e<=1.6, < 6p
+    const F DD = f28_sqr<RR>(D);                                            // PP | RR
+    if (__builtin_amdgcn_update_dpp(0, (int)f28_is_zero_mod_p<RR>(DD), QP_B0, 0xF, 0xF, true)) return false;
+    // lane 0: PPP = P PP, lane 1: Q = U1 PP, lane 2: ZZ1 ZZ2, lane 3: ZZZ1 ZZZ2
+    const F V = f28_mul<RR>(f28_pick<RR>(b1, f28_pick<RR>(b0, a.ZZZ, a.ZZ), f28_pick<RR>(b0, lo, D)),
+                            f28_pick<RR>(b1, f28_pick<RR>(b0, b.ZZZ, b.ZZ), DD));
+    const F PPP = f28_dpp<QP_B0, RR>(V), Q = f28_dpp<QP_B1, RR>(V), PP = f28_dpp<QP_B0, RR>(DD), RR2 = f28_dpp<QP_B2, RR>(DD);
+    const F Rv = f28_dpp<QP_B2, RR>(D), S1 = f28_dpp<QP_B2, RR>(lo);
+    F X3 = f28_sub_k4<RR>(RR2, PPP);
+    X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(X3, f28_add<RR>(Q, Q)));          // W, < 14p
+    const F QX = f28_sub_k16<RR>(Q, X3);                                    // L e<=1.6, < 18p
+    const F nPPP = f28_sub_k4<RR>(f28_zero<RR>(), PPP);                     // limbs < 2^29, < 4p
+    // lane 0: R QX, lane 1: S1 (4p - PPP), lane 2: ZZ3 = (ZZ1 ZZ2) PP, lane 3: ZZZ3 = (ZZZ1 ZZZ2) PPP
+    const F W = f28_mul<RR>(f28_pick<RR>(b1, V, f28_pick<RR>(b0, S1, Rv)),
+                            f28_pick<RR>(b1, f28_pick<RR>(b0, PPP, PP), f28_pick<RR>(b0, nPPP, QX)));
+    a.X = X3;
+    a.Y = f28_weak_norm<RR>(f28_add<RR>(f28_dpp<QP_B0, RR>(W), f28_dpp<QP_B1, RR>(W)));   // W, < 4p
+    a.ZZ = f28_dpp<QP_B2, RR>(W);
+    a.ZZZ = f28_dpp<QP_B3, RR>(W);
+    return true;
+}
+template <class C>
+__device__ __forceinline__ void xyzz28_dbl_quad(XYZZ28<C> &a, unsigned role) {
+    typedef typename C::FqRR RR;
+    typedef F28<RR> F;
+    if (f28_all_zero<RR>(a.ZZ)) return;
+    const bool b0 = role & 1, b1 = role & 2;
+    const F U = f28_add<RR>(a.Y, a.Y);                                      // limbs < 2^29, < 12p
+    const F A = f28_sqr<RR>(f28_pick<RR>(b0, a.X, U));                      // lanes 0, 2: V = U^2 | lanes 1, 3: X^2
+    const F M = f28_add<RR>(f28_add<RR>(A, A), A);                          // lanes 1, 3: 3 X^2, limbs < 3 2^28, < 6p
+    const F V = f28_dpp<QP_B0, RR>(A);
+    // lane 0: W = U V, lane 1: M^2, lane 2: S = X V, lane 3: M^2 (again)
+    const F B = f28_mul<RR>(f28_pick<RR>(b0, M, f28_pick<RR>(b1, a.X, U)), f28_pick<RR>(b0, M, V));
+    const F Wv = f28_dpp<QP_B0, RR>(B), MM = f28_dpp<QP_B1, RR>(B), S = f28_dpp<QP_B2, RR>(B);
+    const F X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(MM, f28_add<RR>(S, S)));  // W, < 10p
+    const F SX = f28_sub_k16<RR>(S, X3);                                    // L e<=1.6, < 18p
+    const F nW = f28_sub_k4<RR>(f28_zero<RR>(), Wv);
+    // lane 0: ZZ3 = V ZZ, lane 1: M (S - X3), lane 2: ZZZ3 = W ZZZ, lane 3: Y (4p - W)
+    const F Cc = f28_mul<RR>(f28_pick<RR>(b1, f28_pick<RR>(b0, a.Y, Wv), f28_pick<RR>(b0, M, V)),
+                             f28_pick<RR>(b1, f28_pick<RR>(b0, nW, a.ZZZ), f28_pick<RR>(b0, SX, a.ZZ)));
+    a.X = X3;
+    a.Y = f28_weak_norm<RR>(f28_add<RR>(f28_dpp<QP_B1, RR>(Cc), f28_dpp<QP_B3, RR>(Cc)));   // W, < 4p
+    a.ZZ = f28_dpp<QP_B0, RR>(Cc);
+    a.ZZZ = f28_dpp<QP_B2, RR>(Cc);
+}
+
+// one interface for the kernels: LP lanes per point (2 or 4), role = lane % LP
+template <class C, unsigned LP>
+__device__ __forceinline__ void xyzz28_add_coop(XYZZ28<C> &a, const XYZZ28<C> &b, unsigned role) {
+    const bool ok = LP == 2 ? xyzz28_add_pair<C>(a, b, role & 1) : xyzz28_add_quad<C>(a, b, role);
+    if (!ok) a = xyzz28_add_exceptional<C>(a, b);     // every lane of the group, the same result
+}
+template <class C, unsigned LP>
+__device__ __forceinline__ void xyzz28_dbl_coop(XYZZ28<C> &a, unsigned role) {
+    if (LP == 2) xyzz28_dbl_pair<C>(a, role & 1); else xyzz28_dbl_quad<C>(a, role);
+}
+
+// sh[k], k < blockDim.x / LP: the value of lane group k on entry (written by its role-0 lane); on exit sh[0] = the workgroup sum
+template <class C, unsigned LP>
+__device__ __forceinline__ void lds_tree_sum_coop(XYZZ28<C> *sh) {
+    const unsigned k = threadIdx.x / LP, role = threadIdx.x % LP;
+    __syncthreads();
+    for (unsigned off = blockDim.x / LP / 2; off > 0; off >>= 1) {
+        if (k < off) {
+            XYZZ28<C> a = sh[k];
+            xyzz28_add_coop<C, LP>(a, sh[k + off], role);
+            if (!role) sh[k] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// k_reduce_level1 on lane groups: group j owns R level-0 outputs; t0 * run goes through the non-adjacent form of t0 (digits
+// +-1, no two adjacent: the lanes of a wave cover every pattern of the low bits, so what a wave pays is the weight of the HIGH
+// bits it shares -- at most half of them in this form -- plus one addition per low position).
+template <class C, unsigned LP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1_coop(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0,
+                                                                                                         unsigned K0, unsigned R, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    const size_t j = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / LP, t0 = j * R;
+    const unsigned role = threadIdx.x % LP;
+    XYZZ28<C> acc;
+    acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
+    if (t0 < lanes0) {
+        XYZZ28<C> run = acc;
+        for (int i = (int)R - 1; i >= 0; --i) {
+            if (t0 + i >= lanes0) continue;
+            xyzz28_add_coop<C, LP>(run, xyzz28_load<C>(A[t0 + i]), role);
+            if (i > 0) xyzz28_add_coop<C, LP>(acc, run, role);          // weight i
+        }
+        if (t0 && !f28_all_zero<RR>(run.ZZ)) {                         // acc += t0 * run
+            uint32_t pos = 0, neg = 0;
+            {
+                uint64_t x = t0;
+                for (unsigned b = 0; x; ++b, x >>= 1)
+                    if (x & 1) {
+                        if ((x & 3) == 3) { neg |= 1u << b; x += 1; } else { pos |= 1u << b; x -= 1; }
+                    }
+            }
+            // -run: Y back below 2p (one product by the radix)
+            const F28<RR> nY = f28_mul<RR>(f28_sub_k16<RR>(f28_zero<RR>(), run.Y), f28_one<RR>());
+            XYZZ28<C> m = run;                                         // the leading digit of a positive number is +1
+            for (int b = 30 - __clz((int)(pos | neg)); b >= 0; --b) {
+                xyzz28_dbl_coop<C, LP>(m, role);
+                if (((pos | neg) >> b) & 1) {
+                    XYZZ28<C> t = run;
+                    t.Y = f28_pick<RR>((neg >> b) & 1, nY, run.Y);
+                    xyzz28_add_coop<C, LP>(m, t, role);
+                }
+            }
+            xyzz28_add_coop<C, LP>(acc, m, role);
+        }
+        for (unsigned k = 1; k < K0; k <<= 1) xyzz28_dbl_coop<C, LP>(acc, role);   // K0 is a power of two
+        for (unsigned i = 0; i < R; ++i)
+            if (t0 + i < lanes0) xyzz28_add_coop<C, LP>(acc, xyzz28_load<C>(Acc[t0 + i]), role);
+    }
+    if (!role) sh[threadIdx.x / LP] = acc;
+    lds_tree_sum_coop<C, LP>(sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
+}
+
+// out[0] = sum of parts[0 .. count) by one workgroup of 256 / LP lane groups
+template <class C, unsigned LP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_sum_final_coop(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    const unsigned role = threadIdx.x % LP;
+    XYZZ28<C> acc;
+    acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
+    for (unsigned i = threadIdx.x / LP; i < count; i += 256 / LP) xyzz28_add_coop<C, LP>(acc, xyzz28_load<C>(parts[i]), role);
+    if (!role) sh[threadIdx.x / LP] = acc;
+    lds_tree_sum_coop<C, LP>(sh);
+    if (threadIdx.x == 0) out[0] = xyzz28_store<C>(sh[0]);
+}
+
+// out[0] = sum of parts[0 .. count) by one 256-lane workgroup
+template <class C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sum_final(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
+    typedef typename C::FqRR RR;
+    XYZZ28<C> *acc = &sh[threadIdx.x];
+    acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
+    for (unsigned i = threadIdx.x; i < count; i += 256) xyzz28_add_into_full<C>(acc, xyzz28_load<C>(parts[i]));
+    lds_tree_sum<C>(sh);
+    if (threadIdx.x == 0) out[0] = xyzz28_store<C>(sh[0]);
+}
+
+// sum_b (b + 1) B_b over the NB buckets whose (folded) task partials sit in ctx->msm: three launches on ctx->stream, the result
+// (internal form) at *out in the workspace.
+template <class C>
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out) {
+    MsmWorkspace &ws = ctx->msm;
+    unsigned K0 = 4;                                   // level-0 fan-in: <= 2^17 lanes = 2 waves per SIMD, one round of the chip
+    while (NB / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;   // (swept in profiles/r02_levers.jsonl: K0 = 2 doubles level 1's work and loses)
+    if (const char *e = getenv("PM_RED_K0")) K0 = (unsigned)atoi(e);        // developer knobs (powers of two)
+    // levels 1 and final on lane GROUPS (2 or 4 lanes per point, a share of the products each): 256 / LP points per workgroup, and
+    // R = 2 LP keeps level 1 at 2^16 lanes = one wave per SIMD (its register budget).  PM_RED_PAIR = 0: one lane per point, 2: pairs.
+    unsigned coop = 4;
+    if (const char *e = getenv("PM_RED_PAIR")) coop = e[0] == '0' ? 0u : e[0] == '2' ? 2u : 4u;
+    unsigned R1 = coop ? 2 * coop : 2;                 // swept on MI355X (tools/sweep_reduce.sh, profiles/r02_m_reduce_pair_sweep.txt)
+    if (const char *e = getenv("PM_RED_R")) R1 = (unsigned)atoi(e);
+    if (K0 == 0 || R1 == 0) return PM_ERR_INVALID_ARG;
+    const unsigned per_block1 = coop ? 256 / coop : 256;      // points per level-1 workgroup
+    const size_t lanes0 = (NB + K0 - 1) / K0, lanes1 = (lanes0 + R1 - 1) / R1, blocks0 = (lanes0 + 255) / 256,
+                 blocks1 = (lanes1 + per_block1 - 1) / per_block1;
+    PM_HIP(ctx, ws.wsum.reserve((2 * lanes0 + (blocks0 > blocks1 ? blocks0 : blocks1) + 4) * sizeof(XYZZ<C>)));
+    XYZZ<C> *A = ws.wsum.as<XYZZ<C>>(), *Acc = A + lanes0, *parts = Acc + lanes0, *dres = parts + (blocks0 > blocks1 ? blocks0 : blocks1);
+    hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
+                       ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), NB, lanes0, K0, A, Acc);
+    PM_HIP(ctx, hipGetLastError());
+    if (coop == 4) {
+        hipLaunchKernelGGL((k_reduce_level1_coop<C, 4>), dim3((unsigned)blocks1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
+                           lanes0, K0, R1, parts);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL((k_sum_final_coop<C, 4>), dim3(1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+    } else if (coop == 2) {
+        hipLaunchKernelGGL((k_reduce_level1_coop<C, 2>), dim3((unsigned)blocks1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
+                           lanes0, K0, R1, parts);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL((k_sum_final_coop<C, 2>), dim3(1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+    } else {
+        hipLaunchKernelGGL(k_reduce_level1<C>, dim3((unsigned)blocks1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, A, Acc, lanes0,
+                           K0, R1, parts);
+        PM_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_sum_final<C>, dim3(1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+    }
+    PM_HIP(ctx, hipGetLastError());
+    *out = dres;
+    return PM_OK;
+}
+
+template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **);
+template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **);
+
+}  // namespace pm
