@@ -2,13 +2,21 @@
 """Headline benchmark: Polymath prove on the synthetic 2^20-constraint R1CS (BASELINE.json
 configs[1]: random A*B=C gates, BLS12-381), one process per GPU.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: this process spawns the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step = one complete create_proof_with_assignment (prover.rs:66-237): scalar H2D, witness map,
-NTTs, the three merged MSMs, both Fiat-Shamir hashes; the proving key (bases + matrices) is
-resident in HBM before the timed region.  With N > 1 ONE proof is spread over the N GPUs (MSM pair
-ranges sharded, partial points all-gathered over RCCL), so scaling is "strong".
+A step = one complete create_proof_with_assignment (prover.rs:66-237) FROM HOST INPUTS, as benches/bench.rs:79 times
+it and SURVEY.md §8d defines the metric: scalar H2D (x, w from pinned host memory), witness map, NTTs, the three merged
+MSMs, both Fiat-Shamir hashes; the proving key (bases + matrices + window tables) is resident in HBM before the timed
+region.  `ms_per_step_hbm_resident` / `value_hbm_resident` in the same line are the variant with the assignment already in
+HBM (pm_prove_phase1_device).  With N > 1 ONE proof is spread over the N GPUs (layout "vector": witness map, four-step
+NTT with one all-to-all per transform, scans and MSM pairs sharded; the ranks joined by a pm_comm = RCCL inside the
+library), so scaling is "strong".
+
+Multi-GPU launches are supervised (polymath_amd/launch.py): ranks are child processes of a parent that never touches the
+GPU, a failing or stalled rank ends the attempt (fail-fast collectives in the library, deadlines here), and the exchange
+layer falls back RCCL -> host-staged torch.distributed until one configuration completes; the JSON line says which ran
+(`config.exchange`, `n_ranks_seen`).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the MSM bucket accumulation,
 HIP-event timed on the library's stream), `cpu_baseline` (the CPU restatement oracle/cpp proving the SAME
@@ -73,13 +81,15 @@ def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
             "seconds": dt, "proof_identical_to_gpu": same, "msm_pairs_per_sec": pairs / dt}
 
 
-def live_traffic(args, timeout_s=200):
+def live_traffic(args, timeout_s=None):
     """HBM traffic of k_accumulate measured NOW, by this run: two child processes of this script under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md's HBM section
     prescribes), PM_MSM_OVERLAP=0 so that every launch runs alone; per-launch bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B
     requests at 64 B; calibrated on this access pattern by tools/pmc_gather_calib.hip) + WRITE_SIZE, both in KB.
     -> (bytes per launch, description) or (None, reason): the caller then falls back to the committed profile."""
-    import csv, shutil, subprocess, tempfile
+    import csv, shutil, signal, subprocess, tempfile
+    if timeout_s is None:
+        timeout_s = 200 * (1 << max(0, args.log_constraints - 20))
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
@@ -94,7 +104,16 @@ def live_traffic(args, timeout_s=200):
                "--log-constraints", str(args.log_constraints), "--curve", args.curve, "--transcript", args.transcript]
         env = dict(os.environ, PM_MSM_OVERLAP="0", TMPDIR="/tmp")
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            # own session: on a timeout the whole tree (rocprofv3 AND the profiled python) is killed, not just the profiler
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, "%s pass exceeded %d s and was killed" % (ctr, timeout_s)
+            if rc != 0:
+                return None, "%s pass exited with code %d" % (ctr, rc)
             path = None
             for root_, _dirs, files in os.walk(d):
                 if "run_counter_collection.csv" in files:
@@ -142,7 +161,7 @@ def msm_micro(ctx, curve, logs, reps=3):
     return out
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -154,14 +173,59 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-micro", default="20,22,24,26", help="log2 lengths of the standalone resident MSM legs ('' = none)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure `roofline.traffic`")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    """Dispatch.  N = 1: the bench runs in this process.  N > 1: this process only SUPERVISES (it never touches the GPU):
+    without a launcher it spawns the N ranks, under torch.distributed.run it supervises its own rank's child
+    (polymath_amd/launch.py); the children come back here with BENCH_CHILD=1 and run worker()."""
+    args = parse_args()
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not os.environ.get("BENCH_CHILD"):
+        world_env = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
+        # the deadline of one attempt: import + synthesis + key setup + K proofs, generous; scaled with the circuit
+        deadline = int(os.environ.get("BENCH_ATTEMPT_DEADLINE_S", str(600 * (1 << max(0, args.log_constraints - 20)) + 60 * args.steps)))
+        if under_launcher and (world_env > 1 or os.environ.get("BENCH_FORCE_VECTOR")):
+            if world_env != args.gpus and world_env > 1:
+                raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world_env))
+            from polymath_amd import launch
+            raise SystemExit(launch.supervise_one(os.path.abspath(__file__), sys.argv[1:], deadline))
+        if not under_launcher and args.gpus > 1:
+            from polymath_amd import launch
+            raise SystemExit(launch.supervise_all(os.path.abspath(__file__), sys.argv[1:], args.gpus, deadline))
+        return worker(args)
+    # a rank of a supervised job: any failure is a non-zero exit NOW (interpreter teardown with a dead communicator may hang)
+    try:
+        worker(args)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+    except BaseException:       # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
+
+
+def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if world != args.gpus and not (world == 1 and os.environ.get("BENCH_FORCE_VECTOR")):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    supervised = bool(os.environ.get("BENCH_CHILD"))
+    from polymath_amd.launch import Watchdog
+    wd = Watchdog(rank) if supervised else None
+    comm_timeout_s = int(os.environ.get("BENCH_COMM_TIMEOUT_S", "60"))
+    os.environ.setdefault("PM_COMM_TIMEOUT_MS", str(comm_timeout_s * 1000))     # the library's collective deadline
+
+    def stage(name, limit_s):
+        if wd:
+            wd.stage_begin(name, limit_s)
+    stage("import torch + rendezvous", 420)
+    import datetime
+    import numpy as np
     import torch
     import torch.distributed as dist
     # test hooks: several ranks sharing one GPU over gloo (tests/test_gpu_parity.py::test_bench_two_ranks_one_gpu)
@@ -175,10 +239,12 @@ def main():
     force_vec = bool(os.environ.get("BENCH_FORCE_VECTOR")) and "MASTER_ADDR" in os.environ
     multi = world > 1 or force_vec
     if multi:
+        pg_timeout = datetime.timedelta(seconds=max(2 * comm_timeout_s, 120))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
+        dist.barrier()          # every rank is up before anybody starts the expensive part
 
     from polymath_amd import circuits as PC
     from polymath_amd.distributed import PointCombiner
@@ -204,12 +270,15 @@ def main():
     # ranks joined by a pm_comm (RCCL inside the library); "pairs": only the MSM pair ranges
     # sharded, the partial points combined through torch.distributed (row 1 only; BENCH_SHARD_LAYOUT=pairs).
     layout = os.environ.get("BENCH_SHARD_LAYOUT", "vector") if multi else "pairs"
-    comm_desc = None
+    comm_desc, comm_meta = None, None
     if multi and layout == "vector":
         from polymath_amd.distributed import make_comm
-        comm, comm_desc = make_comm(rank, world, local, native=(backend == "nccl" and not os.environ.get("BENCH_NO_RCCL")))
+        stage("communicator setup", 60 + 3 * comm_timeout_s)
+        want_native = not os.environ.get("BENCH_NO_RCCL") and (supervised or backend == "nccl")
+        comm, comm_desc, comm_meta = make_comm(rank, world, local, native=want_native, timeout_s=comm_timeout_s)
         pm.ctx.set_comm(comm)
-        log(rank, "pm_comm:", comm_desc)
+        log(rank, "pm_comm:", comm_desc, comm_meta)
+    stage("key setup", 300 * (1 << max(0, args.log_constraints - 20)))
     pk = pm.setup(r1cs, x_trap, z_trap, shard_rank=shard_rank, shard_count=shard_count, layout=layout)
     log(rank, "setup on device: n=%d, layout=%s (%.1f s)" % (pk.n, layout, time.time() - t0))
     x_l, w_l = r1cs.inst_limbs, r1cs.wit_limbs
@@ -224,9 +293,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the assignment is resident in HBM before the timed region (contract: `value` excludes PCIe)
-    d_x = torch.from_numpy(x_l.view("int64")).cuda()
-    d_w = torch.from_numpy(w_l.view("int64")).cuda()
+    # The metric (benches/bench.rs:79): prove FROM HOST INPUTS -- the scalar H2D is inside the step.  The
+    # host buffers are pinned (what a host that cares about the 33 MB copy hands over; a pageable buffer costs ~0.4 ms
+    # more through the runtime's bounce buffers).  The HBM-resident variant (pm_prove_phase1_device) is timed beside it.
+    x_pin = torch.from_numpy(np.ascontiguousarray(x_l).view("int64")).pin_memory()
+    w_pin = torch.from_numpy(np.ascontiguousarray(w_l).view("int64")).pin_memory()
+    x_l, w_l = x_pin.numpy().view("uint64"), w_pin.numpy().view("uint64")
+    d_x, d_w = x_pin.cuda(), w_pin.cuda()
     dev_ptrs = (d_x.data_ptr(), d_w.data_ptr())
     # The whole create_proof_with_assignment is ONE native call (pm_host_prove[_sharded]: the library's C++ host mirror
     # runs the transcript and challenge arithmetic between the phases); with several ranks it calls back into
@@ -234,14 +307,22 @@ def main():
     native = (world == shard_count) and not os.environ.get("BENCH_PYTHON_GLUE")
     comm_info = comm_desc
 
-    def prove_once():
+    def prove_once(resident=False):
+        ptrs = dev_ptrs if resident else None
         if native:
-            return pm.prove_native(pk, x_l, w_l, r_a, dev_ptrs, combine)
-        return pm.prove_limbs(pk, inst, x_l, w_l, r_a, py_combine, dev_ptrs).to_bytes()
+            return pm.prove_native(pk, x_l, w_l, r_a, ptrs, combine)
+        return pm.prove_limbs(pk, inst, x_l, w_l, r_a, py_combine, ptrs).to_bytes()
 
+    stage("warmup proofs", 120 + 20 * args.warmup * (1 << max(0, args.log_constraints - 20)))
     proof_b = None
     for _ in range(args.warmup):
         proof_b = prove_once()
+    stage("timed proofs", 120 + 10 * (args.steps + 4) * (1 << max(0, args.log_constraints - 20)))
+    if os.environ.get("BENCH_TEST_DIE"):            # test hook "rank,seconds": that rank dies (exit 17) mid-run, the job must fail fast
+        die_rank, die_after = os.environ["BENCH_TEST_DIE"].split(",")
+        if int(die_rank) == rank:
+            import threading
+            threading.Timer(float(die_after), lambda: os._exit(17)).start()
     acc_all_ms, sort_all_ms, red_all_ms, ntt_all_ms, poly_all_ms = [], [], [], [], []
     acc_ms, msm_ms, sort_ms, red_ms, phase_ms, acc1_ms = [], [], [], [], [], []
     pm.collect_timings = not native                 # phase-by-phase path: keep the stage slots of every phase
@@ -265,13 +346,19 @@ def main():
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
     pm.collect_timings = False
-    # PCIe-inclusive variant (host x, w buffers through pm_prove_phase1): reported, never `value`
+    # the same proofs with the assignment already resident in HBM (pm_prove_phase1_device): reported beside `value`
     barrier()
     t1 = time.perf_counter()
-    proof_host_b = pm.prove_native(pk, x_l, w_l, r_a, None, combine) if native else pm.prove_limbs(pk, inst, x_l, w_l, r_a, py_combine).to_bytes()
+    for _ in range(args.steps):
+        proof_res_b = prove_once(resident=True)
     barrier()
-    ms_host_inputs = (time.perf_counter() - t1) * 1e3
-    assert proof_host_b == proof_b
+    dt_res = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([dt_res], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_res = float(tt.item())
+    ms_resident = dt_res / args.steps * 1e3
+    assert proof_res_b == proof_b
     # one phase-by-phase proof outside the timed region: per-phase stage breakdown, and the two host paths agree
     pm.collect_timings = True
     t1 = time.perf_counter()
@@ -335,7 +422,12 @@ def main():
                        "parallelism": ("one proof over %d GPUs: witness map, four-step NTT (one all-to-all per transform), scans and MSM pairs sharded; %s"
                                        % (world, comm_desc)) if layout == "vector" and multi else "msm-pairs-sharded x%d" % world},
             "msm_pairs_per_sec": pairs_per_proof / (dt / args.steps),
-            "ms_per_step_pcie_inclusive": ms_host_inputs,
+            "timed_entry_point": "pm_host_prove%s from pinned HOST buffers (x, w: %.1f MB H2D inside every step; SURVEY.md §8d, benches/bench.rs:79)"
+                                 % ("_sharded" if world > 1 else "", (x_l.nbytes + w_l.nbytes) / 1e6),
+            "ms_per_step_hbm_resident": ms_resident, "value_hbm_resident": nr / (dt_res / args.steps),
+            "n_ranks_seen": comm_meta["ranks_seen"] if comm_meta else world,
+            "exchange": comm_meta if comm_meta else {"kind": "none (single GPU)" if not multi else "torch.distributed point all-gather (pairs layout)", "ranks_seen": world},
+            "launch": {"supervised": supervised, "attempt": int(os.environ.get("BENCH_ATTEMPT", "0")), "torch_distributed_backend": backend if multi else None},
             "host_glue": "native (pm_host_prove%s: C++ transcript + challenge arithmetic inside the library)" % ("_sharded" if world > 1 else "")
                          if native else "python (phases driven from bench.py)",
             "ms_per_step_python_glue": ms_python_glue,
@@ -390,10 +482,20 @@ def main():
                 pk.free()                                        # give the HBM back: the 2^26 leg holds 100 GB of window tables
                 log(rank, "standalone resident MSM legs: 2^{%s} pairs ..." % args.msm_micro)
                 out["msm_micro"] = msm_micro(pm.ctx, curve, [int(v) for v in args.msm_micro.split(",")])
-        print(json.dumps(out), flush=True)
+        stage("final agreement", 120)
+        line = json.dumps(out)
     if multi:
+        # the line is printed only when EVERY rank got here: a failed attempt must leave nothing on stdout (launch.py)
         dist.barrier()
-        dist.destroy_process_group()
+        if rank == 0:
+            print(line, flush=True)
+        dist.barrier()
+        if not supervised:                  # supervised ranks leave through os._exit (main): teardown of a communicator
+            dist.destroy_process_group()    # that a peer has already left is where multi-process jobs like to hang
+    elif rank == 0:
+        print(line, flush=True)
+    if wd:
+        wd.stage_end()
 
 
 if __name__ == "__main__":

@@ -46,7 +46,9 @@ typedef enum pm_status {
     PM_ERR_DEGREE_BOUND = 5,       /* == degree asserts                            prover.rs:107,113,222 */
     PM_ERR_HIP = 6,                /* a HIP runtime call failed; see pm_last_error */
     PM_ERR_NO_DEVICE = 7,
-    PM_ERR_STATE = 8               /* phases called out of order */
+    PM_ERR_STATE = 8,              /* phases called out of order */
+    PM_ERR_COMM = 9                /* multi-GPU proofs only (no reference counterpart): a peer rank failed, or a collective
+                                      did not complete within the communicator's deadline; the communicator is dead */
 } pm_status;
 
 typedef struct pm_ctx pm_ctx;
@@ -230,9 +232,13 @@ void pm_host_keccak_f1600(uint64_t state[25]);
  * points, status flags, scan carries).  RCCL form: rank 0 calls pm_comm_rccl_unique_id and ships the 128 bytes to the
  * other ranks by any means (the Rust host's own channel, torch.distributed's store, MPI ...); every rank then calls
  * pm_comm_rccl_create (collective: ncclCommInitRank).  librccl is loaded at first use (dlopen): no link-time dependency.
- * Contract: collectives are matched by program order on every rank; a rank that fails (any non-zero status of a phase) must
- * take the whole job down -- its peers are waiting for it in the next collective, as with any NCCL / MPI program.  The status
- * checks of the prover itself (unsatisfied witness, degree bounds) are exchanged first and fail on ALL ranks together. */
+ * Contract: collectives are matched by program order on every rank.  The status checks of the prover itself (unsatisfied
+ * witness, degree bounds: prover.rs:107,108,221) are exchanged first and fail on ALL ranks together, with the communicator
+ * intact.  Any other failure of one rank (HIP error, out of memory, a dead process) ends the proof on every rank with
+ * PM_ERR_COMM instead of a hang: no collective waits longer than the communicator's deadline (pm_comm_set_timeout_ms;
+ * PM_COMM_TIMEOUT_MS in the environment; 120 s by default), a failing phase aborts its communicator (pm_comm_abort: the local
+ * group wakes its peers at once, RCCL calls ncclCommAbort and the peers run into their deadline), and a failed communicator
+ * stays failed -- the host tears the job down and starts again, as with any NCCL / MPI program. */
 typedef struct pm_comm pm_comm;
 int pm_comm_rccl_unique_id(void *out_128_bytes);
 int pm_comm_rccl_create(const void *unique_id_128_bytes, int rank, int world, int device, pm_comm **out);
@@ -252,6 +258,14 @@ void pm_comm_destroy(pm_comm *c);
 int pm_comm_rank(const pm_comm *c);
 int pm_comm_world(const pm_comm *c);
 const char *pm_comm_last_error(const pm_comm *c);
+/* "rccl" | "local" | "callbacks": which transport a communicator runs on (bench.py reports it). */
+const char *pm_comm_kind(const pm_comm *c);
+/* Deadline of every collective of this communicator, in milliseconds (> 0). */
+int pm_comm_set_timeout_ms(pm_comm *c, long timeout_ms);
+/* This rank gives up (`why` goes to pm_comm_last_error of whoever notices): the communicator fails for good. */
+int pm_comm_abort(pm_comm *c, const char *why);
+/* 1 once the communicator has failed (deadline, peer abort, transport error). */
+int pm_comm_failed(const pm_comm *c);
 /* Local group with PM_LOCAL_COMM_SERIALIZE=1 (ranks take turns between collectives: emulation of N GPUs on one): the
  * milliseconds this rank spent running, waits for its peers excluded; 0 for other communicators.  Measurement aid. */
 double pm_comm_busy_ms(pm_comm *c, int reset);

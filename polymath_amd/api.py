@@ -18,7 +18,7 @@ FQ_LIMBS64 = {PM_BLS12_381: 6, PM_BN254: 4}
 
 STATUS = {0: "PM_OK", 1: "PM_ERR_INVALID_ARG", 2: "PM_ERR_LEN_MISMATCH", 3: "PM_ERR_DOMAIN_TOO_LARGE",
           4: "PM_ERR_REMAINDER_NONZERO", 5: "PM_ERR_DEGREE_BOUND", 6: "PM_ERR_HIP", 7: "PM_ERR_NO_DEVICE",
-          8: "PM_ERR_STATE"}
+          8: "PM_ERR_STATE", 9: "PM_ERR_COMM"}
 (X_POWERS, X_POWERS_Y_ALPHA, X_POWERS_Y_GAMMA, X_POWERS_Y_GAMMA_Z, X_POWERS_ZH_BY_Y_ALPHA,
  UJ_WJ_LCS_BY_Y_ALPHA) = range(6)
 TIMING_SLOTS = ["witness_map", "ntt", "poly", "msm_sort", "msm_accumulate", "msm_reduce", "msm_total", "phase"]
@@ -54,7 +54,7 @@ EXPORTS = [
     "pm_prove_tap", "pm_host_keccak_f1600", "pm_synth_r1cs", "pm_selftest_field",
     "pm_pk_load_sharded", "pm_pk_generate_sharded", "pm_layout_indices", "pm_pk_msm_pieces",
     "pm_comm_rccl_unique_id", "pm_comm_rccl_create", "pm_comm_local_create", "pm_comm_from_callbacks", "pm_comm_destroy", "pm_comm_rank",
-    "pm_comm_world", "pm_comm_last_error", "pm_comm_busy_ms", "pm_host_make_vk", "pm_host_verify", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
+    "pm_comm_world", "pm_comm_last_error", "pm_comm_kind", "pm_comm_set_timeout_ms", "pm_comm_abort", "pm_comm_failed", "pm_comm_busy_ms", "pm_host_make_vk", "pm_host_verify", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
 ]
 SHARD_PAIRS, SHARD_VECTOR = 0, 1
 LAYOUTS = {"pairs": SHARD_PAIRS, "vector": SHARD_VECTOR, 0: 0, 1: 1}
@@ -129,6 +129,11 @@ def load_library():
     L.pm_comm_world.argtypes = [vp]
     L.pm_comm_last_error.argtypes = [vp]
     L.pm_comm_last_error.restype = ct.c_char_p
+    L.pm_comm_kind.argtypes = [vp]
+    L.pm_comm_kind.restype = ct.c_char_p
+    L.pm_comm_set_timeout_ms.argtypes = [vp, ct.c_long]
+    L.pm_comm_abort.argtypes = [vp, ct.c_char_p]
+    L.pm_comm_failed.argtypes = [vp]
     L.pm_host_make_vk.argtypes = [i, u64, u64, u64, u64p, u64p, u64p, ct.c_char_p, sz, ct.POINTER(sz)]
     L.pm_host_verify.argtypes = [i, i, ct.c_char_p, sz, u64p, sz, ct.c_char_p, sz, intp]
     L.pm_comm_busy_ms.argtypes = [vp, i]
@@ -260,6 +265,25 @@ class Comm:
 
     def busy_ms(self, reset=True):
         return float(self.L.pm_comm_busy_ms(self.h, int(reset)))
+
+    @property
+    def kind(self):
+        return self.L.pm_comm_kind(self.h).decode()
+
+    @property
+    def failed(self):
+        return bool(self.L.pm_comm_failed(self.h))
+
+    def last_error(self):
+        return self.L.pm_comm_last_error(self.h).decode()
+
+    def set_timeout_ms(self, ms):
+        st = self.L.pm_comm_set_timeout_ms(self.h, int(ms))
+        if st:
+            raise PolymathError(st, "pm_comm_set_timeout_ms")
+
+    def abort(self, why="aborted by the host"):
+        self.L.pm_comm_abort(self.h, why.encode())
 
     def all_gather(self, arr):
         arr = np.ascontiguousarray(arr)

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpolymath_hip.so")
 SOURCES = ["api.hip", "ntt.hip", "msm.hip", "msm_reduce.hip", "prove.hip", "setup.hip", "host_prove.hip", "synth.hip", "comm.hip", "prove_sharded.hip", "selftest.hip"]
-HEADERS = ["field.cuh", "ec.cuh", "fq28.cuh", "constants.cuh", "internal.h", os.path.join("..", "host", "hashes.hpp"), os.path.join("..", "host", "polymath.hpp"), os.path.join("..", "host", "pairing.hpp"), os.path.join("..", "host", "wire.hpp"), os.path.join("..", "host", "layout.hpp"), "comm.h",
+HEADERS = ["field.cuh", "ec.cuh", "fq28.cuh", "constants.cuh", "internal.h", os.path.join("..", "host", "hashes.hpp"), os.path.join("..", "host", "polymath.hpp"), os.path.join("..", "host", "pairing.hpp"), os.path.join("..", "host", "wire.hpp"), os.path.join("..", "host", "layout.hpp"), os.path.join("..", "host", "rng.hpp"), "comm.h", "prove_common.cuh",
            os.path.join("..", "..", "include", "polymath_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]

@@ -87,6 +87,7 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     ctx->comm = nullptr;
     ctx->tw_clock = 0;
     ctx->shard_roots_n = 0; ctx->shard_roots_N = 0; ctx->shard_roots_curve = -1;
+    ctx->ntt_lds_attr[0] = ctx->ntt_lds_attr[1] = false;
     ctx->keep_timings = false;
     timing_reset(ctx);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -855,15 +856,22 @@ static int guarded(pm_ctx *ctx, F body) {
         explicit Turn(pm_comm *cc) : c(cc) { if (c) c->phase_begin(); }
         ~Turn() { if (c) c->phase_end(); }
     } turn(ctx->comm);
+    int st;
     try {
-        return body();
+        st = body();
     } catch (const std::bad_alloc &) {
         ctx->err = "host allocation failed";
-        return PM_ERR_STATE;
+        st = PM_ERR_STATE;
     } catch (const std::exception &e) {
         ctx->err = e.what();
-        return PM_ERR_STATE;
+        st = PM_ERR_STATE;
     }
+    // Fail-fast (include/polymath_hip.h, pm_comm contract): the prover's own verdicts are the same on every rank; any other
+    // failure is this rank's alone, and its peers are about to wait for it in the next collective -- abort the communicator.
+    const bool shared_verdict = st == PM_OK || st == PM_ERR_LEN_MISMATCH || st == PM_ERR_DOMAIN_TOO_LARGE || st == PM_ERR_REMAINDER_NONZERO ||
+                                st == PM_ERR_DEGREE_BOUND || st == PM_ERR_INVALID_ARG;
+    if (!shared_verdict && ctx->comm && !ctx->comm->failed) ctx->comm->abort(("a prover phase failed on this rank: " + ctx->err).c_str());
+    return st;
 }
 
 extern "C" int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,

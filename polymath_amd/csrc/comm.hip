@@ -10,14 +10,24 @@
 //                                    barrier, device-to-device copies.  What the single-GPU lockstep tests and the
 //                                    per-rank emulation of bench.py run on; also a valid single-process multi-GPU mode.
 //   callbacks (pm_comm_from_callbacks) -- the host brings its own transport (torch.distributed in tests).
+// Fail-fast: no collective waits for a dead peer for ever.  Every communicator has a deadline (pm_comm_set_timeout_ms,
+// PM_COMM_TIMEOUT_MS; 120 s by default) and a sticky `failed` flag; once it is set every collective returns PM_ERR_COMM.
+//   local : the rendezvous is a timed wait; a rank that aborts (pm_comm_abort, or a phase of the sharded prover that
+//           returns an error its peers cannot know) wakes everybody at once.
+//   RCCL  : a watchdog thread follows an event recorded behind every collective; past the deadline, or on an
+//           asynchronous RCCL error, it calls ncclCommAbort, which ends the device-side wait, and marks the
+//           communicator failed -- the blocked stream synchronisation returns and the phase reports PM_ERR_COMM.
 #include <dlfcn.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "internal.h"
 #include "comm.h"
@@ -36,6 +46,7 @@ struct LocalGroup {
     std::vector<const void *> send;
     std::vector<void *> recv;
     std::atomic<bool> failed{false};   // sticky: once a rank failed a collective, every later one reports it
+    std::string why;                   // first failure (guarded by mu)
     // PM_LOCAL_COMM_SERIALIZE=1: between collectives only ONE rank runs at a time (a turnstile), so that N ranks emulated on
     // one GPU do not time-slice it: each rank's kernels then take what they would take alone (bench.py's emulation).
     bool serialize = false;
@@ -44,16 +55,35 @@ struct LocalGroup {
         const char *e = getenv("PM_LOCAL_COMM_SERIALIZE");
         serialize = e && e[0] == '1';
     }
-    void barrier() {
+    // false: the group is dead (a peer aborted, or did not arrive within timeout_ms)
+    bool barrier(long timeout_ms, int rank) {
         std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
         const uint64_t gen = generation;
         if (++arrived == world) {
             arrived = 0;
             ++generation;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            return true;
         }
+        const bool woke = cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return generation != gen || failed.load(); });
+        if (!woke) {
+            if (why.empty()) why = "rank " + std::to_string(rank) + ": a peer did not reach the collective within " + std::to_string(timeout_ms) + " ms";
+            failed = true;
+            cv.notify_all();
+            return false;
+        }
+        return generation != gen;   // a completed rendezvous counts even if the group failed right after it
+    }
+    void fail(const std::string &w) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (why.empty()) why = w;
+        failed = true;
+        cv.notify_all();
+    }
+    std::string reason() {
+        std::unique_lock<std::mutex> lk(mu);
+        return why;
     }
 };
 
@@ -80,36 +110,44 @@ struct LocalComm : pm_comm {
     void phase_begin() override { take_turn(); }
     ~LocalComm() override { release_turn(); }
     void phase_end() override { release_turn(); }
+    const char *kind() const override { return "local"; }
+    void abort(const char *why) override {
+        g->fail(std::string("rank ") + std::to_string(rank) + " aborted: " + (why ? why : ""));
+        dead();
+    }
+    int dead() {                                        // the group failed: this rank's view of it
+        if (!failed.exchange(true)) err = g->reason();
+        return PM_ERR_COMM;
+    }
     int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
-        if (hipStreamSynchronize(stream) != hipSuccess) { err = "local all_to_all: stream sync failed"; g->failed = true; }
+        if (g->failed) return dead();
+        if (hipStreamSynchronize(stream) != hipSuccess) g->fail("local all_to_all: stream sync failed on rank " + std::to_string(rank));
         release_turn();
         g->send[rank] = d_send;
         g->recv[rank] = d_recv;
-        g->barrier();                                   // every rank's send buffer is complete and published
+        bool ok = g->barrier(timeout_ms, rank);         // every rank's send buffer is complete and published
         take_turn();
-        int st = PM_OK;
-        for (int p = 0; p < world && !g->failed; ++p) {
+        for (int p = 0; p < world && ok && !g->failed; ++p) {
             const uint8_t *src = (const uint8_t *)g->send[p] + (size_t)rank * bytes;
-            if (hipMemcpyAsync((uint8_t *)d_recv + (size_t)p * bytes, src, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
-                err = "local all_to_all: copy failed";
-                g->failed = true;
-            }
+            if (hipMemcpyAsync((uint8_t *)d_recv + (size_t)p * bytes, src, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                g->fail("local all_to_all: copy failed on rank " + std::to_string(rank));
         }
-        if (hipStreamSynchronize(stream) != hipSuccess) g->failed = true;
+        if (hipStreamSynchronize(stream) != hipSuccess) g->fail("local all_to_all: stream sync failed on rank " + std::to_string(rank));
         release_turn();
-        g->barrier();                                   // nobody reuses a send buffer before every peer has read it
+        ok = g->barrier(timeout_ms, rank) && ok;        // nobody reuses a send buffer before every peer has read it
         take_turn();
-        if (g->failed) st = PM_ERR_HIP;
-        return st;
+        return ok && !g->failed ? (int)PM_OK : dead();
     }
     int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t) override {
+        if (g->failed) return dead();
         release_turn();
         g->send[rank] = send_h;
-        g->barrier();
-        for (int p = 0; p < world; ++p) memcpy((uint8_t *)recv_h + (size_t)p * bytes, g->send[p], bytes);
-        g->barrier();
+        bool ok = g->barrier(timeout_ms, rank);
+        if (ok)
+            for (int p = 0; p < world; ++p) memcpy((uint8_t *)recv_h + (size_t)p * bytes, g->send[p], bytes);
+        ok = g->barrier(timeout_ms, rank) && ok;
         take_turn();
-        return g->failed ? PM_ERR_HIP : PM_OK;
+        return ok && !g->failed ? (int)PM_OK : dead();
     }
 };
 
@@ -122,6 +160,8 @@ struct RcclApi {
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, Id128, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
+    int (*CommGetAsyncError)(void *, int *) = nullptr;
     int (*AllToAll)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -137,14 +177,16 @@ static RcclApi *rccl_api() {
             if (api.lib) break;
         }
         if (!api.lib) { api.err = std::string("librccl not found: ") + dlerror(); return; }
-        auto sym = [&](const char *n) {
+        auto sym = [&](const char *n, bool required = true) {
             void *p = dlsym(api.lib, n);
-            if (!p && api.err.empty()) api.err = std::string("librccl lacks ") + n;
+            if (!p && required && api.err.empty()) api.err = std::string("librccl lacks ") + n;
             return p;
         };
         api.GetUniqueId = (int (*)(void *))sym("ncclGetUniqueId");
         api.CommInitRank = (int (*)(void **, int, Id128, int))sym("ncclCommInitRank");
         api.CommDestroy = (int (*)(void *))sym("ncclCommDestroy");
+        api.CommAbort = (int (*)(void *))sym("ncclCommAbort", false);
+        api.CommGetAsyncError = (int (*)(void *, int *))sym("ncclCommGetAsyncError", false);
         api.AllToAll = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))sym("ncclAllToAll");
         api.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))sym("ncclAllGather");
         api.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
@@ -157,54 +199,169 @@ struct RcclComm : pm_comm {
     void *comm = nullptr;
     int device = 0;
     hipStream_t side = nullptr;     // stream of the small host all-gathers
-    void *d_stage = nullptr;        // device staging of the host all-gather: [send | world x recv]
+    // staging of the host all-gather, [send | world x recv] on both sides; the host side is PINNED so that the two copies
+    // are real asynchronous DMA transfers and the call costs one stream synchronisation
+    void *d_stage = nullptr, *h_stage = nullptr;
     size_t stage_bytes = 0;
+    // watchdog: an event behind every collective; the thread polls the oldest one
+    static constexpr int RING = 32;
+    hipEvent_t ring[RING] = {};
+    int ring_next = 0;
+    struct Watch { hipEvent_t ev; std::chrono::steady_clock::time_point deadline; };
+    std::deque<Watch> pending;
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::thread wd;
+    bool stop = false, aborted = false;
+    const char *kind() const override { return "rccl"; }
     int fail(const char *what, int rc) {
         RcclApi *a = rccl_api();
         err = std::string(what) + ": " + (a->GetErrorString ? a->GetErrorString(rc) : "rccl error");
-        return PM_ERR_HIP;
+        failed = true;
+        return PM_ERR_COMM;
+    }
+    int dead() { return PM_ERR_COMM; }
+    void abort_comm(const std::string &why) {          // under wmu
+        if (aborted) return;
+        aborted = true;
+        if (!failed.exchange(true)) err = why;
+        fprintf(stderr, "[pm_comm rank %d] %s -- aborting the RCCL communicator\n", rank, why.c_str());
+        if (comm && rccl_api()->CommAbort) rccl_api()->CommAbort(comm);
+    }
+    void abort(const char *why) override {
+        std::unique_lock<std::mutex> lk(wmu);
+        abort_comm(std::string("rank ") + std::to_string(rank) + " aborted: " + (why ? why : ""));
+    }
+    void watchdog() {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(wmu);
+        for (;;) {
+            wcv.wait(lk, [&] { return stop || !pending.empty(); });
+            if (stop) return;
+            const Watch w = pending.front();
+            lk.unlock();
+            const hipError_t q = hipEventQuery(w.ev);
+            int async = 0;
+            if (rccl_api()->CommGetAsyncError && comm && !aborted) (void)rccl_api()->CommGetAsyncError(comm, &async);
+            lk.lock();
+            if (stop) return;
+            if (q == hipSuccess) {
+                if (!pending.empty() && pending.front().ev == w.ev) pending.pop_front();
+                continue;
+            }
+            if (async != 0) {
+                abort_comm(std::string("asynchronous RCCL error: ") + (rccl_api()->GetErrorString ? rccl_api()->GetErrorString(async) : "?"));
+                pending.clear();
+            } else if (q != hipErrorNotReady) {
+                abort_comm("a collective's completion event failed (device error)");
+                pending.clear();
+            } else if (std::chrono::steady_clock::now() > w.deadline) {
+                abort_comm("a collective did not complete within " + std::to_string(timeout_ms) + " ms (peer dead or stalled)");
+                pending.clear();
+            } else {
+                wcv.wait_for(lk, std::chrono::milliseconds(5));
+            }
+        }
+    }
+    void watch(hipStream_t stream) {                     // behind a collective just enqueued on `stream`
+        std::unique_lock<std::mutex> lk(wmu);
+        hipEvent_t ev = ring[ring_next];
+        ring_next = (ring_next + 1) % RING;
+        for (auto it = pending.begin(); it != pending.end();)   // the ring wrapped: that entry is re-armed below
+            it = it->ev == ev ? pending.erase(it) : it + 1;
+        if (hipEventRecord(ev, stream) != hipSuccess) return;
+        pending.push_back(Watch{ev, std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms)});
+        wcv.notify_all();
+    }
+    int start() {
+        for (int i = 0; i < RING; ++i)
+            if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) return PM_ERR_HIP;
+        try {
+            wd = std::thread([this] { watchdog(); });
+        } catch (const std::system_error &) {
+            return PM_ERR_STATE;
+        }
+        return PM_OK;
     }
     ~RcclComm() override {
+        {
+            std::unique_lock<std::mutex> lk(wmu);
+            stop = true;
+            wcv.notify_all();
+        }
+        if (wd.joinable()) wd.join();
         (void)hipSetDevice(device);
-        if (comm) rccl_api()->CommDestroy(comm);
+        if (comm && !aborted) rccl_api()->CommDestroy(comm);
+        for (int i = 0; i < RING; ++i)
+            if (ring[i]) (void)hipEventDestroy(ring[i]);
         if (d_stage) (void)hipFree(d_stage);
+        if (h_stage) (void)hipHostFree(h_stage);
         if (side) (void)hipStreamDestroy(side);
     }
     int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
+        if (failed) return dead();
         const int rc = rccl_api()->AllToAll(d_send, d_recv, bytes, NCCL_UINT8, comm, stream);
-        return rc ? fail("ncclAllToAll", rc) : PM_OK;
+        if (rc) return fail("ncclAllToAll", rc);
+        watch(stream);
+        return PM_OK;
     }
     int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t stream) override {
+        if (failed) return dead();
         hipStream_t side = stream ? stream : this->side;
         const size_t need = bytes * (size_t)(world + 1);
         if (need > stage_bytes) {
             if (d_stage) (void)hipFree(d_stage);
-            d_stage = nullptr;
+            if (h_stage) (void)hipHostFree(h_stage);
+            d_stage = h_stage = nullptr;
             stage_bytes = need < 65536 ? 65536 : need;
-            if (hipMalloc(&d_stage, stage_bytes) != hipSuccess) { err = "all_gather staging allocation failed"; return PM_ERR_HIP; }
+            if (hipMalloc(&d_stage, stage_bytes) != hipSuccess || hipHostMalloc(&h_stage, stage_bytes, hipHostMallocDefault) != hipSuccess) {
+                err = "all_gather staging allocation failed";
+                stage_bytes = 0;
+                return PM_ERR_HIP;
+            }
         }
-        uint8_t *ds = (uint8_t *)d_stage, *dr = ds + bytes;
-        if (hipMemcpyAsync(ds, send_h, bytes, hipMemcpyHostToDevice, side) != hipSuccess) { err = "all_gather H2D failed"; return PM_ERR_HIP; }
+        uint8_t *ds = (uint8_t *)d_stage, *dr = ds + bytes, *hs = (uint8_t *)h_stage, *hr = hs + bytes;
+        memcpy(hs, send_h, bytes);
+        if (hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, side) != hipSuccess) { err = "all_gather H2D failed"; return PM_ERR_HIP; }
         const int rc = rccl_api()->AllGather(ds, dr, bytes, NCCL_UINT8, comm, side);
         if (rc) return fail("ncclAllGather", rc);
-        if (hipMemcpyAsync(recv_h, dr, bytes * (size_t)world, hipMemcpyDeviceToHost, side) != hipSuccess || hipStreamSynchronize(side) != hipSuccess) {
+        watch(side);
+        if (hipMemcpyAsync(hr, dr, bytes * (size_t)world, hipMemcpyDeviceToHost, side) != hipSuccess || hipStreamSynchronize(side) != hipSuccess) {
+            if (failed) return dead();
             err = "all_gather D2H failed";
             return PM_ERR_HIP;
         }
+        if (failed) return dead();                       // the watchdog ended the wait: the bytes are not the peers'
+        memcpy(recv_h, hr, bytes * (size_t)world);
         return PM_OK;
     }
 };
 
 // ------------------------------------------------------------------------------------------------ callbacks
+// Deadlines are the transport's own here (torch.distributed: the process group's timeout); a failing callback makes the
+// communicator fail for good, like the others.
 struct CallbackComm : pm_comm {
     pm_comm_ops ops;
+    const char *kind() const override { return "callbacks"; }
+    int done(int st, const char *what) {
+        if (st != PM_OK && !failed.exchange(true)) err = std::string(what) + " callback failed with status " + std::to_string(st);
+        return st == PM_OK ? (int)PM_OK : (int)PM_ERR_COMM;
+    }
     int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
-        return ops.all_to_all ? ops.all_to_all(ops.user, d_send, d_recv, bytes, (void *)stream) : (int)PM_ERR_INVALID_ARG;
+        if (failed) return PM_ERR_COMM;
+        return ops.all_to_all ? done(ops.all_to_all(ops.user, d_send, d_recv, bytes, (void *)stream), "all_to_all") : (int)PM_ERR_INVALID_ARG;
     }
     int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t) override {
-        return ops.all_gather ? ops.all_gather(ops.user, send_h, recv_h, bytes) : (int)PM_ERR_INVALID_ARG;
+        if (failed) return PM_ERR_COMM;
+        return ops.all_gather ? done(ops.all_gather(ops.user, send_h, recv_h, bytes), "all_gather") : (int)PM_ERR_INVALID_ARG;
     }
 };
+
+static long default_timeout_ms() {
+    const char *e = getenv("PM_COMM_TIMEOUT_MS");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? v : 120000;
+}
 
 }  // namespace
 
@@ -217,6 +374,7 @@ extern "C" int pm_comm_local_create(int world, pm_comm **out /* world handles */
         c->rank = r;
         c->world = world;
         c->g = g;
+        c->timeout_ms = default_timeout_ms();
         out[r] = c;
     }
     return PM_OK;
@@ -241,8 +399,10 @@ extern "C" int pm_comm_rccl_create(const void *unique_id_128_bytes, int rank, in
     c->device = device;
     Id128 id;
     memcpy(id.b, unique_id_128_bytes, 128);
-    if (a->CommInitRank(&c->comm, world, id, rank)) return PM_ERR_HIP;
+    c->timeout_ms = default_timeout_ms();
+    if (a->CommInitRank(&c->comm, world, id, rank)) return PM_ERR_COMM;
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return PM_ERR_HIP;
+    PM_TRY(c->start());
     *out = c.release();
     return PM_OK;
 }
@@ -253,6 +413,7 @@ extern "C" int pm_comm_from_callbacks(const pm_comm_ops *ops, int rank, int worl
     c->rank = rank;
     c->world = world;
     c->ops = *ops;
+    c->timeout_ms = default_timeout_ms();
     *out = c;
     return PM_OK;
 }
@@ -267,6 +428,18 @@ extern "C" double pm_comm_busy_ms(pm_comm *c, int reset) {
     return v;
 }
 extern "C" const char *pm_comm_last_error(const pm_comm *c) { return c ? c->err.c_str() : "null comm"; }
+extern "C" const char *pm_comm_kind(const pm_comm *c) { return c ? c->kind() : "none"; }
+extern "C" int pm_comm_set_timeout_ms(pm_comm *c, long timeout_ms) {
+    if (!c || timeout_ms <= 0) return PM_ERR_INVALID_ARG;
+    c->timeout_ms = timeout_ms;
+    return PM_OK;
+}
+extern "C" int pm_comm_abort(pm_comm *c, const char *why) {
+    if (!c) return PM_ERR_INVALID_ARG;
+    c->abort(why ? why : "pm_comm_abort");
+    return PM_OK;
+}
+extern "C" int pm_comm_failed(const pm_comm *c) { return c && c->failed ? 1 : 0; }
 
 extern "C" int pm_comm_all_gather(pm_comm *c, const void *send, void *recv, size_t bytes) {
     if (!c || !send || !recv) return PM_ERR_INVALID_ARG;

@@ -230,6 +230,7 @@ struct pm_ctx {
     pm::TwiddleCache tw[8];   // the sharded prover works with log m, log n and log 2n tables of both directions
     unsigned long long tw_clock;
     pm::DevBuf scratch, flags, ntt_tmp;   // ntt_tmp: the out-of-place first / last passes of ntt_run
+    bool ntt_lds_attr[2];     // ntt.hip: the tile kernels' dynamic-LDS limit has been raised on this context's device (per curve id)
     pm_comm *comm;            // this rank's communicator (pm_ctx_set_comm); null on single-GPU contexts
     pm_worker worker;         // runs the helper context's MSM concurrently with this context's own work
     pm_ctx *aux;              // helper context (own stream + MSM workspace) for the second of two concurrent MSMs

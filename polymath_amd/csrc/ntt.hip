@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void k_ntt_first_pass(const Fp<P> *src, Fp<P> 
 // and the 2^6 p the product tolerates; they are brought back to the canonical range once, on the way out (conditional subtractions
 // of 32p ... p; in the last pass of an inverse transform the n^-1 product does it).  Elements enter and leave in the dense
 // canonical form: the results are bit-identical.
-// 256 threads and one 72 KiB tile per workgroup: two workgroups share a CU's 160 KiB (tools/lds_occupancy.hip) = 2 waves per SIMD,
-// and one workgroup's barriers and loads hide under the other's butterflies.
+// 512 threads (L28_THREADS) and one 72 KiB tile per workgroup: two workgroups share a CU's 160 KiB (tools/lds_occupancy.hip) = 4 waves
+// per SIMD, and one workgroup's barriers and loads hide under the other's butterflies.
 constexpr unsigned L28_THREADS = 512;
 constexpr unsigned L28_BPL = 1024 / L28_THREADS;   // butterflies per lane and stage of a full 2^11-element tile
 constexpr unsigned L28_EPL = 2048 / L28_THREADS;   // elements per lane of a full tile
@@ -503,11 +503,13 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         typedef typename C::FrNttRR RR;
         const Tw28<RR> *tw28 = twb.as<Tw28<RR>>();
         const size_t lds28 = ((size_t)1 << 11) * RR::N * 4;
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[C::ID]) {
+        // the raised dynamic-LDS limit is a per-DEVICE function attribute: remembered per context (a context lives on one
+        // device and runs one proof at a time), not in a process-wide flag -- a local group may span several devices and its
+        // rank threads call this concurrently
+        if (!ctx->ntt_lds_attr[C::ID]) {
             PM_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_pass28<P, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds28));
             PM_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_first_pass28<P, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds28));
-            attr_set[C::ID] = true;
+            ctx->ntt_lds_attr[C::ID] = true;
         }
         Fr scale_int;
         for (int i = 0; i < P::N; ++i) scale_int.l[i] = RR::STD2INT[i];

@@ -19,6 +19,18 @@ namespace pm {
 using pmlayout::Layout;
 using pmlayout::Segment;
 
+// a collective's status -> the phase's status (the communicator's message goes to pm_last_error)
+static int comm_status(pm_ctx *ctx, int st, const char *what) {
+    if (st) ctx->err = std::string(what) + ": " + ctx->comm->err;
+    return st;
+}
+// end of a phase: whatever the watchdog cut short must not be taken for a result
+static int comm_alive(pm_ctx *ctx) {
+    if (!ctx->comm->failed) return PM_OK;
+    ctx->err = "communicator failed: " + ctx->comm->err;
+    return PM_ERR_COMM;
+}
+
 // omega^e from the half-size table tw[j] = omega^j, j < n/2 (omega^(n/2) = -1)
 template <class P>
 __device__ __forceinline__ Fp<P> tw_pow(const Fp<P> *tw, uint64_t n, uint64_t e) {
@@ -175,8 +187,7 @@ static int dist_intt(pm_ctx *ctx, const pm_pk *pk, const Layout &L, Fp<typename 
     while (((uint64_t)1 << log_m) < L.m) ++log_m;
     PM_TRY(ntt_run<C>(ctx, x, log_m, true));                                    // N local transforms (this rank's), scaled by 1/m
     StageTimer t(ctx, T_NTT);
-    const int st = ctx->comm->all_to_all(x, tmp, (size_t)L.B * sizeof(Fr), ctx->stream);   // block p -> rank p
-    if (st) { ctx->err = "all_to_all: " + ctx->comm->err; return st; }
+    PM_TRY(comm_status(ctx, ctx->comm->all_to_all(x, tmp, (size_t)L.B * sizeof(Fr), ctx->stream), "all_to_all"));   // block p -> rank p
     const Fr *rf = nullptr, *ri = nullptr, *tw = nullptr;
     PM_TRY(shard_roots<C>(ctx, pk, &rf, &ri));
     PM_TRY(twiddles_get<C>(ctx, pk->log_n, true, &tw));
@@ -202,8 +213,7 @@ static int dist_ntt(pm_ctx *ctx, const pm_pk *pk, const Layout &L, const Fp<type
         hipLaunchKernelGGL(k_cross_dft<P>, dim3(nblk(L.m)), dim3(256), 0, ctx->stream, y, tmp, rf, L.N, L.B, tw, L.n, (uint64_t)L.q * L.B, 0,
                            1, Fr::one(), 0);
         PM_HIP(ctx, hipGetLastError());
-        const int st = ctx->comm->all_to_all(tmp, x, (size_t)L.B * sizeof(Fr), ctx->stream);   // block r -> rank r
-        if (st) { ctx->err = "all_to_all: " + ctx->comm->err; return st; }
+        PM_TRY(comm_status(ctx, ctx->comm->all_to_all(tmp, x, (size_t)L.B * sizeof(Fr), ctx->stream), "all_to_all"));   // block r -> rank r
     }
     return ntt_run<C>(ctx, x, log_m, false);
 }
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(256) void k_phase2_pack(const Fp<P> *partials, unsi
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = sh[0];
-    if (threadIdx.x < L.N) out[1 + threadIdx.x] = u[(uint64_t)threadIdx.x * L.B + L.B - 1];
+    for (unsigned k1 = threadIdx.x; k1 < L.N; k1 += 256) out[1 + k1] = u[(uint64_t)k1 * L.B + L.B - 1];   // any N (layout_ok allows > 256)
 }
 
 // ----------------------------------------------------------------------------------- division scan (phase 3)
@@ -424,17 +434,29 @@ static int require_comm(pm_ctx *ctx, const pm_pk *pk) {
 static int flags_or(pm_ctx *ctx, unsigned *flags) {
     const int W = ctx->comm->world;
     std::vector<unsigned> all(W);
-    const int st = ctx->comm->all_gather(flags, all.data(), sizeof(unsigned), ctx->stream);
-    if (st) { ctx->err = "all_gather: " + ctx->comm->err; return st; }
+    PM_TRY(comm_status(ctx, ctx->comm->all_gather(flags, all.data(), sizeof(unsigned), ctx->stream), "all_gather"));
     for (int r = 0; r < W; ++r) *flags |= all[r];
     return PM_OK;
 }
 
-struct PhaseEnd {   // a phase runs holding the turn and every return path hands it on (local serialised emulation); no-op for RCCL
+// One per phase.  (i) A phase runs holding the turn and every return path hands it on (local serialised emulation; no-op
+// for RCCL).  (ii) Fail-fast: a return that was not marked `agreed` -- i.e. anything but success or a status every rank
+// derives from the same exchanged flags -- is a failure the peers cannot know of (HIP error, allocation, layout mismatch):
+// the communicator is aborted so that they leave their next collective with PM_ERR_COMM instead of waiting for ever.
+struct PhaseEnd {
+    pm_ctx *ctx;
     pm_comm *c;
-    explicit PhaseEnd(pm_comm *cc) : c(cc) { if (c) c->phase_begin(); }
-    ~PhaseEnd() { if (c) c->phase_end(); }
+    const char *name;
+    bool agreed = false;
+    PhaseEnd(pm_ctx *x, const char *nm) : ctx(x), c(x->comm), name(nm) { if (c) c->phase_begin(); }
+    int ok(int status) { agreed = true; return status; }
+    ~PhaseEnd() {
+        if (!c) return;
+        if (!agreed && !c->failed) c->abort((std::string(name) + " failed locally: " + ctx->err).c_str());
+        c->phase_end();
+    }
 };
+
 
 // ------------------------------------------------------------------------------------------------- phase 1
 template <class C>
@@ -443,9 +465,9 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
     PM_TRY(require_comm(ctx, pk));
-    PhaseEnd phase_end(ctx->comm);
+    PhaseEnd phase_end(ctx, "phase 1");
     const uint64_t n = pk->n, m0 = pk->m0, mw = pk->mw, nr = pk->nr, Lz = 2 * m0 + mw + nr;
-    if (pk->log_n + 1 > (unsigned)C::TWO_ADICITY) return PM_ERR_DOMAIN_TOO_LARGE;   // prover.rs:317
+    if (pk->log_n + 1 > (unsigned)C::TWO_ADICITY) return phase_end.ok(PM_ERR_DOMAIN_TOO_LARGE);   // prover.rs:317 -- the key's shape: all ranks
     const Layout L = pmlayout::make_layout(n, (uint32_t)pk->shard_count, (uint32_t)pk->shard_rank);
     const uint64_t m = L.m, B = L.B;
     const uint32_t N = L.N, q = L.q;
@@ -570,8 +592,8 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     PM_HIP(ctx, hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
     PM_HIP(ctx, hipStreamSynchronize(st));
     PM_TRY(flags_or(ctx, &hflags));
-    if (hflags & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
-    if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
+    if (hflags & 1u) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);                 // prover.rs:108 -- the same flags on every rank
+    if ((hflags & 2u) || !(hflags & 4u)) return phase_end.ok(PM_ERR_DEGREE_BOUND);   // prover.rs:107
     if (a_early) {
         const int st_c = msm_resident<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
         helper.join();
@@ -584,8 +606,9 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     }
     t_phase.stop();
     timing_flush(ctx);
+    PM_TRY(comm_alive(ctx));
     ctx->phase = 1;
-    return PM_OK;
+    return phase_end.ok(PM_OK);
 }
 
 // ------------------------------------------------------------------------------------------------- phase 2
@@ -596,7 +619,7 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
     if (ctx->phase < 1 || !ctx->pk) return PM_ERR_STATE;
     const pm_pk *pk = ctx->pk;
     PM_TRY(require_comm(ctx, pk));
-    PhaseEnd phase_end(ctx->comm);
+    PhaseEnd phase_end(ctx, "phase 2");
     const Layout L = pmlayout::make_layout(pk->n, (uint32_t)pk->shard_count, (uint32_t)pk->shard_rank);
     hipStream_t st = ctx->stream;
     const Fr x1 = load_fr<P>(x1_in);
@@ -614,8 +637,7 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
     std::vector<Fr> mine(rec), all(rec * L.N);
     PM_HIP(ctx, hipMemcpyAsync(mine.data(), out, rec * sizeof(Fr), hipMemcpyDeviceToHost, st));
     PM_HIP(ctx, hipStreamSynchronize(st));
-    const int rc = ctx->comm->all_gather(mine.data(), all.data(), rec * sizeof(Fr), st);
-    if (rc) { ctx->err = "all_gather: " + ctx->comm->err; return rc; }
+    PM_TRY(comm_status(ctx, ctx->comm->all_gather(mine.data(), all.data(), rec * sizeof(Fr), st), "all_gather"));
     Fr sum = Fr::zero();
     for (uint32_t r = 0; r < L.N; ++r) sum = add<P>(sum, all[r * rec]);
     memcpy(u_at_x1, sum.l, sizeof(Fr));
@@ -629,8 +651,9 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
     PM_HIP(ctx, ctx->halo.reserve(L.N * sizeof(Fr)));
     PM_HIP(ctx, hipMemcpyAsync(ctx->halo.p, halo.data(), L.N * sizeof(Fr), hipMemcpyHostToDevice, st));
     PM_HIP(ctx, hipStreamSynchronize(st));
+    PM_TRY(comm_alive(ctx));
     ctx->phase = 2;
-    return PM_OK;
+    return phase_end.ok(PM_OK);
 }
 
 // ------------------------------------------------------------------------------------------------- phase 3
@@ -642,7 +665,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     if (ctx->phase < 2 || !ctx->pk) return PM_ERR_STATE;            // the halo coefficients come from phase 2's exchange
     const pm_pk *pk = ctx->pk;
     PM_TRY(require_comm(ctx, pk));
-    PhaseEnd phase_end(ctx->comm);
+    PhaseEnd phase_end(ctx, "phase 3");
     hipStream_t st = ctx->stream;
     if (!ctx->keep_timings) timing_reset(ctx);
     TimingGuard timing_guard{ctx};
@@ -670,8 +693,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
         PM_HIP(ctx, hipMemcpyAsync(hV.data(), V, S * sizeof(Fr), hipMemcpyDeviceToHost, st));
     }
     PM_HIP(ctx, hipStreamSynchronize(st));
-    const int rc = ctx->comm->all_gather(hV.data(), hall.data(), SS * sizeof(Fr), st);
-    if (rc) { ctx->err = "all_gather: " + ctx->comm->err; return rc; }
+    PM_TRY(comm_status(ctx, ctx->comm->all_gather(hV.data(), hall.data(), SS * sizeof(Fr), st), "all_gather"));
     // the chain over ALL segments in descending index order: H_b(s) = carry into s; H_a(s) = V_s + x1^(b-a) H_b(s)
     Fr Hb = Fr::zero();
     {
@@ -685,7 +707,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
             Hb = add<P>(hall[(size_t)e.rank * SS + e.idx], mul<P>(pow_val, Hb));
         }
     }
-    if (!Hb.is_zero()) return PM_ERR_REMAINDER_NONZERO;               // prover.rs:221 -- the same value on every rank
+    if (!Hb.is_zero()) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);   // prover.rs:221 -- the same value on every rank
     {
         StageTimer t(ctx, T_POLY);
         PM_HIP(ctx, hipMemcpyAsync(carry, hcarry.data(), S * sizeof(Fr), hipMemcpyHostToDevice, st));
@@ -696,8 +718,9 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     PM_TRY(msm_resident<C>(ctx, pk, 2, qv, d_xy, d_inf));              // [d]_1 = M8, prover.rs:229
     t_phase.stop();
     timing_flush(ctx);
+    PM_TRY(comm_alive(ctx));
     ctx->phase = 3;
-    return PM_OK;
+    return phase_end.ok(PM_OK);
 }
 
 #define PM_INST_SH(C)                                                                                                               \

@@ -136,10 +136,11 @@ class TorchComm:
             return 8
 
 
-def make_comm(rank, world, device, native=True):
+def make_comm(rank, world, device, native=True, timeout_s=60):
     """This rank's pm_comm for a torch.distributed job.  native: RCCL inside the library (rank 0's unique id travels
-    over torch.distributed); every rank learns whether ALL ranks succeeded, otherwise all fall back to TorchComm.
-    -> (api.Comm, description)."""
+    over torch.distributed, whatever its backend); every rank learns whether ALL ranks succeeded, otherwise all fall back to
+    TorchComm.  -> (api.Comm, description, info) with info = {"kind", "ranks_seen", "fallback_reason"}: `ranks_seen` is
+    the number of distinct ranks whose tag came back from an all-gather over the communicator that will carry the proofs."""
     import torch
     import torch.distributed as dist
     from . import api
@@ -149,19 +150,22 @@ def make_comm(rank, world, device, native=True):
         flag = torch.tensor([int(ok)], dtype=torch.int32, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return int(flag.item()) == 1
+    reason = None if native else "not requested"
     if native:
         uid = None
         try:
             uid = api.Comm.rccl_unique_id()              # every rank: proves librccl loads here (rank 0's id is the one used)
-        except Exception:       # noqa: BLE001 -- the fallback below is the handling
-            uid = None
+        except Exception as e:       # noqa: BLE001 -- the fallback below is the handling
+            uid, reason = None, "librccl not loadable: %s" % e
         if all_ok(uid is not None):                       # nobody enters ncclCommInitRank unless everybody can
             box = [uid if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm, ok = None, False
             try:
                 comm = api.Comm.rccl(box[0], rank, world, device)
+                comm.set_timeout_ms(timeout_s * 1000)
                 probe = comm.all_gather(np.array([rank], dtype=np.int64))
+                seen = len(set(probe.reshape(-1).tolist()) & set(range(world)))
                 ok = probe.reshape(-1).tolist() == list(range(world))
                 if ok:
                     # the transforms rely on the block order of the all-to-all (block p -> rank p, block r <- rank r): check it
@@ -173,8 +177,19 @@ def make_comm(rank, world, device, native=True):
                     comm.all_to_all_device(send.data_ptr(), recv.data_ptr(), 64, torch.cuda.current_stream(dev).cuda_stream)
                     torch.cuda.synchronize(dev)
                     ok = recv.cpu().reshape(world, 8)[:, 0].tolist() == [r * world + rank for r in range(world)]
-            except Exception:   # noqa: BLE001
-                ok = False
+                    if not ok:
+                        reason = "all-to-all block order check failed"
+                else:
+                    reason = "all-gather probe returned %s" % probe.reshape(-1).tolist()
+            except Exception as e:   # noqa: BLE001
+                ok, reason = False, "RCCL communicator: %s" % e
             if all_ok(ok):
-                return comm, "rccl (native: ncclAllToAll / ncclAllGather inside the library)"
-    return TorchComm(rank, world).comm, "torch.distributed callbacks (%s), host-staged" % dist.get_backend()
+                return comm, "rccl (native: ncclAllToAll / ncclAllGather inside the library)", {"kind": comm.kind, "ranks_seen": seen, "fallback_reason": None}
+            reason = reason or "a peer could not use RCCL"
+        else:
+            reason = reason or "a peer could not load librccl"
+    tc = TorchComm(rank, world)
+    probe = tc.comm.all_gather(np.array([rank], dtype=np.int64))
+    seen = len(set(probe.reshape(-1).tolist()) & set(range(world)))
+    return tc.comm, "torch.distributed callbacks (%s), host-staged" % dist.get_backend(), \
+        {"kind": "%s over torch.distributed/%s" % (tc.comm.kind, dist.get_backend()), "ranks_seen": seen, "fallback_reason": reason}

@@ -171,20 +171,49 @@ inline typename PairingOf<C>::type::G2 deser_g2_c(Reader &rd) {
         g.inf = (b[2 * NB - 1] & 0x40) != 0;
         larger = (b[2 * NB - 1] & 0x80) != 0;
     }
-    if (g.inf) { g.x = g.y = typename B::Fq2{B::Fq::zero(), B::Fq::zero()}; return g; }
+    if (C::ID != 0 && g.inf && larger) throw WireError("G2: both flag bits set");                 // SWFlags::from_u8 -> None
+    if (g.inf) {
+        // canonical infinity only: the flag with every other bit and byte zero (ark-bls12-381 read_g2_compressed checks x == 0;
+        // a sign bit next to the infinity flag is EncodingFlags' InvalidData)
+        for (int i = 0; i < 2 * NB; ++i) {
+            const uint8_t v = C::ID == 0 ? (i == 0 ? (uint8_t)(b[0] & 0x3F) : b[i]) : (i == 2 * NB - 1 ? (uint8_t)(b[i] & 0x3F) : b[i]);
+            if (v) throw WireError("G2: non-canonical encoding of the point at infinity");
+        }
+        g.x = g.y = typename B::Fq2{B::Fq::zero(), B::Fq::zero()};
+        return g;
+    }
     const bool ok = C::ID == 0 ? (get_fq<Q>(b, true, 0x1F, g.x.c1) && get_fq<Q>(b + NB, true, 0xFF, g.x.c0))
                                : (get_fq<Q>(b, false, 0xFF, g.x.c0) && get_fq<Q>(b + NB, false, 0x3F, g.x.c1));
     if (!ok) throw WireError("G2: coordinate >= p");
     typename B::Fq2 rhs = B::add2(B::mul2(B::mul2(g.x, g.x), g.x), B::twist_b());
     if (!Fq2OpsT<C>::sqrt(rhs, g.y)) throw WireError("G2: not on the twist");
     if (Fq2OpsT<C>::gt(g.y, B::neg2(g.y)) != larger) g.y = B::neg2(g.y);
+    // Validate::Yes (what deserialize_compressed means): the twist has a cofactor on both curves, so a point of E'(Fq2) need not
+    // lie in G2 -- and the pairing is only defined there.  [r] Q == O.
+    if (!B::g2_mul(g, C::FrP::MOD, C::FrP::N).inf) throw WireError("G2: not in the prime-order subgroup");
     return g;
 }
 inline void ser_g2(const Bls12Pairing::G2 &g, Bytes &out) { ser_g2_c<pm::BlsCurve>(g, out); }
 inline Bls12Pairing::G2 deser_g2(Reader &rd) { return deser_g2_c<pm::BlsCurve>(rd); }
 
+// [r] P == O on E(Fq).  BN254's G1 has cofactor 1 (every curve point is in the group); BLS12-381's has cofactor
+// 0x396c8c005555e1568c00aaab0000aaab, so a point on the curve need not be in G1.
 template <class C>
-G1Point<C> deser_g1(Reader &rd) {
+inline bool g1_in_subgroup(const G1Point<C> &g) {
+    if (C::ID != 0 || g.inf) return true;
+    pm::XYZZ<C> acc = pm::XYZZ<C>::identity();
+    for (int i = C::FrP::N - 1; i >= 0; --i)
+        for (int b = 31; b >= 0; --b) {
+            acc = pm::xyzz_dbl<C>(acc);
+            if ((C::FrP::MOD[i] >> b) & 1) pm::xyzz_madd<C>(acc, g.p, false);
+        }
+    return acc.is_identity();
+}
+
+// validate = ark-serialize's Validate::Yes (deserialize_compressed: on the curve AND in the prime-order subgroup); false =
+// deserialize_compressed_unchecked's subgroup part only -- the curve equation is always enforced by decompression.
+template <class C>
+G1Point<C> deser_g1(Reader &rd, bool validate = true) {
     typedef typename C::FqP Q;
     const int NB = Q::N * 4;
     const uint8_t *b = rd.take(NB);
@@ -204,7 +233,14 @@ G1Point<C> deser_g1(Reader &rd) {
         memcpy(le, b, NB);
         le[NB - 1] &= 0x3F;
     }
-    if (g.inf) return g;
+    if (C::ID != 0 && g.inf && larger) throw WireError("G1: both flag bits set");                 // SWFlags::from_u8 -> None
+    if (g.inf) {
+        // canonical infinity only (ark-bls12-381 read_g1_compressed: x must be 0; EncodingFlags: no sign bit with infinity)
+        if (larger) throw WireError("G1: sign bit on the point at infinity");
+        for (int i = 0; i < NB; ++i)
+            if (le[i]) throw WireError("G1: non-canonical encoding of the point at infinity");
+        return g;
+    }
     pm::Fp<Q> x;
     memcpy(x.l, le, NB);
     for (int i = Q::N - 1; i >= 0; --i) {
@@ -218,6 +254,7 @@ G1Point<C> deser_g1(Reader &rd) {
     if (!fq_sqrt<Q>(rhs, y)) throw WireError("G1: not on the curve");
     if ((fq_cmp<Q>(y, pm::neg<Q>(y)) > 0) != larger) y = pm::neg<Q>(y);
     g.p.y = y;
+    if (validate && !g1_in_subgroup<C>(g)) throw WireError("G1: not in the prime-order subgroup");
     return g;
 }
 
@@ -320,7 +357,9 @@ struct WireKey {
         return out;
     }
 
-    static WireKey parse(const uint8_t *data, size_t len) {
+    // validate: the subgroup check on every base point, as deserialize_compressed does (Validate::Yes); false =
+    // deserialize_compressed_unchecked for the vectors (a 2^20-gate key holds 27 M points: 255 doublings each)
+    static WireKey parse(const uint8_t *data, size_t len, bool validate = true) {
         static_assert(C::ID == 0, "the reference instantiates Bls12_381 only (Cargo.toml:35); G2 codecs are BLS12-381");
         Reader rd(data, len);
         WireKey k;
@@ -335,7 +374,7 @@ struct WireKey {
             const uint64_t cnt = rd.u64();
             if (cnt > (len - rd.off) / (C::FqP::N * 4)) throw WireError("truncated key");
             k.vec[which].reserve(cnt);
-            for (uint64_t i = 0; i < cnt; ++i) k.vec[which].push_back(deser_g1<C>(rd));
+            for (uint64_t i = 0; i < cnt; ++i) k.vec[which].push_back(deser_g1<C>(rd, validate));
         }
         if (rd.off != len) throw WireError("trailing bytes after the key");
         return k;

@@ -1,0 +1,179 @@
+"""Process supervision for multi-GPU runs of bench.py (one process per GPU).
+
+The reference is single-process CPU code (prover.rs:66-237), so nothing here has a counterpart in it.  Rules this file
+exists to keep (they come from the GPU pool, not from taste):
+  * a process that has touched the GPU never exec()s another program -- ranks are CHILD processes of a parent that has made
+    no GPU call (this module imports neither torch nor the HIP library);
+  * a dead or stalled rank must end the job with a non-zero exit, not a hang: children run in their own process groups,
+    the supervisor kills all of them when one fails or when the attempt's deadline passes;
+  * the first contact with N real GPUs should produce a number: the exchange layer is tried in order of preference
+    (ATTEMPTS) and the first configuration in which every rank finishes wins.  Rank 0 prints its JSON line only at the very
+    end of a successful attempt, so a failed attempt leaves nothing on stdout.
+
+Two ways in:
+  python bench.py --gpus N            -> supervise_all(): this process spawns the N ranks itself;
+  torchrun ... bench.py --gpus N      -> supervise_one(): every torchrun worker supervises ONE child (its rank); retries are
+                                         agreed without talking: a failing child takes its peers down (fail-fast
+                                         collectives, process-group timeouts), so every supervisor sees a failure and moves
+                                         to the same next attempt, which meets on its own TCP store port.
+"""
+import os
+import signal
+import socket
+import subprocess
+import sys
+import time
+
+# (torch.distributed backend, exchange layer inside the library)
+ATTEMPTS = [
+    ("nccl", "rccl"),        # everything over RCCL/xGMI: the production form
+    ("gloo", "rccl"),        # barrier/rendezvous over gloo, the data path still RCCL inside the library
+    ("nccl", "callbacks"),   # all-to-all staged through the host over torch.distributed
+    ("gloo", "callbacks"),
+]
+
+
+def attempts_from_env(env):
+    """A caller that pins the backend (tests: several ranks on one GPU over gloo) gets exactly that configuration."""
+    if env.get("BENCH_DIST_BACKEND") or env.get("BENCH_NO_RCCL"):
+        backend = env.get("BENCH_DIST_BACKEND", "nccl")
+        return [(backend, "callbacks" if env.get("BENCH_NO_RCCL") or backend != "nccl" else "rccl")]
+    return list(ATTEMPTS)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _log(msg):
+    print("[launch] " + msg, file=sys.stderr, flush=True)
+
+
+def _kill(procs):
+    for p in procs:
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+    t_end = time.time() + 10
+    for p in procs:
+        while p.poll() is None and time.time() < t_end:
+            time.sleep(0.05)
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            p.wait()
+
+
+def _run_attempt(cmd, envs, deadline_s):
+    """Start one child per env; -> (ok, description).  All children are dead on return."""
+    procs = [subprocess.Popen(cmd, env=e, start_new_session=True) for e in envs]
+
+    def on_term(signum, _frame):
+        _kill(procs)
+        os._exit(128 + signum)
+    old = {s: signal.signal(s, on_term) for s in (signal.SIGTERM, signal.SIGINT)}
+    t0 = time.time()
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                _kill(procs)
+                return False, "child %d exited with code %d" % bad[0]
+            if all(c == 0 for c in codes):
+                return True, "ok"
+            if time.time() - t0 > deadline_s:
+                _kill(procs)
+                return False, "deadline of %d s passed" % deadline_s
+            time.sleep(0.05)
+    finally:
+        _kill(procs)
+        for s, h in old.items():
+            signal.signal(s, h)
+
+
+def _child_env(base, rank, local, world, port, attempt, backend, exchange, own_store):
+    e = dict(base)
+    e.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+             BENCH_CHILD="1", BENCH_ATTEMPT=str(attempt), BENCH_DIST_BACKEND=backend)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: without it RCCL's ipc handles fail on this driver
+    if exchange == "callbacks":
+        e["BENCH_NO_RCCL"] = "1"
+    else:
+        e.pop("BENCH_NO_RCCL", None)
+    if own_store:                                        # rank 0's child hosts the TCP store itself
+        for k in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+            e.pop(k, None)
+    return e
+
+
+def supervise_all(script, argv, world, deadline_s=900):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks, fall back through ATTEMPTS.  -> exit code."""
+    cmd = [sys.executable, script] + list(argv)
+    why = "no attempt made"
+    for k, (backend, exchange) in enumerate(attempts_from_env(os.environ)):
+        port = free_port()
+        _log("attempt %d: %d ranks, torch.distributed=%s, exchange=%s, port %d" % (k, world, backend, exchange, port))
+        envs = [_child_env(os.environ, r, r, world, port, k, backend, exchange, True) for r in range(world)]
+        ok, why = _run_attempt(cmd, envs, deadline_s)
+        if ok:
+            return 0
+        _log("attempt %d failed: %s" % (k, why))
+    _log("all attempts failed (last: %s)" % why)
+    return 1
+
+
+def supervise_one(script, argv, deadline_s=900):
+    """A torchrun worker: supervise ONE child that does this rank's work.  -> exit code."""
+    cmd = [sys.executable, script] + list(argv)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    port0 = int(os.environ.get("MASTER_PORT", "29500"))
+    why = "no attempt made"
+    for k, (backend, exchange) in enumerate(attempts_from_env(os.environ)):
+        # attempt 0 meets on the launcher's own store; a retry needs a store no earlier attempt has written to
+        port = port0 if k == 0 else port0 + 37 * k
+        if rank == 0:
+            _log("attempt %d: %d ranks under the external launcher, torch.distributed=%s, exchange=%s, port %d" % (k, world, backend, exchange, port))
+        ok, why = _run_attempt(cmd, [_child_env(os.environ, rank, local, world, port, k, backend, exchange, k > 0)], deadline_s)
+        if ok:
+            return 0
+        _log("rank %d, attempt %d failed: %s" % (rank, k, why))
+    return 1
+
+
+class Watchdog:
+    """In a rank: exits the process (status 124) when a stage outlives its limit -- the backstop behind the library's own
+    collective deadlines (a kernel that can not be aborted, a rendezvous that never completes)."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.lock = rank, threading.Lock()
+        self.stage, self.deadline = "start", None
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def stage_begin(self, name, limit_s):
+        with self.lock:
+            self.stage, self.deadline = name, time.time() + limit_s
+
+    def stage_end(self):
+        with self.lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                late = self.deadline is not None and time.time() > self.deadline
+                stage = self.stage
+            if late:
+                print("[bench rank %d] stage '%s' exceeded its limit -- exiting 124" % (self.rank, stage), file=sys.stderr, flush=True)
+                os._exit(124)

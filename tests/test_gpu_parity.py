@@ -504,6 +504,50 @@ def test_bench_two_ranks_one_gpu_same_proof():
     assert j3["proof_bytes"] == j1["proof_bytes"] and "msm-pairs-sharded" in j3["config"]["parallelism"]
 
 
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (how the driver started round 2's bench): the parent spawns the two ranks
+    itself (polymath_amd/launch.py; here sharing the one GPU over gloo), relays rank 0's line and exits 0; the line says two
+    ranks were seen by the exchange layer and carries the single-GPU proof bytes.  `value` is the host-input metric
+     and the HBM-resident variant is reported beside it."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and j2["n_ranks_seen"] == 2 and j2["proof_bytes"] == j1["proof_bytes"] and j2["proof_verified"]
+    assert j2["launch"]["supervised"] and "callbacks" in j2["exchange"]["kind"]
+    for j in (j1, j2):
+        assert abs(j["value"] - ((1 << 12) - 100) / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+        assert "HOST buffers" in j["timed_entry_point"] and j["ms_per_step_hbm_resident"] > 0
+
+
+def test_bench_dead_rank_ends_the_job_non_zero():
+    """A rank that dies in the middle of the timed proofs (test hook BENCH_TEST_DIE): the job exits NON-ZERO well inside the
+    deadline -- no hang -- and prints no JSON line.  (Transport here: gloo callbacks; the library-level deadline and abort
+    are covered by tests/test_sharded_vector.py.)"""
+    import os, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "100000", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", BENCH_TEST_DIE="1,3.0", BENCH_COMM_TIMEOUT_S="20")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode != 0
+    assert not [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert "exited with code 17" in run.stderr or "failed" in run.stderr, run.stderr[-2000:]
+    assert time.time() - t0 < 400
+
+
 def test_full_size_2p20_proof_passes_pairing_verifier(oracle):
     """BASELINE configs[1] at full size: 2^20-100 synthetic gates (n = 2^21, 29.4 M MSM pairs).  The CPU
     restatement needs minutes here, so the check is the reference's own acceptance criterion

@@ -64,6 +64,55 @@ def test_product_verifier_refuses_malformed_bytes():
         assert not api.verify("bls12_381", "merlin", vk, pub, bytes(off_curve))
     except api.PolymathError:
         pass
+    # ark's deserialize_compressed validates (Validate::Yes): points ON the curve but OUTSIDE the prime-order subgroup are
+    # refused -- the pairing is undefined there -- and so are non-canonical encodings of the point at infinity
+    from oracle.pyref import fields as F
+    c = CURVES["bls12_381"]
+    x = 1
+    while True:                         # a random curve point lies in G1 with probability 1/h ~ 2^-126: take the first x that works
+        y2 = (x * x * x + 4) % c.p
+        y = pow(y2, (c.p + 1) // 4, c.p)
+        if y * y % c.p == y2 and F.g1_add(c, F.g1_mul(c, (x, y), c.r - 1), (x, y)) is not None:     # [r] P != O
+            break
+        x += 1
+    enc = bytearray(x.to_bytes(48, "big"))
+    enc[0] |= 0x80 | (0x20 if y > c.p - y else 0)
+    outside = bytes(enc) + proof[48:]
+    with pytest.raises(api.PolymathError):
+        api.verify("bls12_381", "merlin", vk, pub, outside)
+    with pytest.raises(api.PolymathError):          # the same point as the vk's one_g1
+        api.verify("bls12_381", "merlin", bytes(enc) + vk[48:], pub, proof)
+    inf_ok = bytes([0xC0]) + bytes(47)
+    for dirty in (bytes([0xE0]) + bytes(47), bytes([0xC0]) + bytes(46) + b"\x01", bytes([0xC0, 0x01]) + bytes(46)):
+        with pytest.raises(api.PolymathError):
+            api.verify("bls12_381", "merlin", vk, pub, dirty + proof[48:])
+    assert api.verify("bls12_381", "merlin", vk, pub, inf_ok + proof[48:]) is False        # canonical infinity parses; the proof is wrong
+    # a G2 point of the vk on the twist but outside G2 (x_g2 is bytes 144..240): refused, as is a dirty G2 infinity
+    g2_inf_dirty = bytes([0xC0]) + bytes(94) + b"\x01"
+    with pytest.raises(api.PolymathError):
+        api.verify("bls12_381", "merlin", vk[:144] + g2_inf_dirty + vk[240:], pub, proof)
+    twisted = bytearray(vk[144:240])
+    for tweak in range(1, 13):          # walk x.c0 until the candidate is on the twist: it is then outside G2 (cofactor ~ 2^508)
+        cand = bytearray(twisted)
+        cand[95] = (cand[95] + tweak) & 0xFF
+        try:
+            api.verify("bls12_381", "merlin", vk[:144] + bytes(cand) + vk[240:], pub, proof)
+        except api.PolymathError:
+            continue
+        raise AssertionError("a tampered G2 x-coordinate was parsed as a member of G2")
+    # BN254 (ark-serialize's SWFlags in the top bits of the last byte): both flag bits set is not an encoding, a dirty
+    # infinity is refused, the canonical one parses
+    fxb = load_golden("proofs_bn254.json")[0]
+    vkb = _fixture_vk(api, fxb)
+    pubb = CO.fr_to_mont_limbs("bn254", [I(v) for v in fxb["instance"][1:]])
+    pb = bytes.fromhex(fxb["proofs"]["merlin"]["bytes"])
+    assert api.verify("bn254", "merlin", vkb, pubb, pb)
+    both = bytearray(pb)
+    both[31] |= 0xC0
+    for bad_a in (bytes(both[:32]), b"\x01" + bytes(30) + b"\x40", bytes(31) + b"\xC0"):
+        with pytest.raises(api.PolymathError):
+            api.verify("bn254", "merlin", vkb, pubb, bad_a + pb[32:])
+    assert api.verify("bn254", "merlin", vkb, pubb, bytes(31) + b"\x40" + pb[32:]) is False
 
 
 @pytest.mark.gpu

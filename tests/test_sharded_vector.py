@@ -73,8 +73,10 @@ def test_layout_rejects_bad_shapes():
 
 
 # ------------------------------------------------------------------------------------------------------ GPU
-def _run_ranks(N, fn):
-    """fn(rank) on N threads; re-raises the first exception."""
+def _run_ranks(N, fn, comms=None, timeout=900):
+    """fn(rank) on N threads; re-raises the first exception.  Fail-fast: a rank that raises aborts the group's communicators
+    at once (its peers leave their collective with PM_ERR_COMM instead of waiting for it), and ranks still running after
+    `timeout` seconds are aborted the same way -- a broken rank fails the test in seconds, it does not hang it."""
     errs, outs = [None] * N, [None] * N
 
     def body(r):
@@ -82,15 +84,46 @@ def _run_ranks(N, fn):
             outs[r] = fn(r)
         except BaseException as e:     # noqa: BLE001 -- reported below
             errs[r] = e
-    th = [threading.Thread(target=body, args=(r,)) for r in range(N)]
+            if comms is not None:
+                comms[r].abort("rank %d raised %s" % (r, type(e).__name__))
+    th = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(N)]
     for t in th:
         t.start()
+    import time
+    t_end = time.time() + timeout
     for t in th:
-        t.join()
-    for e in errs:
-        if e is not None:
-            raise e
+        t.join(max(0.0, t_end - time.time()))
+    if any(t.is_alive() for t in th):
+        if comms is not None:
+            for c in comms:
+                c.abort("test timeout")
+            for t in th:
+                t.join(30)
+        raise TimeoutError("ranks still running after %d s: %s" % (timeout, [r for r, t in enumerate(th) if t.is_alive()]))
+    first = [e for e in errs if e is not None and getattr(e, "status", None) != 9] or [e for e in errs if e is not None]
+    if first:
+        raise first[0]              # the root cause, not a peer's PM_ERR_COMM
     return outs
+
+
+def _oracle_reference(oracle, curve, lc, x, z, r_a, transcript="merlin"):
+    """The CPU restatement (oracle/cpp) on the same circuit, trapdoors and r_a, with ITS OWN setup: proof bytes and the
+    intermediate vectors (taps) the sharded GPU proof is compared with -- the (e)-row tests rest on the oracle, not on
+    the single-GPU path."""
+    from oracle import driver as DR
+    from oracle.pyref import serialize as SE, transcripts as T
+    import os
+    c = CURVES[curve]
+
+    class Shape:
+        pass
+    q = Shape()
+    q.m0, q.mw, q.nr = lc.m0, lc.mw, lc.nr
+    q.csr_arrays = [(a.rowptr, a.col, a.val) for a in lc.csrs]
+    opk = oracle.OraclePk(curve, q, x, z, os.cpu_count() or 4)
+    omega = oracle.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+    po = DR.prove(opk, opk.n, opk.sigma, omega, lc.instance, None, r_a, T.make_transcripts(c)[transcript], w_limbs=lc.wit_limbs)
+    return SE.ser_proof(c, po), opk
 
 
 def _sharded_proofs(curve, lc, x, z, r_a, N, transcript="merlin", device_assignment=False):
@@ -101,16 +134,17 @@ def _sharded_proofs(curve, lc, x, z, r_a, N, transcript="merlin", device_assignm
     for r in range(N):
         pms[r].ctx.set_comm(comms[r])
     pks = [pms[r].setup(lc, x, z, shard_rank=r, shard_count=N, layout="vector") for r in range(N)]
-    proofs = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a))
+    proofs = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms)
     return pms, pks, comms, proofs
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
 @pytest.mark.parametrize("N", [2, 4, 8])
-def test_vector_sharded_proof_equals_single_gpu(curve, N):
+def test_vector_sharded_proof_equals_single_gpu(oracle, curve, N):
     """5000 gates (n = 16384): every rank proves on 1/N of the rows, coefficients, scans and MSM pairs; the N proofs are
-    identical to the unsharded proof.  The shards' local vectors, scattered through the layout, equal the whole ones."""
+    identical to the CPU ORACLE's proof of the same input (oracle/cpp, its own setup) and to the unsharded GPU proof.  The
+    shards' local vectors, scattered through the layout, equal the oracle's taps."""
     from polymath_amd import api, circuits as PC
     from polymath_amd.polymath import Polymath
     c = CURVES[curve]
@@ -121,9 +155,16 @@ def test_vector_sharded_proof_equals_single_gpu(curve, N):
     ref_pk = ref_pm.setup(lc, x, z)
     ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
     n = ref_pk.n
-    whole = {w: ref_pk.tap(w, 11 * n) for w in (2, 3, 4, 5, 6, 7)}
+    oracle_proof, opk = _oracle_reference(oracle, curve, lc, x, z, r_a)
+    assert ref == oracle_proof
+    whole = {w: opk.tap(w, 11 * n) for w in (2, 3, 4, 5, 6, 7)}      # the ORACLE's vectors
+    for w in whole:
+        g_tap = ref_pk.tap(w, 11 * n)
+        k = min(len(g_tap), len(whole[w]))
+        assert np.array_equal(g_tap[:k], whole[w][:k]) and not g_tap[k:].any() and not whole[w][k:].any(), w
+        whole[w] = g_tap if len(g_tap) >= len(whole[w]) else whole[w]
     pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
-    assert all(p == ref for p in proofs)
+    assert all(p == oracle_proof for p in proofs)
     # local vectors -> global through the layout
     Lz = len(whole[6])
     for w in (2, 3, 5):                                    # u, w, wit_u: blocked coefficient layout
@@ -200,15 +241,18 @@ def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
         except PolymathProverError as e:
             return e.status
         return 0
-    assert _run_ranks(N, prove_bad) == [4] * N
-    # the contexts are still usable afterwards
-    assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a)))
+    assert _run_ranks(N, prove_bad, comms) == [4] * N
+    # the contexts AND the communicators are still usable afterwards: the verdict was exchanged, nobody aborted
+    assert not any(cm.failed for cm in comms)
+    assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms))
 
 
 @pytest.mark.gpu
-def test_vector_sharded_mid_size_and_pairs_layout_agree():
+def test_vector_sharded_mid_size_and_pairs_layout_agree(oracle):
     """2^16-100 gates on 8 ranks (B = 2048 coefficients per block, several sub-segments per stretch): the vector-sharded
-    proof, the pairs-sharded proof (vector phases replicated, pm_comm combine) and the single-GPU proof are identical."""
+    proof, the pairs-sharded proof (vector phases replicated, pm_comm combine) and the single-GPU proof are identical -- and
+    equal to the CPU oracle's proof of the same input (oracle/cpp on the bases exported from the single-GPU key: its own
+    setup is tested at the smaller sizes)."""
     from polymath_amd import api, circuits as PC
     from polymath_amd.polymath import Polymath
     curve, N = "bls12_381", 8
@@ -219,6 +263,21 @@ def test_vector_sharded_mid_size_and_pairs_layout_agree():
     ref_pm = Polymath(curve, "merlin", device=0)
     ref_pk = ref_pm.setup(lc, x, z)
     ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+    import os
+    from oracle import driver as DR
+    from oracle.pyref import serialize as SE, transcripts as T
+
+    class Shape:
+        pass
+    q = Shape()
+    q.m0, q.mw, q.nr = lc.m0, lc.mw, lc.nr
+    q.csr_arrays = [(a.rowptr, a.col, a.val) for a in lc.csrs]
+    opk = oracle.OraclePk(curve, q, None, None, os.cpu_count() or 4)
+    for i in range(6):
+        opk.import_bases(i, ref_pk.export_bases(i))
+    omega = oracle.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+    po = DR.prove(opk, opk.n, opk.sigma, omega, lc.instance, None, r_a, T.make_transcripts(c)["merlin"], w_limbs=lc.wit_limbs)
+    assert ref == SE.ser_proof(c, po)
     ref_pk.free()
     pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
     assert all(p == ref for p in proofs)
@@ -226,7 +285,127 @@ def test_vector_sharded_mid_size_and_pairs_layout_agree():
         pk.free()
     # PM_SHARD_PAIRS keys on the same contexts and communicators: the native point combine replaces the callback
     pks = [pms[r].setup(lc, x, z, shard_rank=r, shard_count=N, layout="pairs") for r in range(N)]
-    assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a)))
+    assert all(p == ref for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms))
+
+
+@pytest.mark.gpu
+def test_sharded_prover_fails_fast_instead_of_hanging():
+    """The fail-fast contract of pm_comm (include/polymath_hip.h) on the in-process group, 4 ranks:
+    (i) a rank that never shows up: its peers leave the collective with PM_ERR_COMM once the deadline passes (2 s here);
+    (ii) a rank that fails LOCALLY inside a phase (an assignment pointer of the wrong size class is not detectable, so the
+         failure is injected as a communicator abort from the host -- what PhaseEnd does on a HIP error): the peers return
+         at once, long before any deadline;
+    a failed communicator stays failed; fresh communicators on the same contexts and keys prove again."""
+    import time
+    from polymath_amd import api, circuits as PC
+    from polymath_amd.polymath import Polymath, PolymathProverError
+    curve, N = "bls12_381", 4
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, 3000)
+    g = PC.SplitMix64(0xFA57)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    assert all(p == proofs[0] for p in proofs)
+
+    def status_of(r, skip):
+        if r == skip:
+            return "absent"
+        try:
+            pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a)
+        except PolymathProverError as e:
+            return e.status
+        return 0
+    # (i) rank 2 never calls prove
+    for cm in comms:
+        cm.set_timeout_ms(2000)
+    t0 = time.time()
+    got = _run_ranks(N, lambda r: status_of(r, 2), None, timeout=120)
+    assert got == [9, 9, "absent", 9], got
+    assert 1.5 < time.time() - t0 < 60
+    assert all(comms[r].failed for r in (0, 1, 3)) and "did not reach the collective" in comms[0].last_error()
+    assert status_of(0, None) == 9                                   # sticky: no waiting this time
+    # (ii) fresh communicators, long deadline; rank 1 gives up while the others are inside phase 1
+    comms2 = api.Comm.local_group(N)
+    for r in range(N):
+        pms[r].ctx.set_comm(comms2[r])
+        comms2[r].set_timeout_ms(600000)
+
+    def body(r):
+        if r == 1:
+            time.sleep(0.2)
+            comms2[1].abort("injected failure")
+            return "aborted"
+        return status_of(r, None)
+    t0 = time.time()
+    got = _run_ranks(N, body, None, timeout=120)
+    assert got == [9, "aborted", 9, 9], got
+    assert time.time() - t0 < 30
+    assert "injected failure" in comms2[0].last_error()
+    # and the keys / contexts are fine: a third group proves
+    comms3 = api.Comm.local_group(N)
+    for r in range(N):
+        pms[r].ctx.set_comm(comms3[r])
+    again = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms3)
+    assert all(p == proofs[0] for p in again)
+    for pk in pks:
+        pk.free()
+
+
+def test_local_group_deadline_and_abort_without_a_gpu():
+    """pm_comm fail-fast on host memory only (runs on CPU): an absent rank costs its peers the deadline, not for ever; an
+    aborting rank wakes them at once; the failure is sticky and says why."""
+    import time
+    from polymath_amd import api
+    comms = api.Comm.local_group(3)
+    assert comms[0].kind == "local" and not comms[0].failed
+    for cm in comms:
+        cm.set_timeout_ms(700)
+
+    def body(r):
+        if r == 2:
+            return "absent"
+        try:
+            comms[r].all_gather(np.array([r], dtype=np.int64))
+        except api.PolymathError as e:
+            return e.status
+        return 0
+    t0 = time.time()
+    assert _run_ranks(3, body, None, timeout=60) == [9, 9, "absent"]
+    assert 0.5 < time.time() - t0 < 30 and comms[0].failed and "did not reach" in comms[1].last_error()
+    comms = api.Comm.local_group(3)                 # default deadline (120 s): the abort is what ends the wait
+
+    def body2(r):
+        if r == 2:
+            time.sleep(0.3)
+            comms[2].abort("rank 2 gives up")
+            return "aborted"
+        try:
+            comms[r].all_gather(np.array([r], dtype=np.int64))
+        except api.PolymathError as e:
+            return e.status
+        return 0
+    t0 = time.time()
+    assert _run_ranks(3, body2, None, timeout=60) == [9, 9, "aborted"]
+    assert time.time() - t0 < 20 and "rank 2 gives up" in comms[0].last_error()
+    good = api.Comm.local_group(2)
+    out = _run_ranks(2, lambda r: good[r].all_gather(np.array([r + 5], dtype=np.int64)).reshape(-1).tolist(), good)
+    assert out == [[5, 6], [5, 6]]
+
+
+def test_run_ranks_helper_reports_a_broken_rank_in_seconds():
+    """The test harness itself: a rank that raises before its first collective must fail the group at once."""
+    import time
+    from polymath_amd import api
+    comms = api.Comm.local_group(3)
+
+    def body(r):
+        if r == 0:
+            raise ValueError("broken rank")
+        return comms[r].all_gather(np.array([r], dtype=np.int64))
+    t0 = time.time()
+    with pytest.raises(ValueError):
+        _run_ranks(3, body, comms, timeout=60)
+    assert time.time() - t0 < 20
 
 
 
