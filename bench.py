@@ -284,9 +284,7 @@ def worker(args):
     x_l, w_l = r1cs.inst_limbs, r1cs.wit_limbs
     combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local, backend_gloo=(backend != "nccl")) if world > 1 and layout == "pairs" else None
     py_combine = combine            # for the phase-by-phase (Python glue) proofs
-    if multi and layout == "vector":
-        from polymath_amd.distributed import CommPointCombiner
-        py_combine = CommPointCombiner(comm, curve, pm.field.nq)   # the native path combines inside the library (ctx's pm_comm)
+    # (a PM_SHARD_VECTOR key needs no combiner at all: its phases return points already summed over the ranks)
 
     def barrier():
         if multi:

@@ -172,7 +172,11 @@ typedef enum pm_transcript { PM_TRANSCRIPT_MERLIN = 0, PM_TRANSCRIPT_KECCAK256 =
  *   w   : mw Fr, witness assignment
  *   r_a : 2 Fr, the two F::rand draws of prover.rs:110 (constant term first) -- an input so
  *         the RNG stays with the caller.
- * On a sharded pk the outputs are this shard's PARTIAL sums; combine with pm_g1_sum.
+ * On a PM_SHARD_PAIRS key the outputs are this shard's PARTIAL sums; combine with pm_g1_sum (pm_comm_combine_points).
+ * On a PM_SHARD_VECTOR key they are already the sums over all ranks: each phase ends with ONE small exchange that carries
+ * the ranks' status flags, partial points and (phase 1) the block-boundary coefficients the division needs, so every rank
+ * returns the same points and the same status.  With HOST x, w a PM_SHARD_VECTOR rank uploads only its 1/shard_count slice
+ * of w and the communicator's device all-gather delivers the rest.
  * On a non-zero status the output points are UNDEFINED (the [a]_1 MSM may already have run when the witness check
  * fails: it overlaps the transforms). */
 int pm_prove_phase1(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uint64_t *w, const uint64_t *r_a,
@@ -204,7 +208,8 @@ int pm_host_prove(pm_ctx *ctx, const pm_pk *pk, int transcript, const uint64_t *
  * rank's partial points -- count = 2 ([a]_1, [c]_1) after phase 1, count = 1 ([d]_1) after phase 3 -- and must
  * replace them, in place, by the sums over all ranks (all-gather over RCCL + pm_g1_sum: SURVEY.md §8e; RCCL has
  * no elliptic-curve reduction).  xy: count x (x||y Montgomery, 16*fq_limbs bytes); inf: count flags.  A non-zero
- * return aborts the proof with that status.  Every rank then hashes the same points and returns the same proof. */
+ * return aborts the proof with that status.  Every rank then hashes the same points and returns the same proof.
+ * `combine` is for PM_SHARD_PAIRS keys; it is ignored on a PM_SHARD_VECTOR key, whose phases return summed points. */
 typedef int (*pm_combine_fn)(void *user, int count, uint64_t *xy, int *inf);
 int pm_host_prove_sharded(pm_ctx *ctx, const pm_pk *pk, int transcript, const uint64_t *instance_host, const uint64_t *x,
                           const uint64_t *w, int assignment_on_device, const uint64_t *r_a, pm_combine_fn combine, void *user,
@@ -271,6 +276,10 @@ int pm_comm_failed(const pm_comm *c);
 double pm_comm_busy_ms(pm_comm *c, int reset);
 int pm_comm_all_gather(pm_comm *c, const void *send, void *recv, size_t bytes);
 int pm_comm_all_to_all(pm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream);
+/* All-gather of equal DEVICE blocks (rank r's `bytes` at d_recv + r * bytes), stream-ordered: how the sharded prover
+ * distributes the assignment -- each rank uploads 1/world of the witness over its own PCIe link (prover.rs:75-80 needs all
+ * of it on every rank: "broadcast of assignment"). */
+int pm_comm_all_gather_device(pm_comm *c, const void *d_send, void *d_recv, size_t bytes, void *hip_stream);
 /* Sum over ranks of `count` partial G1 points, in place (all-gather + pm_g1_sum): the native pm_combine_fn. */
 int pm_comm_combine_points(pm_comm *c, int curve, int count, uint64_t *xy, int *inf);
 /* Join a context to its rank's communicator.  Required before proving on a PM_SHARD_VECTOR key; with it,

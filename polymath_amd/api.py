@@ -54,7 +54,7 @@ EXPORTS = [
     "pm_prove_tap", "pm_host_keccak_f1600", "pm_synth_r1cs", "pm_selftest_field",
     "pm_pk_load_sharded", "pm_pk_generate_sharded", "pm_layout_indices", "pm_pk_msm_pieces",
     "pm_comm_rccl_unique_id", "pm_comm_rccl_create", "pm_comm_local_create", "pm_comm_from_callbacks", "pm_comm_destroy", "pm_comm_rank",
-    "pm_comm_world", "pm_comm_last_error", "pm_comm_kind", "pm_comm_set_timeout_ms", "pm_comm_abort", "pm_comm_failed", "pm_comm_busy_ms", "pm_host_make_vk", "pm_host_verify", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_combine_points", "pm_ctx_set_comm",
+    "pm_comm_world", "pm_comm_last_error", "pm_comm_kind", "pm_comm_set_timeout_ms", "pm_comm_abort", "pm_comm_failed", "pm_comm_busy_ms", "pm_host_make_vk", "pm_host_verify", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_all_gather_device", "pm_comm_combine_points", "pm_ctx_set_comm",
 ]
 SHARD_PAIRS, SHARD_VECTOR = 0, 1
 LAYOUTS = {"pairs": SHARD_PAIRS, "vector": SHARD_VECTOR, 0: 0, 1: 1}
@@ -140,6 +140,7 @@ def load_library():
     L.pm_comm_busy_ms.restype = ct.c_double
     L.pm_comm_all_gather.argtypes = [vp, vp, vp, sz]
     L.pm_comm_all_to_all.argtypes = [vp, vp, vp, sz, vp]
+    L.pm_comm_all_gather_device.argtypes = [vp, vp, vp, sz, vp]
     L.pm_comm_combine_points.argtypes = [vp, i, i, u64p, intp]
     L.pm_ctx_set_comm.argtypes = [vp, vp]
     _lib = L
@@ -297,6 +298,12 @@ class Comm:
         """pm_comm_all_to_all on device pointers: block p of d_send goes to rank p, block r of d_recv comes from rank r
         (enqueued on `stream`; the caller synchronises)."""
         st = self.L.pm_comm_all_to_all(self.h, ct.c_void_p(d_send), ct.c_void_p(d_recv), bytes_per_peer, ct.c_void_p(stream or 0))
+        if st:
+            raise PolymathError(st, self.L.pm_comm_last_error(self.h).decode())
+
+    def all_gather_device(self, d_send, d_recv, nbytes, stream=None):
+        """pm_comm_all_gather_device on device pointers: rank r's `nbytes` land at d_recv + r * nbytes (the caller synchronises)."""
+        st = self.L.pm_comm_all_gather_device(self.h, ct.c_void_p(d_send), ct.c_void_p(d_recv), nbytes, ct.c_void_p(stream or 0))
         if st:
             raise PolymathError(st, self.L.pm_comm_last_error(self.h).decode())
 

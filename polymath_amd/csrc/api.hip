@@ -568,7 +568,24 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
         MsmTables tb = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS);
         if (!tb.c) continue;
         const double need = (double)len * tb.nwin * sizeof(TablePoint<C>) + (double)len;
-        if (need > budget) continue;
+        const char *te = getenv("PM_TABLES");
+        const bool force_wide = te && te[0] == 'w';          // PM_TABLES=wide: test / tuning knob -- no tables for any MSM, wide mode at any size
+        if (need > budget || force_wide) {
+            // No room for this MSM's tables (the 10n-pair [d]_1 of a 2^24-gate key on one GPU: 515 GB): WIDE mode -- the same
+            // sort / accumulate / reduce kernels on the plain base array, one bucket set per window, 13 additions per pair
+            // instead of the 16 of the one-shot pipeline.  Costs one infinity-flag byte per point.  PM_WIDE=0 disables.
+            const char *e = getenv("PM_WIDE");
+            const size_t piece = (size_t)(len < (uint64_t)msm_max_piece() ? len : (uint64_t)msm_max_piece());
+            MsmTables wt = (e && e[0] == '0') ? MsmTables() : wide_plan(piece);
+            if (wt.c && (piece >= ((size_t)1 << 18) || force_wide) && (double)len < budget) {
+                budget -= (double)len;
+                PM_HIP(ctx, hipMalloc(&pk->d_tab_inf[k], len));
+                PM_TRY(infinity_flags<C>(ctx, d + pk->res_dev_off[k], (size_t)len, (unsigned char *)pk->d_tab_inf[k]));
+                wt.inf = (const unsigned char *)pk->d_tab_inf[k];
+                pk->tables[k] = wt;
+            }
+            continue;
+        }
         budget -= need;
         PM_HIP(ctx, hipMalloc(&pk->d_tab[k], len * tb.nwin * sizeof(TablePoint<C>)));
         PM_HIP(ctx, hipMalloc(&pk->d_tab_inf[k], len));
@@ -817,7 +834,7 @@ extern "C" int pm_pk_msm_plan(const pm_pk *pk, int which, uint64_t *pairs, unsig
     if (pairs) *pairs = len;
     if (windows) *windows = nwin;
     if (window_bits) *window_bits = c;
-    if (tables) *tables = pk->tables[which].c ? 1 : 0;
+    if (tables) *tables = pk->tables[which].c && !pk->tables[which].wide ? 1 : 0;
     return PM_OK;
 }
 

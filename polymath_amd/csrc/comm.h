@@ -21,6 +21,10 @@ struct pm_comm {
     // host buffers: recv holds world x bytes, rank r's contribution at r * bytes.  Blocking.  `stream`: the caller's
     // stream (RCCL runs every collective of a communicator on ONE stream, in program order); null = the comm's own.
     virtual int all_gather(const void *send, void *recv, size_t bytes, hipStream_t stream) = 0;
+    // DEVICE buffers: d_recv holds world x bytes, rank r's block at r * bytes; stream-ordered like all_to_all.  The broadcast
+    // of the assignment: every rank uploads 1/world of the witness over its own PCIe link, the
+    // fabric delivers the rest.
+    virtual int all_gather_device(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) = 0;
     // this rank gives up: wake / unblock whoever can be reached (local group: all peers at once; RCCL: ncclCommAbort here,
     // the peers run into their own deadline)
     virtual void abort(const char *why) {

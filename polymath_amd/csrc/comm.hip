@@ -138,6 +138,22 @@ struct LocalComm : pm_comm {
         take_turn();
         return ok && !g->failed ? (int)PM_OK : dead();
     }
+    int all_gather_device(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
+        if (g->failed) return dead();
+        if (hipStreamSynchronize(stream) != hipSuccess) g->fail("local all_gather_device: stream sync failed on rank " + std::to_string(rank));
+        release_turn();
+        g->send[rank] = d_send;
+        bool ok = g->barrier(timeout_ms, rank);
+        take_turn();
+        for (int p = 0; p < world && ok && !g->failed; ++p)
+            if (hipMemcpyAsync((uint8_t *)d_recv + (size_t)p * bytes, g->send[p], bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                g->fail("local all_gather_device: copy failed on rank " + std::to_string(rank));
+        if (hipStreamSynchronize(stream) != hipSuccess) g->fail("local all_gather_device: stream sync failed on rank " + std::to_string(rank));
+        release_turn();
+        ok = g->barrier(timeout_ms, rank) && ok;
+        take_turn();
+        return ok && !g->failed ? (int)PM_OK : dead();
+    }
     int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t) override {
         if (g->failed) return dead();
         release_turn();
@@ -305,6 +321,13 @@ struct RcclComm : pm_comm {
         watch(stream);
         return PM_OK;
     }
+    int all_gather_device(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
+        if (failed) return dead();
+        const int rc = rccl_api()->AllGather(d_send, d_recv, bytes, NCCL_UINT8, comm, stream);
+        if (rc) return fail("ncclAllGather (device)", rc);
+        watch(stream);
+        return PM_OK;
+    }
     int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t stream) override {
         if (failed) return dead();
         hipStream_t side = stream ? stream : this->side;
@@ -354,6 +377,27 @@ struct CallbackComm : pm_comm {
     int all_gather(const void *send_h, void *recv_h, size_t bytes, hipStream_t) override {
         if (failed) return PM_ERR_COMM;
         return ops.all_gather ? done(ops.all_gather(ops.user, send_h, recv_h, bytes), "all_gather") : (int)PM_ERR_INVALID_ARG;
+    }
+    // the ops table has no device all-gather: an all-to-all whose `world` send blocks are all this rank's block is one
+    void *d_rep = nullptr;
+    size_t rep_bytes = 0;
+    ~CallbackComm() override { if (d_rep) (void)hipFree(d_rep); }
+    int all_gather_device(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
+        if (failed) return PM_ERR_COMM;
+        const size_t need = bytes * (size_t)world;
+        if (need > rep_bytes) {
+            if (d_rep) (void)hipFree(d_rep);
+            d_rep = nullptr;
+            rep_bytes = 0;
+            if (hipMalloc(&d_rep, need) != hipSuccess) { err = "all_gather_device staging allocation failed"; return PM_ERR_HIP; }
+            rep_bytes = need;
+        }
+        for (int p = 0; p < world; ++p)
+            if (hipMemcpyAsync((uint8_t *)d_rep + (size_t)p * bytes, d_send, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+                err = "all_gather_device replicate failed";
+                return PM_ERR_HIP;
+            }
+        return all_to_all(d_rep, d_recv, bytes, stream);
     }
 };
 
@@ -446,6 +490,11 @@ extern "C" int pm_comm_all_gather(pm_comm *c, const void *send, void *recv, size
     const int st = c->all_gather(send, recv, bytes, nullptr);
     c->phase_end();   // a host-level collective: no prover phase is running, nothing to hold a turn for
     return st;
+}
+
+extern "C" int pm_comm_all_gather_device(pm_comm *c, const void *d_send, void *d_recv, size_t bytes, void *hip_stream) {
+    if (!c || !d_send || !d_recv) return PM_ERR_INVALID_ARG;
+    return c->all_gather_device(d_send, d_recv, bytes, (hipStream_t)hip_stream);
 }
 
 extern "C" int pm_comm_all_to_all(pm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream) {

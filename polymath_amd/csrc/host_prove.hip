@@ -28,7 +28,9 @@ int host_prove_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *instance_host,
     try {
         pmhost::Polymath<C, T> pm(view);
         typename pmhost::Polymath<C, T>::Combine cb = nullptr;
-        if (!combine && pk->shard_count != 1 && ctx->comm) {   // the context's own communicator: all-gather + pm_g1_sum, no callback
+        if (pk->layout == PM_SHARD_VECTOR) {
+            combine = nullptr;     // the phases of a PM_SHARD_VECTOR key return points already summed over the ranks (one exchange per phase)
+        } else if (!combine && pk->shard_count != 1 && ctx->comm) {   // the context's own communicator: all-gather + pm_g1_sum, no callback
             combine = [](void *user, int count, uint64_t *xy, int *inf) -> int { return pm_comm_combine_points((pm_comm *)user, C::ID, count, xy, inf); };
             user = ctx->comm;
         }

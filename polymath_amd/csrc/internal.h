@@ -97,6 +97,11 @@ struct MsmTables {
     size_t base_index = 0;           // first point of this MSM inside window 0
     const unsigned char *inf = nullptr;   // device: one flag byte per point of window 0 (1 = point at infinity)
     const void *table = nullptr;          // device: TablePoint<C>[nwin][stride]
+    // WIDE mode (table == nullptr, wide == true): no tables in HBM -- every window keeps its OWN set of 2^(c-1) buckets (key =
+    // w 2^(c-1) + bucket), the points are gathered from the plain base array, the nwin window sums are combined by a Horner
+    // chain of doublings on the host.  Same sort / accumulate / reduce kernels as the table mode, so c can be 19-20 (13-14
+    // additions per pair) where the LDS-histogram pipeline of one-shot MSMs is limited to c = 16.
+    bool wide = false;
 };
 
 struct TwiddleCache {
@@ -265,7 +270,7 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
 // msm_reduce.hip: the bucket reduction of the table-mode MSM (one set of NB >= 4096 buckets whose task partials sit in ctx->msm),
 // three launches on ctx->stream; *out = the sum sum_b (b + 1) B_b, internal form, inside the workspace.
 template <class C>
-int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out);
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets = 1);
 
 // One bucket pipeline covers at most this many pairs (sorted-entry positions are u32: windows x pairs < 2^32); longer
 // MSMs run in pieces summed on the host.  2^27 in production; PM_MSM_MAX_PIECE_LOG (developer / test knob) lowers it
@@ -279,6 +284,8 @@ inline size_t msm_max_piece() {
 // choose c and the number of windows for a key whose longest MSM has `max_len` pairs
 void msm_plan_query(size_t len, unsigned scalar_bits, unsigned *nwin, unsigned *c);
 MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits);
+// the plan of an MSM that gets no tables (MsmTables::wide); c == 0 if none applies (short MSMs: the per-window pipeline)
+MsmTables wide_plan(size_t piece);
 // window 0 of d_table <- the `count` internal-form affine points at d_points; then windows 1..nwin-1
 template <class C>
 struct TablePoint;   // fq28.cuh: 128-byte, 28-bit-limb record

@@ -549,7 +549,7 @@ __device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned lo, unsigned c
 // regions hammering 64 addresses serialised in L2 and cost more than the rest of the kernel.
 template <class P, unsigned NWIN>
 __global__ __launch_bounds__(512) void k_tbl_count(const Fp<P> *scalars, const unsigned char *inf, size_t len, unsigned regions,
-                                                   uint32_t *block_cnt) {
+                                                   uint32_t *block_cnt, uint32_t win_buckets) {
     __shared__ uint32_t cnt[1024];
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
     __syncthreads();
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(512) void k_tbl_count(const Fp<P> *scalars, const u
         uint32_t carry = 0, b, neg;
 #pragma unroll
         for (unsigned w = 0; w < NWIN; ++w)
-            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) atomicAdd(&cnt[b >> LO_BITS], 1u);
+            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) atomicAdd(&cnt[(b + w * win_buckets) >> LO_BITS], 1u);
     }
     __syncthreads();
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) block_cnt[(size_t)blockIdx.x * regions + r] = cnt[r];
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *region_
 template <class P, unsigned NWIN>
 __global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, const unsigned char *inf, size_t len,
                                                        unsigned regions, const uint32_t *region_off, const uint32_t *block_off, size_t tbl_stride, size_t base_index, uint16_t *keys,
-                                                       uint32_t *vals) {
+                                                       uint32_t *vals, uint32_t win_buckets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = (uint32_t *)smem_raw, *delta = cnt + 1024;
     uint32_t *st_val = delta + 1024, *st_key = st_val + (size_t)blockDim.x * NWIN;
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, con
         uint32_t carry = 0, b, neg;
 #pragma unroll
         for (unsigned w = 0; w < NWIN; ++w)
-            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) rank[w] = atomicAdd(&cnt[b >> LO_BITS], 1u);
+            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) rank[w] = atomicAdd(&cnt[(b + w * win_buckets) >> LO_BITS], 1u);
     }
     __syncthreads();
     {   // exclusive scan over the regions (regions <= blockDim, checked by the host): lane r owns region r
@@ -651,6 +651,7 @@ __global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, con
 #pragma unroll
         for (unsigned w = 0; w < NWIN; ++w)
             if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) {
+                b += w * win_buckets;
                 const uint32_t rg = b >> LO_BITS, slot = cnt[rg] + rank[w];
                 st_key[slot] = (rg << 16) | (b & ((1u << LO_BITS) - 1));
                 st_val[slot] = (uint32_t)(((size_t)w * tbl_stride + base_index + i) << 1) | neg;
@@ -1044,14 +1045,20 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
 }
 
 // ------------------------------------------------------------------------- table-mode driver
+// tb.wide: `plain` = the MSM's first base (internal form); the piece's pairs are plain[tb.base_index ...], every window has its own
+// bucket set and the window sums are combined on the host.  Otherwise the window tables of tb.
 template <class C>
 static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename C::FrP> *d_scalars,
-                            size_t len, Affine<C> *h_out, int *h_inf) {
+                            size_t len, Affine<C> *h_out, int *h_inf, const Affine<C> *plain = nullptr) {
     typedef typename C::FrP FrP;
     StageTimer t_total(ctx, T_MSM_TOTAL);
     MsmWorkspace &ws = ctx->msm;
     const unsigned c = tb.c, nwin = tb.nwin;
-    const size_t NB = (size_t)1 << (c - 1);
+    const bool wide = tb.wide;
+    if (wide && !plain) return PM_ERR_INVALID_ARG;
+    const size_t NB1 = (size_t)1 << (c - 1);               // buckets of one window
+    const size_t NB = wide ? NB1 * nwin : NB1;             // buckets of the pipeline: one shared set, or one set per window
+    const uint32_t win_buckets = wide ? (uint32_t)NB1 : 0u;
     const unsigned lo_buckets = (unsigned)(NB < ((size_t)1 << LO_BITS) ? NB : ((size_t)1 << LO_BITS));
     const unsigned regions = (unsigned)(NB / lo_buckets);
     if (regions > 1024) return PM_ERR_INVALID_ARG;
@@ -1070,7 +1077,8 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     PM_HIP(ctx, ws.task_off.reserve((NB + 1) * 4));
     PM_HIP(ctx, ws.cursor.reserve(((NB + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
     PM_HIP(ctx, ws.partials.reserve(max_tasks * sizeof(XYZZ<C>)));
-    const bool two_level = NB >= 4096;                 // msm_reduce.hip: k_reduce_level0 / level1 / final
+    const bool two_level = NB1 >= 4096;                // msm_reduce.hip: k_reduce_level0 / level1 / final
+    if (wide && !two_level) return PM_ERR_INVALID_ARG;  // wide plans have c >= 16 (setup.hip: wide_plan)
     const unsigned red_lanes = (unsigned)((NB + RED_K - 1) / RED_K);              // single-level path (small NB)
     unsigned red_block = 64;
     while (red_block < red_lanes && red_block < 256) red_block <<= 1;
@@ -1097,14 +1105,15 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
 #define PM_TBL_CASE(NW)                                                                                                     \
         case NW:                                                                                                                \
             hipLaunchKernelGGL((k_tbl_count<FrP, NW>), dim3(pblocks), dim3(pbd), 0, ctx->stream, d_scalars, inf, len, regions,  \
-                               block_cnt);                                                                                      \
+                               block_cnt, win_buckets);                                                                         \
             hipLaunchKernelGGL(k_block_scan, dim3(regions), dim3(1024), 0, ctx->stream, block_cnt, pblocks, regions, region_count); \
             hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, region_count, region_off, region_cursor,  \
                                regions);                                                                                        \
             if (hipFuncSetAttribute((const void *)k_tbl_partition<FrP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                     (int)plds) != hipSuccess) break;                                                            \
             hipLaunchKernelGGL((k_tbl_partition<FrP, NW>), dim3(pblocks), dim3(pbd), plds, ctx->stream, d_scalars, inf, len,    \
-                               regions, region_off, block_cnt, tb.stride, tb.base_index, keys, vals);                           \
+                               regions, region_off, block_cnt, wide ? (size_t)0 : tb.stride, tb.base_index, keys, vals,         \
+                               win_buckets);                                                                                    \
             launched = 1;                                                                                                       \
             break;
         switch (nwin) {
@@ -1175,10 +1184,36 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
         size_t blocks = (max_tasks + 127) / 128;
-        hipLaunchKernelGGL((k_accumulate<C, true>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
-                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), tb.table,
-                           ws.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
+        if (wide)
+            hipLaunchKernelGGL((k_accumulate<C, false>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
+                               ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), (const void *)plain,
+                               ws.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
+        else
+            hipLaunchKernelGGL((k_accumulate<C, true>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
+                               ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), tb.table,
+                               ws.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
         PM_HIP(ctx, hipGetLastError());
+    }
+    if (wide) {
+        // all windows' bucket sets reduced by ONE set of launches; then sum_w 2^(off_w) S_w by Horner from the top window: a chain
+        // of 256 dependent doublings -- a few hundred microseconds on the host, milliseconds on one GPU lane
+        std::vector<XYZZ<C>> hS(nwin);
+        {
+            StageTimer t(ctx, T_MSM_REDUCE);
+            PM_TRY(fold_hot_buckets<C>(ctx, NB, max_tasks));
+            XYZZ<C> *dres = nullptr;
+            PM_TRY(reduce_two_level<C>(ctx, NB1, &dres, nwin));
+            PM_HIP(ctx, hipMemcpyAsync(hS.data(), dres, nwin * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        XYZZ<C> acc = XYZZ<C>::identity();
+        for (int w = (int)nwin - 1; w >= 0; --w) {
+            for (unsigned b = 0; b < tb.width[w]; ++b) acc = xyzz_dbl<C>(acc);
+            acc = xyzz_add<C>(acc, xyzz_internal_to_std<C>(hS[w]));
+        }
+        *h_inf = acc.is_identity() ? 1 : 0;
+        *h_out = xyzz_to_affine<C>(acc);
+        return PM_OK;
     }
     XYZZ<C> hres;
     {
@@ -1215,8 +1250,9 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
     }
     const bool tbl = tables && tables->c;
     const size_t MSM_MAX_PIECE = msm_max_piece();
+    const bool wide = tbl && tables->wide;
     if (len <= MSM_MAX_PIECE)
-        return tbl ? msm_piece_tables<C>(ctx, *tables, d_scalars, len, h_out, h_inf)
+        return tbl ? msm_piece_tables<C>(ctx, *tables, d_scalars, len, h_out, h_inf, wide ? d_bases : nullptr)
                    : msm_piece<C>(ctx, d_bases, d_scalars, len, h_out, h_inf);
     // very long MSMs (the 10n-pair quotient commitment at n >= 2^24 on one GPU): pieces, summed on the host
     XYZZ<C> acc = XYZZ<C>::identity();
@@ -1227,7 +1263,7 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
         if (tbl) {
             MsmTables tb = *tables;
             tb.base_index += off;
-            PM_TRY(msm_piece_tables<C>(ctx, tb, d_scalars + off, cnt, &part, &inf));
+            PM_TRY(msm_piece_tables<C>(ctx, tb, d_scalars + off, cnt, &part, &inf, wide ? d_bases : nullptr));
         } else {
             PM_TRY(msm_piece<C>(ctx, d_bases + off, d_scalars + off, cnt, &part, &inf));
         }

@@ -49,9 +49,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     outAcc[t] = xyzz28_store<C>(*acc);
 }
 
+// Several bucket SETS in one launch (the wide-window MSM without tables reduces all of its windows at once): the level-0 outputs
+// of set s are lanes [s set_lanes, (s + 1) set_lanes) and the weight of lane t is its index INSIDE its set; set_lanes is a multiple
+// of the lanes a level-1 workgroup covers, so no workgroup straddles two sets.
 template <class C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0, unsigned K0,
-                                                       unsigned R, XYZZ<C> *out) {
+                                                       unsigned R, XYZZ<C> *out, size_t set_lanes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
     typedef typename C::FqRR RR;
@@ -67,11 +70,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             xyzz28_add_full<C>(run, xyzz28_load<C>(A[t0 + i]));
             if (i > 0) xyzz28_add_into_full<C>(acc, run);          // weight i
         }
-        if (t0) {                                                    // acc += t0 * run
+        const size_t tw = t0 % set_lanes;                            // position inside the bucket set
+        if (tw) {                                                    // acc += tw * run
             XYZZ28<C> m = run;
-            for (int b = 62 - __clzll((long long)t0); b >= 0; --b) {
+            for (int b = 62 - __clzll((long long)tw); b >= 0; --b) {
                 xyzz28_dbl<C>(m);
-                if ((t0 >> b) & 1) xyzz28_add_full<C>(m, run);
+                if ((tw >> b) & 1) xyzz28_add_full<C>(m, run);
             }
             xyzz28_add_into_full<C>(acc, m);
         }
@@ -273,7 +277,7 @@ __device__ __forceinline__ void lds_tree_sum_coop(XYZZ28<C> *sh) {
 // bits it shares -- at most half of them in this form -- plus one addition per low position).
 template <class C, unsigned LP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1_coop(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0,
-                                                                                                         unsigned K0, unsigned R, XYZZ<C> *out) {
+                                                                                                         unsigned K0, unsigned R, XYZZ<C> *out, size_t set_lanes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
     typedef typename C::FqRR RR;
@@ -288,10 +292,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             xyzz28_add_coop<C, LP>(run, xyzz28_load<C>(A[t0 + i]), role);
             if (i > 0) xyzz28_add_coop<C, LP>(acc, run, role);          // weight i
         }
-        if (t0 && !f28_all_zero<RR>(run.ZZ)) {                         // acc += t0 * run
+        const size_t tw = t0 % set_lanes;                              // position inside the bucket set (k_reduce_level1)
+        if (tw && !f28_all_zero<RR>(run.ZZ)) {                         // acc += tw * run
             uint32_t pos = 0, neg = 0;
             {
-                uint64_t x = t0;
+                uint64_t x = tw;
                 for (unsigned b = 0; x; ++b, x >>= 1)
                     if (x & 1) {
                         if ((x & 3) == 3) { neg |= 1u << b; x += 1; } else { pos |= 1u << b; x -= 1; }
@@ -328,10 +333,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned role = threadIdx.x % LP;
     XYZZ28<C> acc;
     acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
+    parts += (size_t)blockIdx.x * count;     // workgroup s sums the level-1 partials of bucket set s
     for (unsigned i = threadIdx.x / LP; i < count; i += 256 / LP) xyzz28_add_coop<C, LP>(acc, xyzz28_load<C>(parts[i]), role);
     if (!role) sh[threadIdx.x / LP] = acc;
     lds_tree_sum_coop<C, LP>(sh);
-    if (threadIdx.x == 0) out[0] = xyzz28_store<C>(sh[0]);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
 }
 
 // out[0] = sum of parts[0 .. count) by one 256-lane workgroup
@@ -342,18 +348,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     typedef typename C::FqRR RR;
     XYZZ28<C> *acc = &sh[threadIdx.x];
     acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
+    parts += (size_t)blockIdx.x * count;
     for (unsigned i = threadIdx.x; i < count; i += 256) xyzz28_add_into_full<C>(acc, xyzz28_load<C>(parts[i]));
     lds_tree_sum<C>(sh);
-    if (threadIdx.x == 0) out[0] = xyzz28_store<C>(sh[0]);
+    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
 }
 
-// sum_b (b + 1) B_b over the NB buckets whose (folded) task partials sit in ctx->msm: three launches on ctx->stream, the result
-// (internal form) at *out in the workspace.
+// sum_b (b + 1) B_b over each of `nsets` sets of NB buckets (set s = buckets [s NB, (s + 1) NB)) whose (folded) task partials sit in
+// ctx->msm: three launches on ctx->stream, the nsets results (internal form) at (*out)[0 .. nsets) in the workspace.  nsets = 1:
+// the shared bucket set of the window-table MSM; nsets = windows: the wide-window MSM without tables.
 template <class C>
-int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out) {
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets) {
     MsmWorkspace &ws = ctx->msm;
+    if (nsets == 0 || (NB & (NB - 1)) != 0) return PM_ERR_INVALID_ARG;
+    const size_t total = NB * nsets;
     unsigned K0 = 4;                                   // level-0 fan-in: <= 2^17 lanes = 2 waves per SIMD, one round of the chip
-    while (NB / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;   // (swept in profiles/r02_levers.jsonl: K0 = 2 doubles level 1's work and loses)
+    while (total / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;   // (swept in profiles/r02_levers.jsonl: K0 = 2 doubles level 1's work and loses)
     if (const char *e = getenv("PM_RED_K0")) K0 = (unsigned)atoi(e);        // developer knobs (powers of two)
     // levels 1 and final on lane GROUPS (2 or 4 lanes per point, a share of the products each): 256 / LP points per workgroup, and
     // R = 2 LP keeps level 1 at 2^16 lanes = one wave per SIMD (its register budget).  PM_RED_PAIR = 0: one lane per point, 2: pairs.
@@ -361,37 +371,43 @@ int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out) {
     if (const char *e = getenv("PM_RED_PAIR")) coop = e[0] == '0' ? 0u : e[0] == '2' ? 2u : 4u;
     unsigned R1 = coop ? 2 * coop : 2;                 // swept on MI355X (tools/sweep_reduce.sh, profiles/r02_m_reduce_pair_sweep.txt)
     if (const char *e = getenv("PM_RED_R")) R1 = (unsigned)atoi(e);
-    if (K0 == 0 || R1 == 0) return PM_ERR_INVALID_ARG;
+    if (K0 == 0 || R1 == 0 || (K0 & (K0 - 1)) != 0) return PM_ERR_INVALID_ARG;
     const unsigned per_block1 = coop ? 256 / coop : 256;      // points per level-1 workgroup
-    const size_t lanes0 = (NB + K0 - 1) / K0, lanes1 = (lanes0 + R1 - 1) / R1, blocks0 = (lanes0 + 255) / 256,
+    const size_t set_lanes = (NB + K0 - 1) / K0;              // level-0 outputs per bucket set
+    if (nsets > 1) {   // no level-1 workgroup may straddle two sets
+        while (set_lanes % ((size_t)R1 * per_block1) != 0 && R1 > 1) R1 >>= 1;
+        if (NB % K0 != 0 || set_lanes % ((size_t)R1 * per_block1) != 0) return PM_ERR_INVALID_ARG;
+    }
+    const size_t lanes0 = set_lanes * nsets, lanes1 = (lanes0 + R1 - 1) / R1, blocks0 = (lanes0 + 255) / 256,
                  blocks1 = (lanes1 + per_block1 - 1) / per_block1;
-    PM_HIP(ctx, ws.wsum.reserve((2 * lanes0 + (blocks0 > blocks1 ? blocks0 : blocks1) + 4) * sizeof(XYZZ<C>)));
+    PM_HIP(ctx, ws.wsum.reserve((2 * lanes0 + (blocks0 > blocks1 ? blocks0 : blocks1) + 4 + nsets) * sizeof(XYZZ<C>)));
     XYZZ<C> *A = ws.wsum.as<XYZZ<C>>(), *Acc = A + lanes0, *parts = Acc + lanes0, *dres = parts + (blocks0 > blocks1 ? blocks0 : blocks1);
     hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
-                       ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), NB, lanes0, K0, A, Acc);
+                       ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), total, lanes0, K0, A, Acc);
     PM_HIP(ctx, hipGetLastError());
+    const unsigned per_set = (unsigned)(blocks1 / nsets);     // level-1 workgroups (= partials) per set; exact when nsets > 1
     if (coop == 4) {
         hipLaunchKernelGGL((k_reduce_level1_coop<C, 4>), dim3((unsigned)blocks1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
-                           lanes0, K0, R1, parts);
+                           lanes0, K0, R1, parts, set_lanes);
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((k_sum_final_coop<C, 4>), dim3(1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+        hipLaunchKernelGGL((k_sum_final_coop<C, 4>), dim3(nsets), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, parts, per_set, dres);
     } else if (coop == 2) {
         hipLaunchKernelGGL((k_reduce_level1_coop<C, 2>), dim3((unsigned)blocks1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
-                           lanes0, K0, R1, parts);
+                           lanes0, K0, R1, parts, set_lanes);
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((k_sum_final_coop<C, 2>), dim3(1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+        hipLaunchKernelGGL((k_sum_final_coop<C, 2>), dim3(nsets), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, parts, per_set, dres);
     } else {
         hipLaunchKernelGGL(k_reduce_level1<C>, dim3((unsigned)blocks1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, A, Acc, lanes0,
-                           K0, R1, parts);
+                           K0, R1, parts, set_lanes);
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_sum_final<C>, dim3(1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, (unsigned)blocks1, dres);
+        hipLaunchKernelGGL(k_sum_final<C>, dim3(nsets), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, per_set, dres);
     }
     PM_HIP(ctx, hipGetLastError());
     *out = dres;
     return PM_OK;
 }
 
-template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **);
-template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **);
+template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **, unsigned);
+template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **, unsigned);
 
 }  // namespace pm

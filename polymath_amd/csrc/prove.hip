@@ -327,10 +327,10 @@ int msm_resident(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::F
     const Affine<C> *bases = (const Affine<C> *)pk->d_bases + pk->res_dev_off[which];
     Affine<C> r;
     int inf = 1;
-    if (pk->tables[which].c) {   // this MSM's own window tables (window 0 = its resident pairs)
+    if (pk->tables[which].c) {   // this MSM's own window tables (window 0 = its resident pairs), or the wide mode on the plain array
         MsmTables tb = pk->tables[which];
         tb.base_index = 0;
-        PM_TRY(msm_run<C>(ctx, (const Affine<C> *)nullptr, d_scalars, (size_t)pk->res_cnt[which], &r, &inf, &tb));
+        PM_TRY(msm_run<C>(ctx, tb.wide ? bases : (const Affine<C> *)nullptr, d_scalars, (size_t)pk->res_cnt[which], &r, &inf, &tb));
     } else {
         PM_TRY(msm_run<C>(ctx, bases, d_scalars, (size_t)pk->res_cnt[which], &r, &inf));
     }

@@ -298,9 +298,15 @@ __global__ __launch_bounds__(256) void k_horner_partial_L(const Fp<P> *u, Layout
     }
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
-// out[0] = sum of `count` partials; out[1 + k1] = the last coefficient of block k1 (the halo the next block's owner needs)
+// out[k1] = the last coefficient of this rank's block k1: the halo the next block's owner needs in the division (phase 3)
 template <class P>
-__global__ __launch_bounds__(256) void k_phase2_pack(const Fp<P> *partials, unsigned count, const Fp<P> *u, Layout L, Fp<P> *out) {
+__global__ void k_halo_pack(const Fp<P> *u, Layout L, Fp<P> *out) {
+    const unsigned k1 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k1 < L.N) out[k1] = u[(uint64_t)k1 * L.B + L.B - 1];
+}
+// out[0] = sum of `count` partials
+template <class P>
+__global__ __launch_bounds__(256) void k_phase2_pack(const Fp<P> *partials, unsigned count, Fp<P> *out) {
     __shared__ Fp<P> sh[256];
     Fp<P> acc = Fp<P>::zero();
     for (unsigned i = threadIdx.x; i < count; i += 256) acc = add<P>(acc, partials[i]);
@@ -311,7 +317,6 @@ __global__ __launch_bounds__(256) void k_phase2_pack(const Fp<P> *partials, unsi
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = sh[0];
-    for (unsigned k1 = threadIdx.x; k1 < L.N; k1 += 256) out[1 + k1] = u[(uint64_t)k1 * L.B + L.B - 1];   // any N (layout_ok allows > 256)
 }
 
 // ----------------------------------------------------------------------------------- division scan (phase 3)
@@ -430,15 +435,6 @@ static int require_comm(pm_ctx *ctx, const pm_pk *pk) {
     return PM_OK;
 }
 
-// OR of a flag word over all ranks: every rank then takes the same decision (and reaches the same collectives)
-static int flags_or(pm_ctx *ctx, unsigned *flags) {
-    const int W = ctx->comm->world;
-    std::vector<unsigned> all(W);
-    PM_TRY(comm_status(ctx, ctx->comm->all_gather(flags, all.data(), sizeof(unsigned), ctx->stream), "all_gather"));
-    for (int r = 0; r < W; ++r) *flags |= all[r];
-    return PM_OK;
-}
-
 // One per phase.  (i) A phase runs holding the turn and every return path hands it on (local serialised emulation; no-op
 // for RCCL).  (ii) Fail-fast: a return that was not marked `agreed` -- i.e. anything but success or a status every rank
 // derives from the same exchanged flags -- is a failure the peers cannot know of (HIP error, allocation, layout mismatch):
@@ -481,7 +477,9 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     const uint64_t hcnt = m - (q == N - 1 ? 1 : 0), rucnt = (uint64_t)N * (B + 1), tail = q == 0 ? 5 : 0;
     const uint64_t len_c = zcnt + hcnt + rucnt + tail;
     if (len_c != pk->res_cnt[1] || m + (q == 0 ? 2 : 0) != pk->res_cnt[0]) return PM_ERR_STATE;   // key and prover disagree on the layout
-    PM_HIP(ctx, ctx->xw.reserve((m0 + mw) * sizeof(Fr)));
+    // assignment: [x (m0) | w padded to N slices of wblk | staging of this rank's slice]
+    const uint64_t wblk = (mw + N - 1) / N;
+    PM_HIP(ctx, ctx->xw.reserve((m0 + ((uint64_t)N + 1) * wblk) * sizeof(Fr)));
     PM_HIP(ctx, ctx->ue.reserve(m * sizeof(Fr)));
     PM_HIP(ctx, ctx->we.reserve(m * sizeof(Fr)));
     PM_HIP(ctx, ctx->u.reserve((m + 2) * sizeof(Fr)));
@@ -499,9 +497,22 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     Fr *ta = ctx->sh_a.as<Fr>(), *tb = ctx->sh_b.as<Fr>(), *tc = ctx->sh_c.as<Fr>();
     unsigned *flags = ctx->flags.as<unsigned>();
     PM_HIP(ctx, hipMemsetAsync(flags, 0, 64, st));
-    const hipMemcpyKind kind = assignment_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    PM_HIP(ctx, hipMemcpyAsync(xw, x, m0 * sizeof(Fr), kind, st));
-    if (mw) PM_HIP(ctx, hipMemcpyAsync(xw + m0, w, mw * sizeof(Fr), kind, st));
+    // Every rank needs the whole assignment (the rows it owns read arbitrary columns: prover.rs:279-302).  From HOST buffers
+    // each rank uploads only its 1/N slice of w over its own PCIe link and the fabric delivers the rest (all-gather of
+    // device blocks: "broadcast of assignment") -- N times less PCIe traffic per rank than N full copies.
+    if (assignment_on_device) {
+        PM_HIP(ctx, hipMemcpyAsync(xw, x, m0 * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        if (mw) PM_HIP(ctx, hipMemcpyAsync(xw + m0, w, mw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    } else {
+        PM_HIP(ctx, hipMemcpyAsync(xw, x, m0 * sizeof(Fr), hipMemcpyHostToDevice, st));
+        if (mw) {
+            Fr *stage = xw + m0 + (uint64_t)N * wblk;
+            const uint64_t lo = std::min<uint64_t>(mw, (uint64_t)q * wblk), hi = std::min<uint64_t>(mw, (uint64_t)(q + 1) * wblk);
+            if (hi - lo < wblk) PM_HIP(ctx, hipMemsetAsync(stage + (hi - lo), 0, (wblk - (hi - lo)) * sizeof(Fr), st));
+            if (hi > lo) PM_HIP(ctx, hipMemcpyAsync(stage, w + 4 * lo, (hi - lo) * sizeof(Fr), hipMemcpyHostToDevice, st));
+            PM_TRY(comm_status(ctx, ctx->comm->all_gather_device(stage, xw + m0, wblk * sizeof(Fr), st), "all_gather_device"));
+        }
+    }
     PM_HIP(ctx, hipMemcpyAsync(ra, r_a, 2 * sizeof(Fr), hipMemcpyHostToDevice, st));
     CsrDev A{pk->d_rowptr[0], pk->d_col[0], pk->d_val[0]}, Bm{pk->d_rowptr[1], pk->d_col[1], pk->d_val[1]},
         Cm{pk->d_rowptr[2], pk->d_col[2], pk->d_val[2]};
@@ -588,21 +599,67 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
                            tail ? sc_c + zcnt + hcnt + rucnt : (Fr *)nullptr, L, flags);
         PM_HIP(ctx, hipGetLastError());
     }
-    unsigned hflags = 0;
-    PM_HIP(ctx, hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
-    PM_HIP(ctx, hipStreamSynchronize(st));
-    PM_TRY(flags_or(ctx, &hflags));
-    if (hflags & 1u) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);                 // prover.rs:108 -- the same flags on every rank
-    if ((hflags & 2u) || !(hflags & 4u)) return phase_end.ok(PM_ERR_DEGREE_BOUND);   // prover.rs:107
+    // ONE exchange for the whole phase, after the MSMs: the status flags, the two partial points and the halo coefficients
+    // phase 3 needs (the last coefficient of each of this rank's blocks).  The flags travel with the points instead of
+    // ahead of them: an unsatisfied witness costs the MSMs before every rank reports it -- the rare path pays, not the proof.
+    struct Rec1 {
+        uint32_t flags, a_inf, c_inf, pad;
+        uint64_t a_xy[sizeof(Affine<C>) / 8], c_xy[sizeof(Affine<C>) / 8];
+    };
+    const size_t rec_bytes = sizeof(Rec1) + (size_t)N * sizeof(Fr);
+    std::vector<uint8_t> mine(rec_bytes), all(rec_bytes * N);
+    Rec1 *r1 = (Rec1 *)mine.data();
+    Fr *my_halo = (Fr *)(mine.data() + sizeof(Rec1));
+    PM_HIP(ctx, ctx->halo.reserve(2 * (size_t)N * sizeof(Fr)));            // [halo of my blocks (phase 3) | my blocks' last coefficients]
+    Fr *d_last = ctx->halo.as<Fr>() + N;
+    hipLaunchKernelGGL(k_halo_pack<P>, dim3((N + 63) / 64), dim3(64), 0, st, (const Fr *)u, L, d_last);
+    PM_HIP(ctx, hipGetLastError());
+    PM_HIP(ctx, hipMemcpyAsync(&r1->flags, flags, 4, hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipMemcpyAsync(my_halo, d_last, (size_t)N * sizeof(Fr), hipMemcpyDeviceToHost, st));   // both land before the MSM's final sync
+    int a_inf_l = 1, c_inf_l = 1;
     if (a_early) {
-        const int st_c = msm_resident<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
+        const int st_c = msm_resident<C>(ctx, pk, 1, sc_c, r1->c_xy, &c_inf_l);
         helper.join();
         for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];
         if (st_a != PM_OK) { ctx->err = ctx->aux->err; return st_a; }
         PM_TRY(st_c);
+        memcpy(r1->a_xy, a_xy, sizeof(Affine<C>));
+        a_inf_l = *a_inf;
     } else {
-        PM_TRY(msm_resident<C>(ctx, pk, 0, u, a_xy, a_inf));
-        PM_TRY(msm_resident<C>(ctx, pk, 1, sc_c, c_xy, c_inf));
+        PM_TRY(msm_resident<C>(ctx, pk, 0, u, r1->a_xy, &a_inf_l));
+        PM_TRY(msm_resident<C>(ctx, pk, 1, sc_c, r1->c_xy, &c_inf_l));
+    }
+    r1->a_inf = (uint32_t)a_inf_l;
+    r1->c_inf = (uint32_t)c_inf_l;
+    r1->pad = 0;
+    PM_TRY(comm_status(ctx, ctx->comm->all_gather(mine.data(), all.data(), rec_bytes, st), "all_gather"));
+    unsigned hflags = 0;
+    std::vector<uint64_t> pa((size_t)N * (sizeof(Affine<C>) / 8)), pc(pa.size());
+    std::vector<int> ia(N), ic(N);
+    for (uint32_t r = 0; r < N; ++r) {
+        const Rec1 *rr = (const Rec1 *)(all.data() + (size_t)r * rec_bytes);
+        hflags |= rr->flags;
+        memcpy(&pa[r * (sizeof(Affine<C>) / 8)], rr->a_xy, sizeof(Affine<C>));
+        memcpy(&pc[r * (sizeof(Affine<C>) / 8)], rr->c_xy, sizeof(Affine<C>));
+        ia[r] = (int)rr->a_inf;
+        ic[r] = (int)rr->c_inf;
+    }
+    if (hflags & 1u) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);                 // prover.rs:108 -- the same flags on every rank
+    if ((hflags & 2u) || !(hflags & 4u)) return phase_end.ok(PM_ERR_DEGREE_BOUND);   // prover.rs:107
+    // [a]_1, [c]_1 = the sums over the ranks (RCCL has no elliptic-curve reduction: all-gather + local adds)
+    PM_TRY(pm_g1_sum(C::ID, pa.data(), ia.data(), N, a_xy, a_inf));
+    PM_TRY(pm_g1_sum(C::ID, pc.data(), ic.data(), N, c_xy, c_inf));
+    // halo of my block k1 = the coefficient just below its first one: the last of rank q-1's block k1, or (q = 0) of
+    // rank N-1's block k1-1; block (0, 0) starts at coefficient 0 and has none
+    {
+        std::vector<Fr> halo(N, Fr::zero());
+        auto last_of = [&](uint32_t r, uint32_t k1) { return ((const Fr *)(all.data() + (size_t)r * rec_bytes + sizeof(Rec1)))[k1]; };
+        for (uint32_t k1 = 0; k1 < N; ++k1) {
+            if (q > 0) halo[k1] = last_of(q - 1, k1);
+            else if (k1 > 0) halo[k1] = last_of(N - 1, k1 - 1);
+        }
+        PM_HIP(ctx, hipMemcpyAsync(ctx->halo.p, halo.data(), (size_t)N * sizeof(Fr), hipMemcpyHostToDevice, st));
+        PM_HIP(ctx, hipStreamSynchronize(st));     // `halo` is a stack vector
     }
     t_phase.stop();
     timing_flush(ctx);
@@ -627,30 +684,20 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
     while (Lh > L.B) Lh >>= 1;
     const uint64_t lanes = L.m / Lh;
     const unsigned blocks = nblk(lanes);
-    const size_t rec = 1 + (size_t)L.N;
-    PM_HIP(ctx, ctx->scratch.reserve(((size_t)blocks + rec) * sizeof(Fr)));
+    PM_HIP(ctx, ctx->scratch.reserve(((size_t)blocks + 1) * sizeof(Fr)));
     Fr *part = ctx->scratch.as<Fr>(), *out = part + blocks;
     hipLaunchKernelGGL(k_horner_partial_L<P>, dim3(blocks), dim3(256), 0, st, ctx->u.as<Fr>(), L, x1, Lh, part);
     PM_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_phase2_pack<P>, dim3(1), dim3(256), 0, st, (const Fr *)part, blocks, (const Fr *)ctx->u.as<Fr>(), L, out);
+    hipLaunchKernelGGL(k_phase2_pack<P>, dim3(1), dim3(256), 0, st, (const Fr *)part, blocks, out);
     PM_HIP(ctx, hipGetLastError());
-    std::vector<Fr> mine(rec), all(rec * L.N);
-    PM_HIP(ctx, hipMemcpyAsync(mine.data(), out, rec * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    Fr mine;
+    std::vector<Fr> all(L.N);
+    PM_HIP(ctx, hipMemcpyAsync(&mine, out, sizeof(Fr), hipMemcpyDeviceToHost, st));
     PM_HIP(ctx, hipStreamSynchronize(st));
-    PM_TRY(comm_status(ctx, ctx->comm->all_gather(mine.data(), all.data(), rec * sizeof(Fr), st), "all_gather"));
+    PM_TRY(comm_status(ctx, ctx->comm->all_gather(&mine, all.data(), sizeof(Fr), st), "all_gather"));
     Fr sum = Fr::zero();
-    for (uint32_t r = 0; r < L.N; ++r) sum = add<P>(sum, all[r * rec]);
+    for (uint32_t r = 0; r < L.N; ++r) sum = add<P>(sum, all[r]);
     memcpy(u_at_x1, sum.l, sizeof(Fr));
-    // halo of my block k1 = the coefficient just below its first one: the last of rank q-1's block k1, or (q = 0) of
-    // rank N-1's block k1-1; block (0, 0) starts at coefficient 0 and has none
-    std::vector<Fr> halo(L.N, Fr::zero());
-    for (uint32_t k1 = 0; k1 < L.N; ++k1) {
-        if (L.q > 0) halo[k1] = all[(L.q - 1) * rec + 1 + k1];
-        else if (k1 > 0) halo[k1] = all[(L.N - 1) * rec + 1 + (k1 - 1)];
-    }
-    PM_HIP(ctx, ctx->halo.reserve(L.N * sizeof(Fr)));
-    PM_HIP(ctx, hipMemcpyAsync(ctx->halo.p, halo.data(), L.N * sizeof(Fr), hipMemcpyHostToDevice, st));
-    PM_HIP(ctx, hipStreamSynchronize(st));
     PM_TRY(comm_alive(ctx));
     ctx->phase = 2;
     return phase_end.ok(PM_OK);
@@ -662,7 +709,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
                          int *d_inf) {
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
-    if (ctx->phase < 2 || !ctx->pk) return PM_ERR_STATE;            // the halo coefficients come from phase 2's exchange
+    if (ctx->phase < 2 || !ctx->pk) return PM_ERR_STATE;            // x1 is phase 2's; the halo coefficients came with phase 1's exchange
     const pm_pk *pk = ctx->pk;
     PM_TRY(require_comm(ctx, pk));
     PhaseEnd phase_end(ctx, "phase 3");
@@ -715,7 +762,25 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
                            (const Fr *)lane_vals, (const Fr *)carry, qv);
         PM_HIP(ctx, hipGetLastError());
     }
-    PM_TRY(msm_resident<C>(ctx, pk, 2, qv, d_xy, d_inf));              // [d]_1 = M8, prover.rs:229
+    // [d]_1 = M8, prover.rs:229: this rank's partial sum, then the sum over the ranks (all-gather + local adds, like phase 1)
+    {
+        struct Rec3 {
+            uint64_t xy[sizeof(Affine<C>) / 8];
+            uint64_t inf;
+        } mine3;
+        int inf_l = 1;
+        PM_TRY(msm_resident<C>(ctx, pk, 2, qv, mine3.xy, &inf_l));
+        mine3.inf = (uint64_t)inf_l;
+        std::vector<Rec3> all3(N);
+        PM_TRY(comm_status(ctx, ctx->comm->all_gather(&mine3, all3.data(), sizeof(Rec3), st), "all_gather"));
+        std::vector<uint64_t> pts((size_t)N * (sizeof(Affine<C>) / 8));
+        std::vector<int> infs(N);
+        for (uint32_t r = 0; r < N; ++r) {
+            memcpy(&pts[r * (sizeof(Affine<C>) / 8)], all3[r].xy, sizeof(Affine<C>));
+            infs[r] = (int)all3[r].inf;
+        }
+        PM_TRY(pm_g1_sum(C::ID, pts.data(), infs.data(), N, d_xy, d_inf));
+    }
     t_phase.stop();
     timing_flush(ctx);
     PM_TRY(comm_alive(ctx));

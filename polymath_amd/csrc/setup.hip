@@ -337,6 +337,30 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
     return best_t;
 }
 
+// Plan of the WIDE mode (no tables: MsmTables::wide): every window has its own 2^(c-1) buckets.  piece = the pairs one bucket
+// pipeline covers (<= msm_max_piece()).  Cost in the units of tables_plan: nwin (piece + reduction of one bucket set), with the
+// sort front end's limit of 512 regions of 2^15 buckets (one scan lane per region in k_tbl_partition) and >= 4096 buckets per
+// window (the two-level reduction).  Long MSMs land on 13 windows of 20 / 19 bits: 13 additions per pair where the
+// LDS-histogram pipeline of the one-shot MSM stops at c = 16 (16 additions).
+MsmTables wide_plan(size_t piece) {
+    MsmTables best_t;
+    double best = 1e300;
+    for (unsigned nwin = 12; nwin <= 19; ++nwin) {
+        MsmTables t;
+        tables_layout(t, nwin);
+        if (t.c < 14 || t.c > 23) continue;
+        const double NB = (double)((size_t)1 << (t.c - 1));
+        if ((double)nwin * NB / 32768.0 > 512.0) continue;
+        if ((double)nwin * (double)piece >= 4294967296.0) continue;          // u32 positions of the sorted entries
+        const double E = (double)nwin * (double)piece;
+        const double cost = std::max(E, E / (NB * nwin) * 135e3) + 3.3e6 + 3.3 * NB * nwin;   // ONE batched reduction over all sets
+        if (cost < best) { best = cost; best_t = t; }
+    }
+    best_t.wide = best_t.c != 0;
+    best_t.stride = 0;
+    return best_t;
+}
+
 #define PM_INST(C)                                                                                              \
     template int powers_fill<C>(pm_ctx *, Fp<typename C::FrP> *, size_t, const Fp<typename C::FrP> &,           \
                                 const Fp<typename C::FrP> &);                                                   \

@@ -34,10 +34,12 @@ def _accepts(curve, vk, proof, public_inputs, tname="merlin"):
 
 # ------------------------------------------------- whole proofs, bit-exact against the CPU restatement, at size
 @pytest.mark.parametrize("curve", CURVE_LIST)
-@pytest.mark.parametrize("log_nr,tables", [(16, "1"), (16, "0"), (18, "1"), (18, "0")])
+@pytest.mark.parametrize("log_nr,tables", [(16, "1"), (16, "0"), (16, "wide"), (18, "1"), (18, "0"), (18, "wide")])
 def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, log_nr, tables, monkeypatch):
     """2^16-100 and 2^18-100 synthetic gates (n = 2^17 / 2^19: three-pass NTT, per-MSM window tables with 12-13 windows,
-    three-level sort, two-level bucket reduction), both curves, with the key's tables and with PM_TABLES=0.
+    three-level sort, two-level bucket reduction), both curves, with the key's tables, with PM_TABLES=0 (the per-window
+    pipeline) and with PM_TABLES=wide (no tables, one bucket set per window on the table pipeline's kernels: what a key whose
+    tables do not fit HBM runs -- the 10n-pair [d]_1 of a 2^24-gate circuit on one GPU).
     The CPU restatement's key is seeded with the GPU's exported bases (their parity is tested at mid size: the CPU
     setup would take minutes here); proof, challenges and all 8 intermediate vectors must be identical."""
     import os
@@ -54,6 +56,8 @@ def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, lo
     pm = Polymath(curve, "merlin", ctx=gpu_ctx)
     gpk = pm.setup(lc, x, z)
     assert gpk.msm_plan(2)[3] == (tables == "1")
+    if tables == "wide":
+        assert all(13 <= gpk.msm_plan(k)[1] <= 19 and gpk.msm_plan(k)[2] >= 14 for k in range(3))     # wide_plan: big windows, no tables
     threads = os.cpu_count() or 8
     opk = oracle.OraclePk(curve, q, None, None, threads)
     for i in range(6):
@@ -118,9 +122,12 @@ def test_config_2p22_one_gpu():
 
 def test_config_2p24_one_gpu_piece_split():
     """BASELINE configs[3] circuit (2^24-100 gates, n = 2^25, 470 M MSM pairs) on ONE GPU: nine-stage NTT passes, and the
-    335 M-pair quotient MSM runs in > 2^27-pair pieces (msm.hip: msm_run) on the per-window pipeline."""
+    335 M-pair quotient MSM runs in > 2^27-pair pieces (msm.hip: msm_run).  Its window tables would take 515 GB, so the key runs
+    it (and the 100 M-pair [c]_1) in the WIDE mode: 13 windows of 20 / 19 bits on the plain base array, 13 additions per
+    pair instead of the per-window pipeline's 16 (pm_pk_msm_plan shows the plan)."""
     plans = _full_size_config("bls12_381", 24, 0x2424)
     assert plans[2][0] == 10 * (1 << 25) + 22 and plans[2][0] > (1 << 27)
+    assert plans[0][3] and not plans[2][3] and plans[2][1] == 13 and plans[1][1] == 13, plans     # [a]: tables; [c], [d]: wide, 13 windows
 
 
 def test_config_bn254_2p20():
@@ -164,10 +171,13 @@ def test_prove_with_piece_split_msms_equals_whole(gpu_ctx, oracle, api, monkeypa
     c = CURVES[curve]
     lc = PC.synthetic_r1cs_native(curve, 5000)
     pm = Polymath(curve, "keccak256", ctx=gpu_ctx)
-    for tables in ("1", "0"):
+    first = None
+    for tables in ("1", "0", "wide"):
         monkeypatch.setenv("PM_TABLES", tables)
         pk = pm.setup(lc, 0xABCDEF, 0x123457)
         ref = pm.prove_native(pk, lc.inst_limbs, lc.wit_limbs, [5, 7])
+        first = first or ref
+        assert ref == first
         monkeypatch.setenv("PM_MSM_MAX_PIECE_LOG", "12")
         assert pm.prove_native(pk, lc.inst_limbs, lc.wit_limbs, [5, 7]) == ref
         monkeypatch.delenv("PM_MSM_MAX_PIECE_LOG")

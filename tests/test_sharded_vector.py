@@ -162,7 +162,7 @@ def test_vector_sharded_proof_equals_single_gpu(oracle, curve, N):
         g_tap = ref_pk.tap(w, 11 * n)
         k = min(len(g_tap), len(whole[w]))
         assert np.array_equal(g_tap[:k], whole[w][:k]) and not g_tap[k:].any() and not whole[w][k:].any(), w
-        whole[w] = g_tap if len(g_tap) >= len(whole[w]) else whole[w]
+        whole[w] = g_tap                                              # == the oracle's over its whole length, zeros beyond
     pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
     assert all(p == oracle_proof for p in proofs)
     # local vectors -> global through the layout
