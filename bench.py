@@ -281,6 +281,8 @@ def worker(args):
     stage("key setup", 300 * (1 << max(0, args.log_constraints - 20)))
     pk = pm.setup(r1cs, x_trap, z_trap, shard_rank=shard_rank, shard_count=shard_count, layout=layout)
     log(rank, "setup on device: n=%d, layout=%s (%.1f s)" % (pk.n, layout, time.time() - t0))
+    if multi:
+        dist.barrier()          # the ranks' setups differ by seconds: do not let that skew eat into the first proof's collective deadline
     x_l, w_l = r1cs.inst_limbs, r1cs.wit_limbs
     combine = PointCombiner(pm.ctx, curve, pm.field.nq, rank, world, device=local, backend_gloo=(backend != "nccl")) if world > 1 and layout == "pairs" else None
     py_combine = combine            # for the phase-by-phase (Python glue) proofs

@@ -88,6 +88,8 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     ctx->tw_clock = 0;
     ctx->shard_roots_n = 0; ctx->shard_roots_N = 0; ctx->shard_roots_curve = -1;
     ctx->ntt_lds_attr[0] = ctx->ntt_lds_attr[1] = false;
+    ctx->h_pinned = nullptr;
+    ctx->msm_async = 0;
     ctx->keep_timings = false;
     timing_reset(ctx);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -118,6 +120,8 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     for (auto &b : ctx->lvl) b.release();
     for (auto &b : ctx->fb_table) b.release();
     for (auto &t : ctx->tw) { t.fwd.release(); t.inv.release(); t.fwd_int.release(); t.inv_int.release(); }
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev_sc_a);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -566,8 +570,9 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
         const uint64_t len = pk->res_cnt[k];
         if (!len) continue;
         MsmTables tb = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS);
-        if (!tb.c) continue;
-        const double need = (double)len * tb.nwin * sizeof(TablePoint<C>) + (double)len;
+        // no table plan at all (nwin x points would overflow the u32 table indices: the 335 M-pair [d]_1 of a 2^24-gate key) counts
+        // as "does not fit"
+        const double need = tb.c ? (double)len * tb.nwin * sizeof(TablePoint<C>) + (double)len : 1e300;
         const char *te = getenv("PM_TABLES");
         const bool force_wide = te && te[0] == 'w';          // PM_TABLES=wide: test / tuning knob -- no tables for any MSM, wide mode at any size
         if (need > budget || force_wide) {

@@ -4,7 +4,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -227,6 +229,7 @@ struct PendingTimer {
 struct pm_ctx {
     int device;
     std::vector<PendingTimer> pending_timers;
+    std::vector<hipEvent_t> event_pool;   // recycled stage-timer events: ~50 create / destroy pairs per proof are 0.2 ms of host time
     hipStream_t stream;
     std::string err;
     double timing_ms[pm::T_NUM_SLOTS];
@@ -235,6 +238,8 @@ struct pm_ctx {
     pm::TwiddleCache tw[8];   // the sharded prover works with log m, log n and log 2n tables of both directions
     unsigned long long tw_clock;
     pm::DevBuf scratch, flags, ntt_tmp;   // ntt_tmp: the out-of-place first / last passes of ntt_run
+    void *h_pinned;           // 4 KiB of pinned host memory: the asynchronous MSM's result slot (msm.hip: msm_begin / msm_end)
+    int msm_async;            // 0 none pending, 1 enqueued (msm_end synchronises), 2 ran synchronously (result parked in the slot)
     bool ntt_lds_attr[2];     // ntt.hip: the tile kernels' dynamic-LDS limit has been raised on this context's device (per curve id)
     pm_comm *comm;            // this rank's communicator (pm_ctx_set_comm); null on single-GPU contexts
     pm_worker worker;         // runs the helper context's MSM concurrently with this context's own work
@@ -254,6 +259,37 @@ struct pm_ctx {
 
 namespace pm {
 
+// Developer aid: PM_PROFILE_HOST=1 prints, at the end of every phase of the sharded prover, how the HOST thread's wall time of that
+// phase splits over labelled sections (stderr; one line per phase and rank).  What a kernel trace cannot show: waits, collectives,
+// host arithmetic.  Costs two clock reads per section when off.
+struct HostProfile {
+    bool on;
+    const char *phase;
+    int rank;
+    std::chrono::steady_clock::time_point t0, last;
+    std::vector<std::pair<const char *, double>> parts;
+    HostProfile(const char *ph, int r) : phase(ph), rank(r) {
+        static const bool enabled = [] { const char *e = getenv("PM_PROFILE_HOST"); return e && e[0] == '1'; }();
+        on = enabled;
+        if (on) t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(const char *label) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        parts.emplace_back(label, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+    ~HostProfile() {
+        if (!on) return;
+        std::string line = std::string("[pm host rank ") + std::to_string(rank) + "] " + phase + ":";
+        char buf[96];
+        for (auto &p : parts) { snprintf(buf, sizeof buf, " %s=%.3f", p.first, p.second); line += buf; }
+        snprintf(buf, sizeof buf, " | total=%.3f ms\n", std::chrono::duration<double, std::milli>(last - t0).count());
+        line += buf;
+        fputs(line.c_str(), stderr);
+    }
+};
+
 // ---- per-curve entry points implemented in the .hip translation units -----------------------
 template <class C>
 int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d_data, unsigned log_n, bool inverse);
@@ -266,6 +302,16 @@ int twiddles_get(pm_ctx *ctx, unsigned log_n, bool inv_dir, const Fp<typename C:
 template <class C>
 int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len,
             Affine<C> *h_out, int *h_inf, const MsmTables *tables = nullptr);
+
+// the same in two halves (msm.hip): enqueue on ctx->stream without waiting / wait and convert
+template <class C>
+int msm_begin(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, const MsmTables *tables);
+template <class C>
+int msm_end(pm_ctx *ctx, Affine<C> *h_out, int *h_inf);
+template <class C>
+int msm_resident_begin(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars);
+template <class C>
+int msm_resident_end(pm_ctx *ctx, uint64_t *out_xy, int *out_inf);
 
 // msm_reduce.hip: the bucket reduction of the table-mode MSM (one set of NB >= 4096 buckets whose task partials sit in ctx->msm),
 // three launches on ctx->stream; *out = the sum sum_b (b + 1) B_b, internal form, inside the workspace.
@@ -344,11 +390,15 @@ struct StageTimer {
     int slot;
     hipEvent_t a, b;
     bool ok;
+    static bool take(pm_ctx *c, hipEvent_t *e) {
+        if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); return true; }
+        return hipEventCreate(e) == hipSuccess;
+    }
     StageTimer(pm_ctx *c, int s) : ctx(c), slot(s), ok(false) {
-        if (hipEventCreate(&a) != hipSuccess) return;
-        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+        if (!take(c, &a)) return;
+        if (!take(c, &b)) { c->event_pool.push_back(a); return; }
         ok = hipEventRecord(a, ctx->stream) == hipSuccess;
-        if (!ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+        if (!ok) { c->event_pool.push_back(a); c->event_pool.push_back(b); }
     }
     void stop() {
         if (!ok) return;
@@ -364,8 +414,8 @@ inline void timing_flush(pm_ctx *ctx) {
         float ms = 0;
         if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess)
             ctx->timing_ms[t.slot] += ms;
-        (void)hipEventDestroy(t.a);
-        (void)hipEventDestroy(t.b);
+        ctx->event_pool.push_back(t.a);
+        ctx->event_pool.push_back(t.b);
     }
     ctx->pending_timers.clear();
 }

@@ -1047,21 +1047,23 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
 // ------------------------------------------------------------------------- table-mode driver
 // tb.wide: `plain` = the MSM's first base (internal form); the piece's pairs are plain[tb.base_index ...], every window has its own
 // bucket set and the window sums are combined on the host.  Otherwise the window tables of tb.
+// async_res != nullptr (table mode only): everything is ENQUEUED on ctx->stream, the reduced point (internal form) is copied to
+// *async_res -- pinned host memory -- and the call returns without waiting; the caller synchronises and finishes (msm_end).
 template <class C>
 static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename C::FrP> *d_scalars,
-                            size_t len, Affine<C> *h_out, int *h_inf, const Affine<C> *plain = nullptr) {
+                            size_t len, Affine<C> *h_out, int *h_inf, const Affine<C> *plain = nullptr, XYZZ<C> *async_res = nullptr) {
     typedef typename C::FrP FrP;
     StageTimer t_total(ctx, T_MSM_TOTAL);
     MsmWorkspace &ws = ctx->msm;
     const unsigned c = tb.c, nwin = tb.nwin;
     const bool wide = tb.wide;
-    if (wide && !plain) return PM_ERR_INVALID_ARG;
+    if ((wide && !plain) || (wide && async_res)) return PM_ERR_INVALID_ARG;
     const size_t NB1 = (size_t)1 << (c - 1);               // buckets of one window
     const size_t NB = wide ? NB1 * nwin : NB1;             // buckets of the pipeline: one shared set, or one set per window
     const uint32_t win_buckets = wide ? (uint32_t)NB1 : 0u;
     const unsigned lo_buckets = (unsigned)(NB < ((size_t)1 << LO_BITS) ? NB : ((size_t)1 << LO_BITS));
     const unsigned regions = (unsigned)(NB / lo_buckets);
-    if (regions > 1024) return PM_ERR_INVALID_ARG;
+    if (regions > 1024 || (size_t)regions * lo_buckets != NB) return PM_ERR_INVALID_ARG;   // whole regions only (wide mode: nwin 2^(c-1) buckets)
     const size_t Emax = (size_t)nwin * len;
     size_t seg = 2 * (Emax / NB + 1);
     if (seg < 64) seg = 64;
@@ -1231,8 +1233,9 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             hipLaunchKernelGGL(k_sum_parts<C>, dim3(1), dim3(64), 0, ctx->stream, parts, bpw, dres);
             PM_HIP(ctx, hipGetLastError());
         }
-        PM_HIP(ctx, hipMemcpyAsync(&hres, dres, sizeof(hres), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(ctx, hipMemcpyAsync(async_res ? async_res : &hres, dres, sizeof(hres), hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (async_res) return PM_OK;                       // msm_end: stream sync, then the two lines below
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     XYZZ<C> acc = xyzz_internal_to_std<C>(hres);
     *h_inf = acc.is_identity() ? 1 : 0;
@@ -1274,6 +1277,51 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
     return PM_OK;
 }
 
+// Asynchronous pair for a single-piece table-mode MSM: msm_begin enqueues the whole pipeline on ctx->stream and returns at once
+// (the result travels to the context's pinned slot), msm_end waits for the stream and converts the point.  Two contexts (ctx and
+// its helper ctx->aux: own streams, own workspaces) can so run two MSMs concurrently from ONE host thread -- the latency-bound
+// sort front end and bucket reduction of one hide under the accumulation of the other.  MSMs that need the host in the middle
+// (several pieces, wide mode, no tables) run synchronously inside msm_begin; msm_end then just hands the result over.
+template <class C>
+int msm_begin(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, const MsmTables *tables) {
+    ctx->msm_async = 0;
+    const bool tbl = tables && tables->c && !tables->wide;
+    if (!ctx->h_pinned) {
+        if (hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) { ctx->h_pinned = nullptr; ctx->err = "pinned result slot allocation failed"; return PM_ERR_HIP; }
+    }
+    Affine<C> *slot_pt = (Affine<C> *)((uint8_t *)ctx->h_pinned + 1024);
+    int *slot_inf = (int *)((uint8_t *)ctx->h_pinned + 2048);
+    if (len == 0 || !tbl || len > msm_max_piece()) {           // synchronous: result parked in the slot
+        PM_TRY(msm_run<C>(ctx, d_bases, d_scalars, len, slot_pt, slot_inf, tables));
+        ctx->msm_async = 2;
+        return PM_OK;
+    }
+    PM_TRY(msm_piece_tables<C>(ctx, *tables, d_scalars, len, (Affine<C> *)nullptr, (int *)nullptr, (const Affine<C> *)nullptr, (XYZZ<C> *)ctx->h_pinned));
+    ctx->msm_async = 1;
+    return PM_OK;
+}
+
+template <class C>
+int msm_end(pm_ctx *ctx, Affine<C> *h_out, int *h_inf) {
+    if (ctx->msm_async == 2) {
+        *h_out = *(const Affine<C> *)((const uint8_t *)ctx->h_pinned + 1024);
+        *h_inf = *(const int *)((const uint8_t *)ctx->h_pinned + 2048);
+    } else if (ctx->msm_async == 1) {
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const XYZZ<C> acc = xyzz_internal_to_std<C>(*(const XYZZ<C> *)ctx->h_pinned);
+        *h_inf = acc.is_identity() ? 1 : 0;
+        *h_out = xyzz_to_affine<C>(acc);
+    } else {
+        return PM_ERR_STATE;
+    }
+    ctx->msm_async = 0;
+    return PM_OK;
+}
+
+template int msm_begin<BlsCurve>(pm_ctx *, const Affine<BlsCurve> *, const Fp<BlsFrP> *, size_t, const MsmTables *);
+template int msm_begin<BnCurve>(pm_ctx *, const Affine<BnCurve> *, const Fp<BnFrP> *, size_t, const MsmTables *);
+template int msm_end<BlsCurve>(pm_ctx *, Affine<BlsCurve> *, int *);
+template int msm_end<BnCurve>(pm_ctx *, Affine<BnCurve> *, int *);
 template int msm_run<BlsCurve>(pm_ctx *, const Affine<BlsCurve> *, const Fp<BlsFrP> *, size_t, Affine<BlsCurve> *, int *, const MsmTables *);
 template int msm_run<BnCurve>(pm_ctx *, const Affine<BnCurve> *, const Fp<BnFrP> *, size_t, Affine<BnCurve> *, int *, const MsmTables *);
 

@@ -338,6 +338,25 @@ int msm_resident(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::F
     return PM_OK;
 }
 
+template <class C>
+int msm_resident_begin(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars) {
+    const Affine<C> *bases = (const Affine<C> *)pk->d_bases + pk->res_dev_off[which];
+    if (pk->tables[which].c) {
+        MsmTables tb = pk->tables[which];
+        tb.base_index = 0;
+        return msm_begin<C>(ctx, tb.wide ? bases : (const Affine<C> *)nullptr, d_scalars, (size_t)pk->res_cnt[which], &tb);
+    }
+    return msm_begin<C>(ctx, bases, d_scalars, (size_t)pk->res_cnt[which], (const MsmTables *)nullptr);
+}
+template <class C>
+int msm_resident_end(pm_ctx *ctx, uint64_t *out_xy, int *out_inf) {
+    Affine<C> r;
+    int inf = 1;
+    PM_TRY(msm_end<C>(ctx, &r, &inf));
+    store_affine_host<C>(r, inf, out_xy, out_inf);
+    return PM_OK;
+}
+
 // PM_SHARD_PAIRS: the scalar vector is the whole logical one; this rank's pairs are the contiguous range at res_lo
 template <class C>
 static int msm_shard(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars, uint64_t *out_xy,
@@ -609,6 +628,8 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
 
 #define PM_INST(C)                                                                                                     \
     template int msm_resident<C>(pm_ctx *, const pm_pk *, int, const Fp<typename C::FrP> *, uint64_t *, int *);        \
+    template int msm_resident_begin<C>(pm_ctx *, const pm_pk *, int, const Fp<typename C::FrP> *);                     \
+    template int msm_resident_end<C>(pm_ctx *, uint64_t *, int *);                                                     \
     template int prove_phase1_impl<C>(pm_ctx *, const pm_pk *, const uint64_t *, const uint64_t *, const uint64_t *,   \
                                       uint64_t *, int *, uint64_t *, int *, bool);                                         \
     template int prove_phase2_impl<C>(pm_ctx *, const uint64_t *, uint64_t *);                                         \

@@ -462,6 +462,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     typedef Fp<P> Fr;
     PM_TRY(require_comm(ctx, pk));
     PhaseEnd phase_end(ctx, "phase 1");
+    HostProfile hp("phase 1", pk->shard_rank);
     const uint64_t n = pk->n, m0 = pk->m0, mw = pk->mw, nr = pk->nr, Lz = 2 * m0 + mw + nr;
     if (pk->log_n + 1 > (unsigned)C::TWO_ADICITY) return phase_end.ok(PM_ERR_DOMAIN_TOO_LARGE);   // prover.rs:317 -- the key's shape: all ranks
     const Layout L = pmlayout::make_layout(n, (uint32_t)pk->shard_count, (uint32_t)pk->shard_rank);
@@ -528,6 +529,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         hipLaunchKernelGGL(k_check_sap_L<P>, dim3(nblk(m)), dim3(256), 0, st, ue, we, m, flags);   // rem == 0 of prover.rs:108
         PM_HIP(ctx, hipGetLastError());
     }
+    hp.mark("upload+witness");
     // N1, N2 (prover.rs:94,96): the transforms consume their input, so the witness-only U part (N5) is prepared first
     if (!sparse_head) {
         PM_HIP(ctx, hipMemcpyAsync(tc, ue, m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
@@ -537,39 +539,6 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     }
     PM_TRY(dist_intt<C>(ctx, pk, L, ue, ta, u));
     if (q == 0) PM_HIP(ctx, hipMemcpyAsync(u + m, ra, 2 * sizeof(Fr), hipMemcpyDeviceToDevice, st));   // sc_a = u || r_a on rank 0
-    // [a]_1 on the helper context while the remaining transforms run (prove.hip does the same)
-    const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
-    if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
-    int st_a = PM_OK;
-    struct Joiner {     // an early error return must not leave the helper job running into freed stack variables
-        pm_worker *w;
-        bool pending;
-        void join() { if (pending) { w->wait(); pending = false; } }
-        ~Joiner() { join(); }
-    } helper{&ctx->worker, false};
-    bool a_early = overlap && ctx->aux;
-    if (a_early) {
-        pm_ctx *aux = ctx->aux;
-        PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
-        timing_reset(aux);
-        {
-            helper.pending = ctx->worker.submit([&, aux] {
-                if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0) != hipSuccess) {
-                    st_a = PM_ERR_HIP;
-                    aux->err = "helper stream setup failed";
-                    return;
-                }
-                try {
-                    st_a = msm_resident<C>(aux, pk, 0, u, a_xy, a_inf);
-                } catch (const std::exception &e) {
-                    st_a = PM_ERR_STATE;
-                    aux->err = e.what();
-                }
-                timing_flush(aux);
-            });
-            if (!helper.pending) a_early = false;
-        }
-    }
     PM_TRY(dist_intt<C>(ctx, pk, L, we, ta, wv));
     if (sparse_head) {
         const Fr *winv = nullptr;
@@ -599,6 +568,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
                            tail ? sc_c + zcnt + hcnt + rucnt : (Fr *)nullptr, L, flags);
         PM_HIP(ctx, hipGetLastError());
     }
+    hp.mark("transforms");
     // ONE exchange for the whole phase, after the MSMs: the status flags, the two partial points and the halo coefficients
     // phase 3 needs (the last coefficient of each of this rank's blocks).  The flags travel with the points instead of
     // ahead of them: an unsatisfied witness costs the MSMs before every rank reports it -- the rare path pays, not the proof.
@@ -616,23 +586,37 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     PM_HIP(ctx, hipGetLastError());
     PM_HIP(ctx, hipMemcpyAsync(&r1->flags, flags, 4, hipMemcpyDeviceToHost, st));
     PM_HIP(ctx, hipMemcpyAsync(my_halo, d_last, (size_t)N * sizeof(Fr), hipMemcpyDeviceToHost, st));   // both land before the MSM's final sync
+    // [a]_1 and [c]_1 are independent MSMs: both pipelines are ENQUEUED before either is waited for -- [a]_1 on the helper
+    // context's stream and workspace, behind an event on this stream; [c]_1 here -- so the smaller one's latency-bound sort
+    // front end and bucket reduction run under the larger one's accumulation.  One host thread, no collective in between
+    // (the single-GPU prover starts [a]_1 earlier, from a second thread: prove.hip).  PM_MSM_OVERLAP=0: one after the other.
     int a_inf_l = 1, c_inf_l = 1;
-    if (a_early) {
-        const int st_c = msm_resident<C>(ctx, pk, 1, sc_c, r1->c_xy, &c_inf_l);
-        helper.join();
-        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];
-        if (st_a != PM_OK) { ctx->err = ctx->aux->err; return st_a; }
+    const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
+    if (overlap && ctx->aux) {
+        pm_ctx *aux = ctx->aux;
+        timing_reset(aux);
+        PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
+        PM_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0));
+        int st_a = msm_resident_begin<C>(aux, pk, 0, u);
+        const int st_c = st_a == PM_OK ? msm_resident_begin<C>(ctx, pk, 1, sc_c) : (int)PM_OK;
+        const int en_c = st_a == PM_OK && st_c == PM_OK ? msm_resident_end<C>(ctx, r1->c_xy, &c_inf_l) : (int)PM_OK;
+        if (st_a == PM_OK) st_a = msm_resident_end<C>(aux, r1->a_xy, &a_inf_l);      // always drained: its scalars live in this context
+        timing_flush(aux);
+        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += aux->timing_ms[s];
+        if (st_a != PM_OK) { ctx->err = aux->err; return st_a; }
         PM_TRY(st_c);
-        memcpy(r1->a_xy, a_xy, sizeof(Affine<C>));
-        a_inf_l = *a_inf;
+        PM_TRY(en_c);
     } else {
         PM_TRY(msm_resident<C>(ctx, pk, 0, u, r1->a_xy, &a_inf_l));
         PM_TRY(msm_resident<C>(ctx, pk, 1, sc_c, r1->c_xy, &c_inf_l));
     }
+    hp.mark("msm_a+c");
     r1->a_inf = (uint32_t)a_inf_l;
     r1->c_inf = (uint32_t)c_inf_l;
     r1->pad = 0;
     PM_TRY(comm_status(ctx, ctx->comm->all_gather(mine.data(), all.data(), rec_bytes, st), "all_gather"));
+    hp.mark("exchange");
     unsigned hflags = 0;
     std::vector<uint64_t> pa((size_t)N * (sizeof(Affine<C>) / 8)), pc(pa.size());
     std::vector<int> ia(N), ic(N);
@@ -661,8 +645,10 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         PM_HIP(ctx, hipMemcpyAsync(ctx->halo.p, halo.data(), (size_t)N * sizeof(Fr), hipMemcpyHostToDevice, st));
         PM_HIP(ctx, hipStreamSynchronize(st));     // `halo` is a stack vector
     }
+    hp.mark("sums+halo");
     t_phase.stop();
     timing_flush(ctx);
+    hp.mark("timers");
     PM_TRY(comm_alive(ctx));
     ctx->phase = 1;
     return phase_end.ok(PM_OK);
@@ -677,6 +663,7 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
     const pm_pk *pk = ctx->pk;
     PM_TRY(require_comm(ctx, pk));
     PhaseEnd phase_end(ctx, "phase 2");
+    HostProfile hp("phase 2", pk->shard_rank);
     const Layout L = pmlayout::make_layout(pk->n, (uint32_t)pk->shard_count, (uint32_t)pk->shard_rank);
     hipStream_t st = ctx->stream;
     const Fr x1 = load_fr<P>(x1_in);
@@ -694,7 +681,9 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
     std::vector<Fr> all(L.N);
     PM_HIP(ctx, hipMemcpyAsync(&mine, out, sizeof(Fr), hipMemcpyDeviceToHost, st));
     PM_HIP(ctx, hipStreamSynchronize(st));
+    hp.mark("horner");
     PM_TRY(comm_status(ctx, ctx->comm->all_gather(&mine, all.data(), sizeof(Fr), st), "all_gather"));
+    hp.mark("exchange");
     Fr sum = Fr::zero();
     for (uint32_t r = 0; r < L.N; ++r) sum = add<P>(sum, all[r]);
     memcpy(u_at_x1, sum.l, sizeof(Fr));
@@ -713,6 +702,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     const pm_pk *pk = ctx->pk;
     PM_TRY(require_comm(ctx, pk));
     PhaseEnd phase_end(ctx, "phase 3");
+    HostProfile hp("phase 3", pk->shard_rank);
     hipStream_t st = ctx->stream;
     if (!ctx->keep_timings) timing_reset(ctx);
     TimingGuard timing_guard{ctx};
@@ -740,7 +730,9 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
         PM_HIP(ctx, hipMemcpyAsync(hV.data(), V, S * sizeof(Fr), hipMemcpyDeviceToHost, st));
     }
     PM_HIP(ctx, hipStreamSynchronize(st));
+    hp.mark("seg_reduce");
     PM_TRY(comm_status(ctx, ctx->comm->all_gather(hV.data(), hall.data(), SS * sizeof(Fr), st), "all_gather"));
+    hp.mark("exchange");
     // the chain over ALL segments in descending index order: H_b(s) = carry into s; H_a(s) = V_s + x1^(b-a) H_b(s)
     Fr Hb = Fr::zero();
     {
@@ -754,6 +746,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
             Hb = add<P>(hall[(size_t)e.rank * SS + e.idx], mul<P>(pow_val, Hb));
         }
     }
+    hp.mark("chain");
     if (!Hb.is_zero()) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);   // prover.rs:221 -- the same value on every rank
     {
         StageTimer t(ctx, T_POLY);
@@ -770,6 +763,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
         } mine3;
         int inf_l = 1;
         PM_TRY(msm_resident<C>(ctx, pk, 2, qv, mine3.xy, &inf_l));
+        hp.mark("expand+msm_d");
         mine3.inf = (uint64_t)inf_l;
         std::vector<Rec3> all3(N);
         PM_TRY(comm_status(ctx, ctx->comm->all_gather(&mine3, all3.data(), sizeof(Rec3), st), "all_gather"));
@@ -779,7 +773,9 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
             memcpy(&pts[r * (sizeof(Affine<C>) / 8)], all3[r].xy, sizeof(Affine<C>));
             infs[r] = (int)all3[r].inf;
         }
+        hp.mark("exchange_d");
         PM_TRY(pm_g1_sum(C::ID, pts.data(), infs.data(), N, d_xy, d_inf));
+        hp.mark("sum");
     }
     t_phase.stop();
     timing_flush(ctx);

@@ -345,10 +345,10 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
 MsmTables wide_plan(size_t piece) {
     MsmTables best_t;
     double best = 1e300;
-    for (unsigned nwin = 12; nwin <= 19; ++nwin) {
+    for (unsigned nwin = 12; nwin <= 16; ++nwin) {
         MsmTables t;
         tables_layout(t, nwin);
-        if (t.c < 14 || t.c > 23) continue;
+        if (t.c < 16 || t.c > 23) continue;                                   // whole 2^15-bucket regions per window (the sort's first level)
         const double NB = (double)((size_t)1 << (t.c - 1));
         if ((double)nwin * NB / 32768.0 > 512.0) continue;
         if ((double)nwin * (double)piece >= 4294967296.0) continue;          // u32 positions of the sorted entries

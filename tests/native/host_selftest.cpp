@@ -84,6 +84,17 @@ int main() {
         Bytes ob(64);
         for (int i = 0; i < 16; ++i) for (int b = 0; b < 4; ++b) ob[4 * i + b] = (uint8_t)(out[i] >> (8 * b));
         if (hex(ob) != "10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4ed2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e") { fails++; printf("chacha20 RFC 7539 KAT\n"); }
+        // ... and the TWELVE-round function StdRng actually runs, against a published known answer: draft-strombergson-chacha-test-
+        // vectors-01, TC1 (all-zero 256-bit key and IV), 12 rounds, keystream block 0 -- and the 8-round block of the same table
+        {
+            uint32_t zk[8] = {0}, zt[4] = {0};
+            chacha_block(zk, zt, 12, out);
+            for (int i = 0; i < 16; ++i) for (int b = 0; b < 4; ++b) ob[4 * i + b] = (uint8_t)(out[i] >> (8 * b));
+            if (hex(ob) != "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be") { fails++; printf("chacha12 KAT\n"); }
+            chacha_block(zk, zt, 8, out);
+            for (int i = 0; i < 16; ++i) for (int b = 0; b < 4; ++b) ob[4 * i + b] = (uint8_t)(out[i] >> (8 * b));
+            if (hex(ob) != "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42") { fails++; printf("chacha8 KAT\n"); }
+        }
         StdRng t = StdRng::test_rng();
         const unsigned long long t0 = t.next_u64();
         StdRng r = StdRng::seed_from_u64(t0);

@@ -57,7 +57,7 @@ def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, lo
     gpk = pm.setup(lc, x, z)
     assert gpk.msm_plan(2)[3] == (tables == "1")
     if tables == "wide":
-        assert all(13 <= gpk.msm_plan(k)[1] <= 19 and gpk.msm_plan(k)[2] >= 14 for k in range(3))     # wide_plan: big windows, no tables
+        assert all(12 <= gpk.msm_plan(k)[1] <= 16 and gpk.msm_plan(k)[2] >= 16 for k in range(3))     # wide_plan: big windows, no tables
     threads = os.cpu_count() or 8
     opk = oracle.OraclePk(curve, q, None, None, threads)
     for i in range(6):

@@ -32,6 +32,10 @@ def test_host_hash_known_answers(tmp_path):
     from polymath_amd.polymath import FIELDS
     key = list(struct.unpack("<8I", bytes(range(32))))                      # RFC 7539 section 2.3.2 (20 rounds)
     assert struct.pack("<16I", *R.chacha_block(key, [1, 0x09000000, 0x4A000000, 0], 20)).hex().startswith("10f1e7e4d13b5915500fdd1fa32071c4")
+    # the 12-round function StdRng runs (rand 0.8: ChaCha12), pinned by a published vector: draft-strombergson-chacha-test-vectors-01,
+    # TC1 (all-zero key and IV), 12 rounds, block 0
+    assert struct.pack("<16I", *R.chacha_block([0] * 8, [0] * 4, 12)).hex() == (
+        "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be")
     line = [l for l in out.stdout.splitlines() if l.startswith("rng ")][0].split()
     t0 = R.StdRng.test_rng().next_u64()
     assert line[1] == "test_rng_first=%016x" % t0
