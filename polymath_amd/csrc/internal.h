@@ -248,6 +248,7 @@ struct pm_ctx {
     // proof in flight
     const pm_pk *pk;
     int phase;
+    uint64_t ra_host[8];      // r_a of the proof in flight (phase 3's numerator constants need it on the host)
     bool keep_timings;   // pm_host_prove: the stage slots accumulate over the three phases of one proof
     pm::DevBuf xw, ue, we, u, w, wit_u, u2, sc_a, sc_c, quotient, ztail, lvl[6], ra;
     // PM_SHARD_VECTOR prover (prove_sharded.hip): transform temporaries, halo coefficients, roots of the cross-rank butterfly

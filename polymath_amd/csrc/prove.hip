@@ -400,6 +400,7 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     PM_HIP(ctx, hipMemcpyAsync(xw, x, m0 * sizeof(Fr), kind, st));
     if (mw) PM_HIP(ctx, hipMemcpyAsync(xw + m0, w, mw * sizeof(Fr), kind, st));
     PM_HIP(ctx, hipMemcpyAsync(ra, r_a, 2 * sizeof(Fr), hipMemcpyHostToDevice, st));
+    memcpy(ctx->ra_host, r_a, 2 * sizeof(Fr));
     {
         StageTimer t(ctx, T_WITNESS_MAP);
         CsrDev A{pk->d_rowptr[0], pk->d_col[0], pk->d_val[0]}, B{pk->d_rowptr[1], pk->d_col[1], pk->d_val[1]},
@@ -557,8 +558,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     const uint64_t n = pk->n, sigma = pk->sigma;
     Fr x1 = load_fr<P>(x1_in), x2 = load_fr<P>(x2_in), a_at = load_fr<P>(a_in), c_at = load_fr<P>(c_in);
     Fr rah[2];
-    PM_HIP(ctx, hipMemcpyAsync(rah, ctx->ra.p, sizeof(rah), hipMemcpyDeviceToHost, st));
-    PM_HIP(ctx, hipStreamSynchronize(st));
+    memcpy(rah, ctx->ra_host, sizeof(rah));          // phase 1 kept the host copy of r_a: no device read-back, no synchronisation here
     NumParams np{n, sigma, 8 * sigma + 2 * n - 1};
     const NumConsts<P> nc = make_num_consts<P>(x2, rah, a_at, c_at);
     // levels of the chunked recurrence

@@ -515,6 +515,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         }
     }
     PM_HIP(ctx, hipMemcpyAsync(ra, r_a, 2 * sizeof(Fr), hipMemcpyHostToDevice, st));
+    memcpy(ctx->ra_host, r_a, 2 * sizeof(Fr));
     CsrDev A{pk->d_rowptr[0], pk->d_col[0], pk->d_val[0]}, Bm{pk->d_rowptr[1], pk->d_col[1], pk->d_val[1]},
         Cm{pk->d_rowptr[2], pk->d_col[2], pk->d_val[2]};
     const bool sparse_head = 2 * m0 <= 16;
@@ -711,8 +712,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     const uint32_t N = (uint32_t)pk->shard_count, q = (uint32_t)pk->shard_rank;
     const Fr x1 = load_fr<P>(x1_in), x2 = load_fr<P>(x2_in), a_at = load_fr<P>(a_in), c_at = load_fr<P>(c_in);
     Fr rah[2];
-    PM_HIP(ctx, hipMemcpyAsync(rah, ctx->ra.p, sizeof(rah), hipMemcpyDeviceToHost, st));
-    PM_HIP(ctx, hipStreamSynchronize(st));
+    memcpy(rah, ctx->ra_host, sizeof(rah));          // phase 1 kept the host copy of r_a: no device read-back, no synchronisation here
     const NumConsts<P> nc = make_num_consts<P>(x2, rah, a_at, c_at);
     const SegData sd{n, sigma};
     const size_t S = pk->segs.size(), SS = pk->seg_slots;   // SS = the longest segment list of any rank (the exchanged record size)

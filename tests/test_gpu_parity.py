@@ -530,6 +530,30 @@ def test_bench_gpus_2_starts_its_own_ranks():
         assert "HOST buffers" in j["timed_entry_point"] and j["ms_per_step_hbm_resident"] > 0
 
 
+def test_bench_fallback_chain_when_rccl_cannot_serve_the_job():
+    """Two ranks on ONE GPU with nothing pinned: RCCL refuses two ranks on one device, so attempt 0 (torch.distributed = nccl) dies
+    in its first collective, the supervisor moves on, and the next attempt (gloo process group; the library's RCCL communicator
+    fails to come up on every rank, so all of them agree on the host-staged exchange) completes.  What the launcher does on a
+    fabric that will not come up, seen end to end: one JSON line, from a later attempt, with the single-GPU proof."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    env = dict(os.environ, BENCH_FORCE_DEVICE="0", BENCH_ATTEMPT_DEADLINE_S="300")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_DIST_BACKEND", "BENCH_NO_RCCL"):
+        env.pop(k, None)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True, timeout=1500, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads(lines[0])
+    assert j2["launch"]["attempt"] >= 1 and "attempt 0 failed" in two.stderr
+    assert j2["n_gpus"] == 2 and j2["n_ranks_seen"] == 2 and j2["proof_bytes"] == j1["proof_bytes"] and j2["proof_verified"]
+    assert j2["exchange"]["fallback_reason"]                      # ... and the line says why the preferred exchange was not used
+
+
 def test_bench_dead_rank_ends_the_job_non_zero():
     """A rank that dies in the middle of the timed proofs (test hook BENCH_TEST_DIE): the job exits NON-ZERO well inside the
     deadline -- no hang -- and prints no JSON line.  (Transport here: gloo callbacks; the library-level deadline and abort
