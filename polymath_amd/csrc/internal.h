@@ -310,7 +310,7 @@ int msm_begin(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *
 template <class C>
 int msm_end(pm_ctx *ctx, Affine<C> *h_out, int *h_inf);
 template <class C>
-int msm_resident_begin(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars);
+int msm_resident_begin(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars, uint64_t lo = 0, uint64_t count = 0);
 template <class C>
 int msm_resident_end(pm_ctx *ctx, uint64_t *out_xy, int *out_inf);
 

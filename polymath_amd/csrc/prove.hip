@@ -338,15 +338,18 @@ int msm_resident(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::F
     return PM_OK;
 }
 
+// pairs [lo, lo + count) of MSM `which` (count = 0: all of them); d_scalars points at the MSM's FIRST scalar
 template <class C>
-int msm_resident_begin(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars) {
+int msm_resident_begin(pm_ctx *ctx, const pm_pk *pk, int which, const Fp<typename C::FrP> *d_scalars, uint64_t lo, uint64_t count) {
     const Affine<C> *bases = (const Affine<C> *)pk->d_bases + pk->res_dev_off[which];
+    if (count == 0) { lo = 0; count = pk->res_cnt[which]; }
+    if (lo + count > pk->res_cnt[which]) return PM_ERR_INVALID_ARG;
     if (pk->tables[which].c) {
         MsmTables tb = pk->tables[which];
-        tb.base_index = 0;
-        return msm_begin<C>(ctx, tb.wide ? bases : (const Affine<C> *)nullptr, d_scalars, (size_t)pk->res_cnt[which], &tb);
+        tb.base_index = (size_t)lo;
+        return msm_begin<C>(ctx, tb.wide ? bases : (const Affine<C> *)nullptr, d_scalars + lo, (size_t)count, &tb);
     }
-    return msm_begin<C>(ctx, bases, d_scalars, (size_t)pk->res_cnt[which], (const MsmTables *)nullptr);
+    return msm_begin<C>(ctx, bases + lo, d_scalars + lo, (size_t)count, (const MsmTables *)nullptr);
 }
 template <class C>
 int msm_resident_end(pm_ctx *ctx, uint64_t *out_xy, int *out_inf) {
@@ -628,7 +631,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
 
 #define PM_INST(C)                                                                                                     \
     template int msm_resident<C>(pm_ctx *, const pm_pk *, int, const Fp<typename C::FrP> *, uint64_t *, int *);        \
-    template int msm_resident_begin<C>(pm_ctx *, const pm_pk *, int, const Fp<typename C::FrP> *);                     \
+    template int msm_resident_begin<C>(pm_ctx *, const pm_pk *, int, const Fp<typename C::FrP> *, uint64_t, uint64_t);  \
     template int msm_resident_end<C>(pm_ctx *, uint64_t *, int *);                                                     \
     template int prove_phase1_impl<C>(pm_ctx *, const pm_pk *, const uint64_t *, const uint64_t *, const uint64_t *,   \
                                       uint64_t *, int *, uint64_t *, int *, bool);                                         \

@@ -357,16 +357,24 @@ __device__ __forceinline__ Fp<P> numerator_seg(const Segment &g, uint64_t j, con
     }
 }
 
-constexpr unsigned SEG_THREADS = 1024;
+constexpr unsigned SEG_THREADS_MAX = 1024;   // lane values are stored with this stride whatever the workgroup size
 
 // One workgroup per segment.  Lane t owns the `span` consecutive indices from a + t span:  v_t = their local Horner
 // value; V = sum_t v_t x1^(t span) is the segment's value H_a with carry-in 0.  v_t is kept for the expansion.
-template <class P>
+template <class P, unsigned SEG_THREADS>
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_reduce(const Segment *segs, SegData sd, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u,
                                                             const Fp<P> *u2lo, const Fp<P> *u2hi, const Fp<P> *halo, Fp<P> x1, Fp<P> *lane_vals,
                                                             Fp<P> *V) {
     __shared__ Fp<P> sh[SEG_THREADS];
     const Segment g = segs[blockIdx.x];
+    if (g.kind == pmlayout::SEG_FILLER) {   // most filler segments hold zeros only (the constants sit at 0, 1 and 2 sigma .. 2 sigma + 2): V = 0
+        const uint64_t s2 = 2 * sd.sigma;
+        if (!(g.a < 2 || (g.a < s2 + 3 && g.b > s2))) {     // uniform over the workgroup
+            lane_vals[(size_t)blockIdx.x * SEG_THREADS_MAX + threadIdx.x] = Fp<P>::zero();
+            if (threadIdx.x == 0) V[blockIdx.x] = Fp<P>::zero();
+            return;
+        }
+    }
     const uint64_t len = g.b - g.a, span = (len + SEG_THREADS - 1) / SEG_THREADS;
     const uint64_t lo = (uint64_t)threadIdx.x * span;
     uint64_t hi = lo + span;
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_reduce(const Segment *segs,
     if (lo < len) {
         for (uint64_t j = hi; j-- > lo;) acc = add<P>(mul<P>(acc, x1), numerator_seg<P>(g, j, sd, nc, u, wit_u, u2lo, u2hi, halo));
     }
-    lane_vals[(size_t)blockIdx.x * SEG_THREADS + threadIdx.x] = acc;
+    lane_vals[(size_t)blockIdx.x * SEG_THREADS_MAX + threadIdx.x] = acc;
     sh[threadIdx.x] = lo < len ? mul<P>(acc, pow_u64<P>(x1, lo)) : acc;
     __syncthreads();
     for (unsigned off = SEG_THREADS / 2; off > 0; off >>= 1) {
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_reduce(const Segment *segs,
 // carry[s] = H_b of segment s (from the chain over ALL ranks' segment values).  Suffix scan of the lane values with the
 // constant multiplier X = x1^span (every lane but the last active one owns a full span; the carry-in is folded into the
 // last lane's value), then every lane re-walks its span and writes q_{k-1} = H_k.
-template <class P>
+template <class P, unsigned SEG_THREADS>
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_expand(const Segment *segs, SegData sd, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u,
                                                             const Fp<P> *u2lo, const Fp<P> *u2hi, const Fp<P> *halo, Fp<P> x1,
                                                             const Fp<P> *lane_vals, const Fp<P> *carry, Fp<P> *q) {
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_expand(const Segment *segs,
     const Fp<P> cin = carry[blockIdx.x];
     Fp<P> w = Fp<P>::zero();
     if (t < active) {
-        w = lane_vals[(size_t)blockIdx.x * SEG_THREADS + t];
+        w = lane_vals[(size_t)blockIdx.x * SEG_THREADS_MAX + t];
         if (t == active - 1) w = add<P>(w, mul<P>(cin, pow_u64<P>(x1, hi - lo)));
     }
     sh[t] = w;
@@ -717,7 +725,10 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     const SegData sd{n, sigma};
     const size_t S = pk->segs.size(), SS = pk->seg_slots;   // SS = the longest segment list of any rank (the exchanged record size)
     PM_HIP(ctx, ctx->quotient.reserve((pk->res_cnt[2] + 1) * sizeof(Fr)));
-    PM_HIP(ctx, ctx->lvl[0].reserve(S * SEG_THREADS * sizeof(Fr)));    // lane values
+    PM_HIP(ctx, ctx->lvl[0].reserve(S * SEG_THREADS_MAX * sizeof(Fr)));    // lane values
+    // 512 lanes per segment: with ~256-400 segments per rank every CU holds one or two workgroups at 2-4 waves per SIMD (1024 lanes
+    // and half as many segments left a third of the chip idle and four waves queueing on each busy SIMD); PM_SEG_THREADS=1024: round 2
+    const bool seg512 = [] { const char *e = getenv("PM_SEG_THREADS"); return !(e && atoi(e) == 1024); }();
     PM_HIP(ctx, ctx->lvl[1].reserve(2 * S * sizeof(Fr)));              // V | carry
     Fr *qv = ctx->quotient.as<Fr>(), *lane_vals = ctx->lvl[0].as<Fr>(), *V = ctx->lvl[1].as<Fr>(), *carry = V + S;
     const Fr *u = ctx->u.as<Fr>(), *wit_u = ctx->wit_u.as<Fr>(), *u2lo = ctx->u2.as<Fr>(), *u2hi = u2lo + m, *halo = ctx->halo.as<Fr>();
@@ -725,7 +736,8 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     std::vector<Fr> hV(SS, Fr::zero()), hall(SS * N), hcarry(S);
     {
         StageTimer t(ctx, T_POLY);
-        hipLaunchKernelGGL(k_seg_reduce<P>, dim3((unsigned)S), dim3(SEG_THREADS), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1, lane_vals, V);
+        if (seg512) hipLaunchKernelGGL((k_seg_reduce<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1, lane_vals, V);
+        else hipLaunchKernelGGL((k_seg_reduce<P, 1024>), dim3((unsigned)S), dim3(1024), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1, lane_vals, V);
         PM_HIP(ctx, hipGetLastError());
         PM_HIP(ctx, hipMemcpyAsync(hV.data(), V, S * sizeof(Fr), hipMemcpyDeviceToHost, st));
     }
@@ -751,8 +763,10 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     {
         StageTimer t(ctx, T_POLY);
         PM_HIP(ctx, hipMemcpyAsync(carry, hcarry.data(), S * sizeof(Fr), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_seg_expand<P>, dim3((unsigned)S), dim3(SEG_THREADS), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
-                           (const Fr *)lane_vals, (const Fr *)carry, qv);
+        if (seg512) hipLaunchKernelGGL((k_seg_expand<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
+                                       (const Fr *)lane_vals, (const Fr *)carry, qv);
+        else hipLaunchKernelGGL((k_seg_expand<P, 1024>), dim3((unsigned)S), dim3(1024), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
+                                (const Fr *)lane_vals, (const Fr *)carry, qv);
         PM_HIP(ctx, hipGetLastError());
     }
     // [d]_1 = M8, prover.rs:229: this rank's partial sum, then the sum over the ranks (all-gather + local adds, like phase 1)
@@ -762,7 +776,35 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
             uint64_t inf;
         } mine3;
         int inf_l = 1;
-        PM_TRY(msm_resident<C>(ctx, pk, 2, qv, mine3.xy, &inf_l));
+        // PM_MSM_SPLIT_D=1 (experiment): the quotient MSM as two half-length pipelines enqueued back to back on the helper
+        // context and on this one, like [a]_1 / [c]_1 of phase 1 -- each half's sort front end, tail and bucket reduction under
+        // the other's accumulation, for a second bucket set to reduce
+        const bool split_d = [] { const char *e = getenv("PM_MSM_SPLIT_D"); return e && e[0] == '1'; }();
+        if (split_d && pk->tables[2].c && !pk->tables[2].wide && (ctx->aux || pm_ctx_create(ctx->device, &ctx->aux) == PM_OK)) {
+            pm_ctx *aux = ctx->aux;
+            const uint64_t len = pk->res_cnt[2], half = len / 2;
+            timing_reset(aux);
+            PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
+            PM_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0));
+            uint64_t xy2[sizeof(Affine<C>) / 8];
+            int inf2 = 1;
+            int s1 = msm_resident_begin<C>(aux, pk, 2, qv, 0, half);
+            const int s2 = s1 == PM_OK ? msm_resident_begin<C>(ctx, pk, 2, qv, half, len - half) : (int)PM_OK;
+            const int e2 = s1 == PM_OK && s2 == PM_OK ? msm_resident_end<C>(ctx, mine3.xy, &inf_l) : (int)PM_OK;
+            if (s1 == PM_OK) s1 = msm_resident_end<C>(aux, xy2, &inf2);
+            timing_flush(aux);
+            for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += aux->timing_ms[s];
+            if (s1 != PM_OK) { ctx->err = aux->err; return s1; }
+            PM_TRY(s2);
+            PM_TRY(e2);
+            uint64_t two[2 * (sizeof(Affine<C>) / 8)];
+            int infs2[2] = {inf_l, inf2};
+            memcpy(two, mine3.xy, sizeof(Affine<C>));
+            memcpy(two + sizeof(Affine<C>) / 8, xy2, sizeof(Affine<C>));
+            PM_TRY(pm_g1_sum(C::ID, two, infs2, 2, mine3.xy, &inf_l));
+        } else {
+            PM_TRY(msm_resident<C>(ctx, pk, 2, qv, mine3.xy, &inf_l));
+        }
         hp.mark("expand+msm_d");
         mine3.inf = (uint64_t)inf_l;
         std::vector<Rec3> all3(N);

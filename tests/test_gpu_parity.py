@@ -632,6 +632,18 @@ def test_reference_bench_circuit_skew(oracle):
     assert PR.verify_proof(c, vk, proof.as_dict(), inst[1:], T.make_transcripts(c)["merlin"], PA.pairing_check)
     assert dt < 0.2, "skewed proof took %.0f ms: hot buckets are being reduced sequentially again" % (dt * 1e3)
     pk.free()
+    # the same skew through the WIDE mode (no tables, one bucket set per window: the hot bucket of every window is folded inside
+    # its own set) and through the per-window pipeline: identical bytes
+    import os
+    for mode in ("wide", "0"):
+        os.environ["PM_TABLES"] = mode
+        try:
+            pk2 = pm.setup((r1cs, inst, wit), x, z)
+            assert not pk2.msm_plan(1)[3]
+            assert pm.prove_limbs(pk2, inst, xl, wl, r_a).to_bytes() == proof.to_bytes(), mode
+            pk2.free()
+        finally:
+            del os.environ["PM_TABLES"]
 
 
 def test_phase1_device_resident_assignment_equals_host(gpu_ctx, oracle, api):

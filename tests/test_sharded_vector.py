@@ -473,6 +473,63 @@ def test_rccl_comm_world_of_one():
     comm.close()
 
 
+_WATCHDOG_SCRIPT = r"""
+import ctypes as ct, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from polymath_amd import api
+hip = ct.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [ct.POINTER(ct.c_void_p), ct.c_size_t]
+hip.hipStreamCreate.argtypes = [ct.POINTER(ct.c_void_p)]
+hip.hipMemcpyAsync.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p]
+hip.hipStreamSynchronize.argtypes = [ct.c_void_p]
+ctx = api.Context(0)
+comm = api.Comm.rccl(api.Comm.rccl_unique_id(), 0, 1, 0)
+assert comm.kind == "rccl" and not comm.failed
+st = ct.c_void_p()
+assert hip.hipStreamCreate(ct.byref(st)) == 0
+big = 1 << 30
+a, b, s, r = ct.c_void_p(), ct.c_void_p(), ct.c_void_p(), ct.c_void_p()
+for p, n in ((a, big), (b, big), (s, 4096), (r, 4096)):
+    assert hip.hipMalloc(ct.byref(p), n) == 0
+comm.all_to_all_device(s.value, r.value, 4096, st.value)            # healthy: completes
+assert hip.hipStreamSynchronize(st) == 0 and not comm.failed
+comm.set_timeout_ms(2)
+for _ in range(400):                                                 # ~0.5 s of copies queued AHEAD of the collective
+    assert hip.hipMemcpyAsync(b, a, big, 3, st) == 0
+t0 = time.time()
+comm.all_to_all_device(s.value, r.value, 4096, st.value)            # cannot complete within 2 ms: the watchdog must abort the communicator
+hip.hipStreamSynchronize(st)
+deadline = time.time() + 20
+while not comm.failed and time.time() < deadline:
+    time.sleep(0.01)
+assert comm.failed, "the watchdog did not fire"
+print("FIRED after %.2f s: %s" % (time.time() - t0, comm.last_error()))
+try:
+    comm.all_gather(np.arange(3, dtype=np.int64))
+    print("STILL ALIVE")
+except api.PolymathError as e:
+    print("STICKY", e.status)
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_watchdog_aborts_a_collective_that_misses_its_deadline(tmp_path):
+    """The RCCL half of the fail-fast contract, on the one GPU of this box: a communicator (world of one) with a 2 ms deadline and
+    a collective queued behind half a second of copies on its stream -- the completion event cannot arrive in time, so the
+    watchdog thread must call ncclCommAbort and mark the communicator failed; later collectives return PM_ERR_COMM at once.
+    (A real dead PEER cannot be staged on one GPU -- RCCL refuses two ranks on one device; this exercises the watchdog, the abort
+    and the sticky failure on the real library.)  Runs in a child process: a misbehaving abort must not take pytest down."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "watchdog.py"
+    script.write_text(_WATCHDOG_SCRIPT)
+    run = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-3000:])
+    assert "FIRED" in run.stdout and "did not complete within 2 ms" in run.stdout and "STICKY 9" in run.stdout, run.stdout
+    assert "aborting the RCCL communicator" in run.stderr
+
+
 @pytest.mark.gpu
 def test_config_2p22_eight_ranks_vector_sharded():
     """BASELINE configs[2] as named -- the 2^22-100-gate circuit (n = 2^23, 117 M MSM pairs) proved as ONE proof by 8 ranks

@@ -11,6 +11,10 @@ os.environ["PM_LOCAL_COMM_SERIALIZE"] = "1"
 # PM_MSM_OVERLAP (default on): a rank enqueues its [a] and [c] MSM pipelines on two streams from ONE host thread, with no collective
 # in between, so the overlap happens entirely inside the rank's turn -- as it does on a GPU of its own.  (Round 2's helper THREAD
 # escaped the turnstile; the emulation then ran with PM_MSM_OVERLAP=0.)
+# The N emulated ranks share ONE process, hence one set of hardware queues (ROCm default: 4); a real rank has its process's queues
+# to itself.  With 2 N streams on 4 queues a rank's two MSM streams often land on the same queue and serialise (per-rank busy time
+# bimodal: 12.0 / 13.3 ms at N = 8); 8 queues restore what a rank sees on a GPU of its own (profiles/r03_m_*).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from polymath_amd import api, circuits as PC   # noqa: E402
 from polymath_amd.polymath import Polymath, FIELDS   # noqa: E402
 
