@@ -185,7 +185,7 @@ def main():
     if not os.environ.get("BENCH_CHILD"):
         world_env = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
         # the deadline of one attempt: import + synthesis + key setup + K proofs, generous; scaled with the circuit
-        deadline = int(os.environ.get("BENCH_ATTEMPT_DEADLINE_S", str(600 * (1 << max(0, args.log_constraints - 20)) + 60 * args.steps)))
+        deadline = int(os.environ.get("BENCH_ATTEMPT_DEADLINE_S", str(900 * (1 << max(0, args.log_constraints - 20)) + 60 * args.steps)))
         if under_launcher and (world_env > 1 or os.environ.get("BENCH_FORCE_VECTOR")):
             if world_env != args.gpus and world_env > 1:
                 raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world_env))
@@ -223,7 +223,7 @@ def worker(args):
     def stage(name, limit_s):
         if wd:
             wd.stage_begin(name, limit_s)
-    stage("import torch + rendezvous", 420)
+    stage("import torch + rendezvous", 600 + (600 if int(os.environ.get("BENCH_ATTEMPT", "0")) > 0 else 0))
     import datetime
     import numpy as np
     import torch
@@ -240,10 +240,17 @@ def worker(args):
     multi = world > 1 or force_vec
     if multi:
         pg_timeout = datetime.timedelta(seconds=max(2 * comm_timeout_s, 120))
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=pg_timeout)
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        attempt = int(os.environ.get("BENCH_ATTEMPT", "0"))
+        if supervised and attempt > 0:
+            # A retry meets on a store of its own (launch.py gave it a fresh port).  Under an external launcher the ranks'
+            # supervisors notice the previous attempt's failure at different times -- the rank that failed at once, its peers when
+            # their collective deadline passed -- so the rendezvous waits much longer than any collective does.
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0,
+                                  timeout=datetime.timedelta(seconds=600), wait_for_workers=True)
+            dist.init_process_group(backend, store=store, rank=rank, world_size=world, timeout=pg_timeout, **kw)
         else:
-            dist.init_process_group(backend, timeout=pg_timeout)
+            dist.init_process_group(backend, timeout=pg_timeout, **kw)
         dist.barrier()          # every rank is up before anybody starts the expensive part
 
     from polymath_amd import circuits as PC

@@ -552,6 +552,16 @@ def test_bench_fallback_chain_when_rccl_cannot_serve_the_job():
     assert j2["launch"]["attempt"] >= 1 and "attempt 0 failed" in two.stderr
     assert j2["n_gpus"] == 2 and j2["n_ranks_seen"] == 2 and j2["proof_bytes"] == j1["proof_bytes"] and j2["proof_verified"]
     assert j2["exchange"]["fallback_reason"]                      # ... and the line says why the preferred exchange was not used
+    # the same under an external launcher (how the driver starts N > 1): every torchrun worker supervises its own rank's child;
+    # the retry meets on a TCP store of its own, next to the launcher's
+    three = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29561", os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                           capture_output=True, text=True, timeout=1500, env=env)
+    assert three.returncode == 0, three.stderr[-3000:]
+    lines = [l for l in three.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j3 = json.loads(lines[0])
+    assert j3["launch"]["attempt"] >= 1 and j3["n_ranks_seen"] == 2 and j3["proof_bytes"] == j1["proof_bytes"]
 
 
 def test_bench_dead_rank_ends_the_job_non_zero():
