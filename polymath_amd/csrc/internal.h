@@ -248,6 +248,8 @@ struct pm_ctx {
     // proof in flight
     const pm_pk *pk;
     int phase;
+    std::vector<uint8_t> seg_all;   // sharded prover: phase 2's exchanged records ([u(x1) partial | P_s | Q_s] per rank) for phase 3
+    uint64_t x1_host[4];      // ... and the x1 they were taken at
     uint64_t ra_host[8];      // r_a of the proof in flight (phase 3's numerator constants need it on the host)
     bool keep_timings;   // pm_host_prove: the stage slots accumulate over the three phases of one proof
     pm::DevBuf xw, ue, we, u, w, wit_u, u2, sc_a, sc_c, quotient, ztail, lvl[6], ra;

@@ -359,47 +359,100 @@ __device__ __forceinline__ Fp<P> numerator_seg(const Segment &g, uint64_t j, con
 
 constexpr unsigned SEG_THREADS_MAX = 1024;   // lane values are stored with this stride whatever the workgroup size
 
-// One workgroup per segment.  Lane t owns the `span` consecutive indices from a + t span:  v_t = their local Horner
-// value; V = sum_t v_t x1^(t span) is the segment's value H_a with carry-in 0.  v_t is kept for the expansion.
+// The division scan in two halves that straddle the second challenge.  The numerator's coefficients depend on x2 (and on a, c at
+// x1, which come after it) only through a handful of constants: on a data segment N_k = c1 D1_k + c2 D2_k (+ one constant at the
+// first index of the u region), with D1, D2 this rank's coefficient arrays -- wit_u, (u^2)_lo, (u^2)_hi, or (u_i, u_{i-1}).  So
+// the Horner sums of the DATA at x1 can be taken as soon as x1 is known (phase 2) and travel with the u(x1) partials; phase 3 then
+// needs no exchange before its MSM: every rank derives all segment values V_s = c1 P_s + c2 Q_s + constants on the host.
+//
+// k_seg_base (phase 2): one workgroup per segment; lane t owns the `span` consecutive indices from a + t span:
+//   laneP[t] = sum_j D1_{lo + j} x1^j,  laneQ[t] likewise for D2 (u region only);  P_s = sum_t laneP[t] x1^(t span), Q_s likewise.
+template <class P>
+__device__ __forceinline__ void seg_data(const Segment &g, uint64_t j, const SegData &sd, const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2lo,
+                                         const Fp<P> *u2hi, const Fp<P> *halo, Fp<P> &d1, Fp<P> &d2) {
+    d1 = Fp<P>::zero();
+    d2 = Fp<P>::zero();
+    switch (g.kind) {
+        case pmlayout::SEG_WITU: d1 = wit_u[g.loc0 + j]; break;
+        case pmlayout::SEG_U2LO: d1 = u2lo[g.loc0 + j]; break;
+        case pmlayout::SEG_U2HI: d1 = u2hi[g.loc0 + j]; break;
+        case pmlayout::SEG_U: {
+            const uint64_t i = g.a + j - 5 * sd.sigma;
+            if (i < sd.n) d1 = u[g.loc0 + j];
+            if (i > 0) d2 = (j == 0 && g.halo) ? halo[g.halo - 1] : u[g.loc0 + j - 1];
+            break;
+        }
+        default: break;
+    }
+}
+
 template <class P, unsigned SEG_THREADS>
-__global__ __launch_bounds__(SEG_THREADS) void k_seg_reduce(const Segment *segs, SegData sd, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u,
-                                                            const Fp<P> *u2lo, const Fp<P> *u2hi, const Fp<P> *halo, Fp<P> x1, Fp<P> *lane_vals,
-                                                            Fp<P> *V) {
+__global__ __launch_bounds__(SEG_THREADS) void k_seg_base(const Segment *segs, SegData sd, const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2lo,
+                                                          const Fp<P> *u2hi, const Fp<P> *halo, Fp<P> x1, Fp<P> *laneP, Fp<P> *laneQ, Fp<P> *Pseg,
+                                                          Fp<P> *Qseg) {
     __shared__ Fp<P> sh[SEG_THREADS];
     const Segment g = segs[blockIdx.x];
-    if (g.kind == pmlayout::SEG_FILLER) {   // most filler segments hold zeros only (the constants sit at 0, 1 and 2 sigma .. 2 sigma + 2): V = 0
-        const uint64_t s2 = 2 * sd.sigma;
-        if (!(g.a < 2 || (g.a < s2 + 3 && g.b > s2))) {     // uniform over the workgroup
-            lane_vals[(size_t)blockIdx.x * SEG_THREADS_MAX + threadIdx.x] = Fp<P>::zero();
-            if (threadIdx.x == 0) V[blockIdx.x] = Fp<P>::zero();
-            return;
-        }
+    const size_t at = (size_t)blockIdx.x * SEG_THREADS_MAX + threadIdx.x;
+    if (g.kind == pmlayout::SEG_FILLER) {      // no data: zeros and a few constants that only exist once x2 is known (phase 3)
+        laneP[at] = Fp<P>::zero();
+        laneQ[at] = Fp<P>::zero();
+        if (threadIdx.x == 0) { Pseg[blockIdx.x] = Fp<P>::zero(); Qseg[blockIdx.x] = Fp<P>::zero(); }
+        return;
     }
+    const bool two = g.kind == pmlayout::SEG_U;
     const uint64_t len = g.b - g.a, span = (len + SEG_THREADS - 1) / SEG_THREADS;
     const uint64_t lo = (uint64_t)threadIdx.x * span;
     uint64_t hi = lo + span;
     if (hi > len) hi = len;
-    Fp<P> acc = Fp<P>::zero();
+    Fp<P> accP = Fp<P>::zero(), accQ = Fp<P>::zero();
     if (lo < len) {
-        for (uint64_t j = hi; j-- > lo;) acc = add<P>(mul<P>(acc, x1), numerator_seg<P>(g, j, sd, nc, u, wit_u, u2lo, u2hi, halo));
+        for (uint64_t j = hi; j-- > lo;) {
+            Fp<P> d1, d2;
+            seg_data<P>(g, j, sd, u, wit_u, u2lo, u2hi, halo, d1, d2);
+            accP = add<P>(mul<P>(accP, x1), d1);
+            if (two) accQ = add<P>(mul<P>(accQ, x1), d2);
+        }
     }
-    lane_vals[(size_t)blockIdx.x * SEG_THREADS_MAX + threadIdx.x] = acc;
-    sh[threadIdx.x] = lo < len ? mul<P>(acc, pow_u64<P>(x1, lo)) : acc;
+    laneP[at] = accP;
+    laneQ[at] = accQ;
+    const Fp<P> xl = lo < len ? pow_u64<P>(x1, lo) : Fp<P>::zero();
+    sh[threadIdx.x] = lo < len ? mul<P>(accP, xl) : accP;
     __syncthreads();
     for (unsigned off = SEG_THREADS / 2; off > 0; off >>= 1) {
         if (threadIdx.x < off) sh[threadIdx.x] = add<P>(sh[threadIdx.x], sh[threadIdx.x + off]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) V[blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) Pseg[blockIdx.x] = sh[0];
+    __syncthreads();
+    sh[threadIdx.x] = two && lo < len ? mul<P>(accQ, xl) : Fp<P>::zero();
+    __syncthreads();
+    for (unsigned off = SEG_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = add<P>(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) Qseg[blockIdx.x] = sh[0];
 }
 
-// carry[s] = H_b of segment s (from the chain over ALL ranks' segment values).  Suffix scan of the lane values with the
+// 512 lanes per segment: with ~256-400 segments per rank every CU holds one or two workgroups at 2-4 waves per SIMD (1024 lanes and
+// half as many segments left a third of the chip idle and four waves queueing on each busy SIMD); PM_SEG_THREADS=1024: round 2
+static bool seg_threads_512() {
+    static const bool v = [] { const char *e = getenv("PM_SEG_THREADS"); return !(e && atoi(e) == 1024); }();
+    return v;
+}
+
+// does [a, b) contain one of the numerator's constants (indices 0, 1, 2 sigma .. 2 sigma + 2)?
+__host__ __device__ inline bool filler_has_const(uint64_t a, uint64_t b, uint64_t sigma) {
+    const uint64_t s2 = 2 * sigma;
+    return a < 2 || (a < s2 + 3 && b > s2);
+}
+
+// k_seg_expand (phase 3).  carry[s] = H_b of segment s (from the chain over ALL ranks' segment values).  Suffix scan of the lane values with the
 // constant multiplier X = x1^span (every lane but the last active one owns a full span; the carry-in is folded into the
 // last lane's value), then every lane re-walks its span and writes q_{k-1} = H_k.
 template <class P, unsigned SEG_THREADS>
 __global__ __launch_bounds__(SEG_THREADS) void k_seg_expand(const Segment *segs, SegData sd, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u,
                                                             const Fp<P> *u2lo, const Fp<P> *u2hi, const Fp<P> *halo, Fp<P> x1,
-                                                            const Fp<P> *lane_vals, const Fp<P> *carry, Fp<P> *q) {
+                                                            const Fp<P> *laneP, const Fp<P> *laneQ, const Fp<P> *carry, Fp<P> *q) {
     __shared__ Fp<P> sh[SEG_THREADS];
     const Segment g = segs[blockIdx.x];
     const uint64_t len = g.b - g.a, span = (len + SEG_THREADS - 1) / SEG_THREADS;
@@ -410,7 +463,24 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_expand(const Segment *segs,
     const Fp<P> cin = carry[blockIdx.x];
     Fp<P> w = Fp<P>::zero();
     if (t < active) {
-        w = lane_vals[(size_t)blockIdx.x * SEG_THREADS_MAX + t];
+        // this lane's Horner value of the numerator (carry-in 0) from phase 2's data sums and the constants phase 3 brought
+        const size_t at = (size_t)blockIdx.x * SEG_THREADS_MAX + t;
+        switch (g.kind) {
+            case pmlayout::SEG_WITU:
+            case pmlayout::SEG_U2LO:
+            case pmlayout::SEG_U2HI: w = mul<P>(nc.x2, laneP[at]); break;
+            case pmlayout::SEG_U: {
+                const Fp<P> p = laneP[at];
+                w = add<P>(add<P>(p, mul<P>(nc.two_x2_r0, p)), mul<P>(nc.two_x2_r1, laneQ[at]));
+                const uint64_t k0 = 5 * sd.sigma;                        // the constant term sits at the region's first index
+                if (g.a + lo <= k0 && k0 < g.a + hi) w = add<P>(w, mul<P>(nc.minus_const, pow_u64<P>(x1, k0 - g.a - lo)));
+                break;
+            }
+            default:
+                if (filler_has_const(g.a + lo, g.a + hi, sd.sigma))      // a handful of lanes in the whole proof
+                    for (uint64_t j = hi; j-- > lo;) w = add<P>(mul<P>(w, x1), numerator_seg<P>(g, j, sd, nc, u, wit_u, u2lo, u2hi, halo));
+                break;
+        }
         if (t == active - 1) w = add<P>(w, mul<P>(cin, pow_u64<P>(x1, hi - lo)));
     }
     sh[t] = w;
@@ -680,22 +750,43 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
     while (Lh > L.B) Lh >>= 1;
     const uint64_t lanes = L.m / Lh;
     const unsigned blocks = nblk(lanes);
-    PM_HIP(ctx, ctx->scratch.reserve(((size_t)blocks + 1) * sizeof(Fr)));
+    const size_t S = pk->segs.size(), SS = pk->seg_slots;   // SS = the longest segment list of any rank (the exchanged record size)
+    const size_t rec = 1 + 2 * SS;                          // [ u(x1) partial | P_s (SS) | Q_s (SS) ]
+    PM_HIP(ctx, ctx->scratch.reserve(((size_t)blocks + rec) * sizeof(Fr)));
+    PM_HIP(ctx, ctx->lvl[0].reserve(2 * S * SEG_THREADS_MAX * sizeof(Fr)));    // lane values of the division scan: laneP | laneQ
     Fr *part = ctx->scratch.as<Fr>(), *out = part + blocks;
+    Fr *laneP = ctx->lvl[0].as<Fr>(), *laneQ = laneP + S * SEG_THREADS_MAX;
     hipLaunchKernelGGL(k_horner_partial_L<P>, dim3(blocks), dim3(256), 0, st, ctx->u.as<Fr>(), L, x1, Lh, part);
     PM_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_phase2_pack<P>, dim3(1), dim3(256), 0, st, (const Fr *)part, blocks, out);
     PM_HIP(ctx, hipGetLastError());
-    Fr mine;
-    std::vector<Fr> all(L.N);
-    PM_HIP(ctx, hipMemcpyAsync(&mine, out, sizeof(Fr), hipMemcpyDeviceToHost, st));
+    {   // the x1-dependent half of phase 3's division scan (k_seg_base): its segment sums ride on this phase's exchange
+        StageTimer t(ctx, T_POLY);
+        const SegData sd{pk->n, pk->sigma};
+        const uint64_t m = pk->n / (uint64_t)pk->shard_count;
+        const Fr *u = ctx->u.as<Fr>(), *wit_u = ctx->wit_u.as<Fr>(), *u2lo = ctx->u2.as<Fr>(), *u2hi = u2lo + m, *halo = ctx->halo.as<Fr>();
+        const Segment *d_segs = (const Segment *)pk->d_segs;
+        PM_HIP(ctx, hipMemsetAsync(out + 1, 0, 2 * SS * sizeof(Fr), st));
+        if (seg_threads_512())
+            hipLaunchKernelGGL((k_seg_base<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, u, wit_u, u2lo, u2hi, halo, x1, laneP, laneQ, out + 1,
+                               out + 1 + SS);
+        else
+            hipLaunchKernelGGL((k_seg_base<P, 1024>), dim3((unsigned)S), dim3(1024), 0, st, d_segs, sd, u, wit_u, u2lo, u2hi, halo, x1, laneP, laneQ,
+                               out + 1, out + 1 + SS);
+        PM_HIP(ctx, hipGetLastError());
+    }
+    std::vector<Fr> mine(rec);
+    ctx->seg_all.resize(rec * L.N * sizeof(Fr));
+    Fr *all = (Fr *)ctx->seg_all.data();
+    PM_HIP(ctx, hipMemcpyAsync(mine.data(), out, rec * sizeof(Fr), hipMemcpyDeviceToHost, st));
     PM_HIP(ctx, hipStreamSynchronize(st));
-    hp.mark("horner");
-    PM_TRY(comm_status(ctx, ctx->comm->all_gather(&mine, all.data(), sizeof(Fr), st), "all_gather"));
+    hp.mark("horner+seg_base");
+    PM_TRY(comm_status(ctx, ctx->comm->all_gather(mine.data(), all, rec * sizeof(Fr), st), "all_gather"));
     hp.mark("exchange");
     Fr sum = Fr::zero();
-    for (uint32_t r = 0; r < L.N; ++r) sum = add<P>(sum, all[r]);
+    for (uint32_t r = 0; r < L.N; ++r) sum = add<P>(sum, all[r * rec]);
     memcpy(u_at_x1, sum.l, sizeof(Fr));
+    memcpy(ctx->x1_host, x1_in, sizeof(Fr));                // phase 3 must be called with the same x1: its data sums are in ctx->seg_all
     PM_TRY(comm_alive(ctx));
     ctx->phase = 2;
     return phase_end.ok(PM_OK);
@@ -723,31 +814,42 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     memcpy(rah, ctx->ra_host, sizeof(rah));          // phase 1 kept the host copy of r_a: no device read-back, no synchronisation here
     const NumConsts<P> nc = make_num_consts<P>(x2, rah, a_at, c_at);
     const SegData sd{n, sigma};
-    const size_t S = pk->segs.size(), SS = pk->seg_slots;   // SS = the longest segment list of any rank (the exchanged record size)
+    const size_t S = pk->segs.size(), SS = pk->seg_slots, rec = 1 + 2 * SS;
+    if (memcmp(ctx->x1_host, x1_in, sizeof(Fr)) != 0 || ctx->seg_all.size() != rec * N * sizeof(Fr)) {
+        ctx->err = "phase 3 needs the x1 of phase 2 (its data sums of the division scan were taken at that point)";
+        return phase_end.ok(PM_ERR_STATE);      // the same call on every rank
+    }
     PM_HIP(ctx, ctx->quotient.reserve((pk->res_cnt[2] + 1) * sizeof(Fr)));
-    PM_HIP(ctx, ctx->lvl[0].reserve(S * SEG_THREADS_MAX * sizeof(Fr)));    // lane values
-    // 512 lanes per segment: with ~256-400 segments per rank every CU holds one or two workgroups at 2-4 waves per SIMD (1024 lanes
-    // and half as many segments left a third of the chip idle and four waves queueing on each busy SIMD); PM_SEG_THREADS=1024: round 2
-    const bool seg512 = [] { const char *e = getenv("PM_SEG_THREADS"); return !(e && atoi(e) == 1024); }();
-    PM_HIP(ctx, ctx->lvl[1].reserve(2 * S * sizeof(Fr)));              // V | carry
-    Fr *qv = ctx->quotient.as<Fr>(), *lane_vals = ctx->lvl[0].as<Fr>(), *V = ctx->lvl[1].as<Fr>(), *carry = V + S;
+    PM_HIP(ctx, ctx->lvl[1].reserve((S + 1) * sizeof(Fr)));            // carries
+    Fr *qv = ctx->quotient.as<Fr>(), *laneP = ctx->lvl[0].as<Fr>(), *laneQ = laneP + S * SEG_THREADS_MAX, *carry = ctx->lvl[1].as<Fr>();
     const Fr *u = ctx->u.as<Fr>(), *wit_u = ctx->wit_u.as<Fr>(), *u2lo = ctx->u2.as<Fr>(), *u2hi = u2lo + m, *halo = ctx->halo.as<Fr>();
     const Segment *d_segs = (const Segment *)pk->d_segs;
-    std::vector<Fr> hV(SS, Fr::zero()), hall(SS * N), hcarry(S);
-    {
-        StageTimer t(ctx, T_POLY);
-        if (seg512) hipLaunchKernelGGL((k_seg_reduce<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1, lane_vals, V);
-        else hipLaunchKernelGGL((k_seg_reduce<P, 1024>), dim3((unsigned)S), dim3(1024), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1, lane_vals, V);
-        PM_HIP(ctx, hipGetLastError());
-        PM_HIP(ctx, hipMemcpyAsync(hV.data(), V, S * sizeof(Fr), hipMemcpyDeviceToHost, st));
-    }
-    PM_HIP(ctx, hipStreamSynchronize(st));
-    hp.mark("seg_reduce");
-    PM_TRY(comm_status(ctx, ctx->comm->all_gather(hV.data(), hall.data(), SS * sizeof(Fr), st), "all_gather"));
-    hp.mark("exchange");
-    // the chain over ALL segments in descending index order: H_b(s) = carry into s; H_a(s) = V_s + x1^(b-a) H_b(s)
+    std::vector<Fr> hcarry(S);
+    const Fr *hall = (const Fr *)ctx->seg_all.data();
+    // The chain over ALL segments in descending index order: H_b(s) = carry into s; H_a(s) = V_s + x1^(b-a) H_b(s), with
+    //   V_s = c1 P_s + c2 Q_s + (the constants inside s) x1^(their offset)   -- P_s, Q_s from phase 2's exchange, no exchange here.
     Fr Hb = Fr::zero();
     {
+        const uint64_t s3 = 3 * sigma, s5 = 5 * sigma, s8 = 8 * sigma, s2 = 2 * sigma;
+        const Fr c1u = add<P>(Fr::one(), nc.two_x2_r0);
+        auto value_of = [&](const pm_pk::SegRef &e) -> Fr {
+            const Fr Ps = hall[(size_t)e.rank * rec + 1 + e.idx], Qs = hall[(size_t)e.rank * rec + 1 + SS + e.idx];
+            const uint64_t a = e.a, b = e.b;
+            if ((a >= s3 && a < s3 + n) || a >= s8) return mul<P>(nc.x2, Ps);                       // witness_u, (u^2)_lo, (u^2)_hi
+            if (a >= s5 && a <= s5 + n) {                                                              // the u region (n + 1 entries)
+                Fr v = add<P>(mul<P>(c1u, Ps), mul<P>(nc.two_x2_r1, Qs));
+                if (a == s5) v = add<P>(v, nc.minus_const);                                            // its first index, offset 0
+                return v;
+            }
+            Fr v = Fr::zero();                                                                          // fillers: the constants
+            if (filler_has_const(a, b, sigma)) {
+                const uint64_t pos[5] = {0, 1, s2, s2 + 1, s2 + 2};
+                const Fr val[5] = {nc.x2r0, nc.x2r1, nc.b2[0], nc.b2[1], nc.b2[2]};
+                for (int i = 0; i < 5; ++i)
+                    if (pos[i] >= a && pos[i] < b) v = add<P>(v, mul<P>(val[i], pow_u64<P>(x1, pos[i] - a)));
+            }
+            return v;
+        };
         uint64_t pow_len = 0;
         Fr pow_val = Fr::one();
         for (size_t i = pk->all_segs.size(); i-- > 0;) {
@@ -755,7 +857,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
             if (e.rank == q) hcarry[e.idx] = Hb;
             const uint64_t len = e.b - e.a;
             if (len != pow_len) { pow_len = len; pow_val = pow_u64<P>(x1, len); }
-            Hb = add<P>(hall[(size_t)e.rank * SS + e.idx], mul<P>(pow_val, Hb));
+            Hb = add<P>(value_of(e), mul<P>(pow_val, Hb));
         }
     }
     hp.mark("chain");
@@ -763,10 +865,10 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     {
         StageTimer t(ctx, T_POLY);
         PM_HIP(ctx, hipMemcpyAsync(carry, hcarry.data(), S * sizeof(Fr), hipMemcpyHostToDevice, st));
-        if (seg512) hipLaunchKernelGGL((k_seg_expand<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
-                                       (const Fr *)lane_vals, (const Fr *)carry, qv);
+        if (seg_threads_512()) hipLaunchKernelGGL((k_seg_expand<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
+                                                  (const Fr *)laneP, (const Fr *)laneQ, (const Fr *)carry, qv);
         else hipLaunchKernelGGL((k_seg_expand<P, 1024>), dim3((unsigned)S), dim3(1024), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
-                                (const Fr *)lane_vals, (const Fr *)carry, qv);
+                                (const Fr *)laneP, (const Fr *)laneQ, (const Fr *)carry, qv);
         PM_HIP(ctx, hipGetLastError());
     }
     // [d]_1 = M8, prover.rs:229: this rank's partial sum, then the sum over the ranks (all-gather + local adds, like phase 1)
