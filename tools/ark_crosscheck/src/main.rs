@@ -13,7 +13,7 @@
 //!   bench <out.json>      ark-ec msm_unchecked and ark-poly fft at 2^20 .. 2^24 (benches/bench.rs:2 thread convention).
 use std::{fmt::Write as _, fs, time::Instant};
 
-use ark_bls12_381::{Bls12_381, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
+use ark_bls12_381::{Bls12_381, Fr, G1Affine, G1Projective, G2Projective};
 use ark_crypto_primitives::snark::{CircuitSpecificSetupSNARK, SNARK};
 use ark_ec::{AffineRepr, CurveGroup, PrimeGroup, VariableBaseMSM};
 use ark_ff::{BigInteger, Field, PrimeField, UniformRand};   // Field: square()
@@ -105,8 +105,12 @@ fn fq_hex<F: PrimeField>(v: &F) -> String {
     format!("\"0x{}\"", if t.is_empty() { "0" } else { t })
 }
 fn g1_json(p: &G1Affine) -> String {
+    // `xy()` hands out references in ark-ec 0.4 and values on algebra HEAD: `to_owned()` gives a plain Fq either way
     match p.xy() {
-        Some((x, y)) => format!("[{}, {}]", fq_hex(&x), fq_hex(&y)),
+        Some((x, y)) => {
+            let (x, y): (ark_bls12_381::Fq, ark_bls12_381::Fq) = (x.to_owned(), y.to_owned());
+            format!("[{}, {}]", fq_hex(&x), fq_hex(&y))
+        }
         None => "null".to_string(),
     }
 }
