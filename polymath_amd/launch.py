@@ -28,8 +28,8 @@ import time
 ATTEMPTS = [
     ("nccl", "rccl"),        # everything over RCCL/xGMI: the production form
     ("gloo", "rccl"),        # barrier/rendezvous over gloo, the data path still RCCL inside the library
-    ("nccl", "callbacks"),   # all-to-all staged through the host over torch.distributed
-    ("gloo", "callbacks"),
+    ("gloo", "callbacks"),   # nothing depends on RCCL any more: exchanges staged through the host over gloo
+    ("nccl", "callbacks"),   # (RCCL for torch only; tried last: two RCCL-dependent attempts have failed by now)
 ]
 
 
