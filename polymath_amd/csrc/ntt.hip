@@ -268,9 +268,61 @@ __device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d
 // 2.5 * 2^30: < 2^63.8).  The stage that ends the pass leaves its carries to l28_emit.
 template <class P, class RR, bool FIRST>
 __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols,
-                                           size_t lo0) {
+                                           size_t lo0, bool pair_stages) {
     const unsigned cols = 1u << log_cols, cm = cols - 1, rows = 1u << ns, nbf = (rows >> 1) * cols, tid = threadIdx.x;
+    // Two stages per LDS round trip (round 3): a lane takes the four rows r0 + {0, h, 2h, 3h} of one column, runs stage st on
+    // (r0, r0 + h), (r0 + 2h, r0 + 3h) and stage st + 1 on (r0, r0 + 2h), (r0 + h, r0 + 3h) in registers -- the same four products,
+    // additions and (after the odd stage) weak normalisations in the same order, so the values are bit-identical to the
+    // stage-at-a-time loop below; three twiddle records instead of four (stage st's is shared), half the barriers and half the
+    // LDS traffic.  An odd stage count ends with one ordinary stage.  PM_NTT_RADIX4=0: one stage at a time (round 2).
+    auto two_stages = [&](unsigned st, auto norm_tag) {
+        constexpr bool NORM = decltype(norm_tag)::value;
+        const unsigned half = 1u << st, sA = s0 + st + 1, sB = sA + 1, ngroups = (rows >> 2) * cols;
+        for (unsigned e = tid; e < ngroups; e += L28_THREADS) {
+            const unsigned c = e & cm, k = e >> log_cols;
+            const unsigned r0 = ((k >> st) << (st + 2)) | (k & (half - 1)), r1 = r0 + half, r2 = r1 + half, r3 = r2 + half;
+            const unsigned low = r0 & (half - 1);
+            const size_t jA = FIRST ? (size_t)low : ((size_t)low << s0) + lo0 + c;
+            const size_t jB0 = jA, jB1 = FIRST ? (size_t)(low + half) : ((size_t)(low + half) << s0) + lo0 + c;
+            const Tw28<RR> wA = tw[jA << (log_n - sA)], wB0 = tw[jB0 << (log_n - sB)], wB1 = tw[jB1 << (log_n - sB)];
+            const unsigned e0 = r0 * cols + (FIRST ? ((c + r0) & cm) : c), e1 = r1 * cols + (FIRST ? ((c + r1) & cm) : c);
+            const unsigned e2 = r2 * cols + (FIRST ? ((c + r2) & cm) : c), e3 = r3 * cols + (FIRST ? ((c + r3) & cm) : c);
+            const F28<RR> x0 = l28_load<RR>(t, tile, e0), x1 = l28_load<RR>(t, tile, e1), x2 = l28_load<RR>(t, tile, e2), x3 = l28_load<RR>(t, tile, e3);
+            F28<RR> w;
+#pragma unroll
+            for (int i = 0; i < RR::N; ++i) w.l[i] = wA.l[i];
+            const F28<RR> p1 = f28_mul<RR>(x1, w), p3 = f28_mul<RR>(x3, w);
+            const F28<RR> a0 = f28_add<RR>(x0, p1), a1 = f28_sub_k4<RR>(x0, p1), a2 = f28_add<RR>(x2, p3), a3 = f28_sub_k4<RR>(x2, p3);
+#pragma unroll
+            for (int i = 0; i < RR::N; ++i) w.l[i] = wB0.l[i];
+            const F28<RR> q2 = f28_mul<RR>(a2, w);
+#pragma unroll
+            for (int i = 0; i < RR::N; ++i) w.l[i] = wB1.l[i];
+            const F28<RR> q3 = f28_mul<RR>(a3, w);
+            const F28<RR> b0 = f28_add<RR>(a0, q2), b2 = f28_sub_k4<RR>(a0, q2), b1 = f28_add<RR>(a1, q3), b3 = f28_sub_k4<RR>(a1, q3);
+            if (NORM) {
+                l28_store<RR>(t, tile, e0, f28_weak_norm<RR>(b0));
+                l28_store<RR>(t, tile, e1, f28_weak_norm<RR>(b1));
+                l28_store<RR>(t, tile, e2, f28_weak_norm<RR>(b2));
+                l28_store<RR>(t, tile, e3, f28_weak_norm<RR>(b3));
+            } else {
+                l28_store<RR>(t, tile, e0, b0);
+                l28_store<RR>(t, tile, e1, b1);
+                l28_store<RR>(t, tile, e2, b2);
+                l28_store<RR>(t, tile, e3, b3);
+            }
+        }
+    };
     for (unsigned st = 0; st < ns; ++st) {
+        if (pair_stages && (st & 1) == 0 && st + 1 < ns) {          // stages st (even: no normalisation) and st + 1 (odd) together
+            if (st + 2 != ns)
+                two_stages(st, std::true_type{});
+            else
+                two_stages(st, std::false_type{});                    // the stage that ends the pass leaves its carries to l28_emit
+            __syncthreads();
+            ++st;
+            continue;
+        }
         const unsigned s = s0 + st + 1, half = 1u << st;
         const bool norm = (st & 1) == 1 && st + 1 != ns;
         auto slots = [&](unsigned e, unsigned &e0, unsigned &e1, size_t &j) {
@@ -340,7 +392,7 @@ __device__ __forceinline__ void l28_emit(const F28<RR> &v, Fp<P> *dst, const F28
 // general pass: stages [s0, s0 + ns), tile of 2^ns rows x 2^log_cols contiguous columns, src -> dst at the same positions
 template <class P, class RR>
 __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_pass28(const Fp<P> *a, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns,
-                                                             unsigned log_cols, Fp<P> scale_int, int do_scale) {
+                                                             unsigned log_cols, Fp<P> scale_int, int do_scale, int pair_stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
     const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols;
@@ -362,7 +414,7 @@ __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         }
     }
     __syncthreads();
-    l28_stages<P, RR, false>(t, tile, tw, log_n, s0, ns, log_cols, lo0);
+    l28_stages<P, RR, false>(t, tile, tw, log_n, s0, ns, log_cols, lo0, pair_stages != 0);
     const F28<RR> sc = f28_unpack<RR>(scale_int.l);
     for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
         const unsigned r = e >> log_cols, c = e & (cols - 1);
@@ -373,7 +425,7 @@ __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // first pass with the bit reversal folded into its loads (see k_ntt_first_pass), src -> dst
 template <class P, class RR>
 __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned ns,
-                                                                   unsigned log_cols) {
+                                                                   unsigned log_cols, int pair_stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
     const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols, H = log_n - ns, cm = cols - 1;
@@ -392,7 +444,7 @@ __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         }
     }
     __syncthreads();
-    l28_stages<P, RR, true>(t, tile, tw, log_n, 0, ns, log_cols, 0);
+    l28_stages<P, RR, true>(t, tile, tw, log_n, 0, ns, log_cols, 0, pair_stages != 0);
     const F28<RR> none = f28_zero<RR>();
     for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
         const unsigned c = e >> ns, r = e & (rows - 1);
@@ -517,6 +569,7 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         // passes balanced over the stages, every tile 2^11 elements (21 = 7 + 7 + 7 with 16-column tiles, not 8 + 8 + 5 with a
         // last pass whose workgroups hold 2^8 elements; 17 and 18 take two 9-stage passes instead of three)
         const unsigned p8 = (log_n + 7) / 8, p9 = (log_n + 8) / 9, npass = p9 < p8 ? p9 : p8;
+        static const int pair_stages = [] { const char *e = getenv("PM_NTT_RADIX4"); return e && e[0] == '0' ? 0 : 1; }();
         unsigned s0 = 0;
         for (unsigned k = 0; k < npass; ++k) {
             const unsigned ns = log_n / npass + (k < log_n % npass ? 1 : 0);
@@ -524,12 +577,12 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
             const bool last = s0 + ns == log_n;
             if (k == 0) {
                 hipLaunchKernelGGL((k_ntt_first_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
-                                   ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)d, tmp, tw28, log_n, ns, log_cols);
+                                   ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)d, tmp, tw28, log_n, ns, log_cols, pair_stages);
             } else {
                 if (s0 < log_cols) log_cols = s0;
                 hipLaunchKernelGGL((k_ntt_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
                                    ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)tmp, last ? d : tmp, tw28, log_n, s0, ns,
-                                   log_cols, scale_int, last && inv_dir ? 1 : 0);
+                                   log_cols, scale_int, last && inv_dir ? 1 : 0, pair_stages);
             }
             PM_HIP(ctx, hipGetLastError());
             s0 += ns;
