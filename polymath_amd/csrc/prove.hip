@@ -260,6 +260,13 @@ __global__ void k_div_level0(NumParams np, NumConsts<P> nc, const Fp<P> *u, cons
     if (t >= nchunks) return;
     uint64_t lo = t * L, hi = lo + L;
     if (hi > np.len) hi = np.len;
+    // 6n of the 10n indices lie in the zero stretches between the blocks (numerator_at's table): a chunk inside one has V = 0
+    {
+        const uint64_t s = np.sigma, n = np.n;
+        const bool zeros = (lo >= 2 && hi <= 2 * s) || (lo >= 2 * s + 3 && hi <= 3 * s) || (lo >= 3 * s + n && hi <= 5 * s) ||
+                           (lo >= 5 * s + n + 1 && hi <= 8 * s);
+        if (zeros) { V[t] = Fp<P>::zero(); return; }
+    }
     Fp<P> acc = Fp<P>::zero();
     for (uint64_t k = hi; k-- > lo;) acc = add<P>(mul<P>(acc, x1), numerator_at<P>(k, np, nc, u, wit_u, u2));
     V[t] = acc;
