@@ -321,6 +321,18 @@ __global__ void k_div_expand0(NumParams np, NumConsts<P> nc, const Fp<P> *u, con
     uint64_t lo = t * L, hi = lo + L;
     if (hi > np.len) hi = np.len;
     Fp<P> acc = Hup[t + 1];
+    {   // inside a zero stretch (k_div_level0) the quotient is a geometric tail: one product per coefficient, no table walk
+        const uint64_t s = np.sigma, n = np.n;
+        const bool zeros = (lo >= 2 && hi <= 2 * s) || (lo >= 2 * s + 3 && hi <= 3 * s) || (lo >= 3 * s + n && hi <= 5 * s) ||
+                           (lo >= 5 * s + n + 1 && hi <= 8 * s);
+        if (zeros) {
+            for (uint64_t k = hi; k-- > lo;) {
+                acc = mul<P>(acc, x1);
+                q[k - 1] = acc;        // lo >= 2 here
+            }
+            return;
+        }
+    }
     for (uint64_t k = hi; k-- > lo;) {
         acc = add<P>(mul<P>(acc, x1), numerator_at<P>(k, np, nc, u, wit_u, u2));
         if (k > 0) q[k - 1] = acc;
