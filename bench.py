@@ -427,7 +427,7 @@ def worker(args):
                        (args.log_constraints, curve, n.bit_length() - 1, args.transcript),
                        "msm_pairs_per_proof": pairs_per_proof,
                        "parallelism": ("one proof over %d GPUs: witness map, four-step NTT (one all-to-all per transform), scans and MSM pairs sharded; %s"
-                                       % (world, comm_desc)) if layout == "vector" and multi else "msm-pairs-sharded x%d" % world},
+                                       % (world, comm_desc)) if layout == "vector" and multi else ("msm-pairs-sharded x%d" % world if world > 1 else "one GPU")},
             "msm_pairs_per_sec": pairs_per_proof / (dt / args.steps),
             "timed_entry_point": "pm_host_prove%s from pinned HOST buffers (x, w: %.1f MB H2D inside every step; SURVEY.md §8d, benches/bench.rs:79)"
                                  % ("_sharded" if world > 1 else "", (x_l.nbytes + w_l.nbytes) / 1e6),
