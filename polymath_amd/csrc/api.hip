@@ -388,6 +388,7 @@ static void pk_release(pm_pk *pk) {
     }
     if (pk->d_bases) (void)hipFree(pk->d_bases);
     if (pk->d_segs) (void)hipFree(pk->d_segs);
+    if (pk->d_all_segs) (void)hipFree(pk->d_all_segs);
     for (int k = 0; k < 3; ++k) {
         if (pk->d_tab[k]) (void)hipFree(pk->d_tab[k]);
         if (pk->d_tab_inf[k]) (void)hipFree(pk->d_tab_inf[k]);
@@ -459,6 +460,9 @@ static int pk_init_layout(pm_ctx *ctx, pm_pk *pk, uint64_t m0, uint64_t mw, uint
         if (at != pmlayout::numerator_len(n)) return PM_ERR_STATE;
         PM_HIP(ctx, hipMalloc(&pk->d_segs, pk->segs.size() * sizeof(pmlayout::Segment)));
         PM_HIP(ctx, hipMemcpy(pk->d_segs, pk->segs.data(), pk->segs.size() * sizeof(pmlayout::Segment), hipMemcpyHostToDevice));
+        // the carry chain of the division scan runs on the device too (prove_sharded.hip: k_seg_chain): all ranks' segments, in index order
+        PM_HIP(ctx, hipMalloc(&pk->d_all_segs, pk->all_segs.size() * sizeof(pm_pk::SegRef)));
+        PM_HIP(ctx, hipMemcpy(pk->d_all_segs, pk->all_segs.data(), pk->all_segs.size() * sizeof(pm_pk::SegRef), hipMemcpyHostToDevice));
         pk->pieces[0] = pmlayout::pieces_a(ks, L);
         pk->pieces[1] = pmlayout::pieces_c(ks, L);
         pk->pieces[2] = pmlayout::pieces_d(ks, pk->segs);

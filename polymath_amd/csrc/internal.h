@@ -163,6 +163,7 @@ struct pm_pk {
     std::vector<SegRef> all_segs;    // the segments of ALL ranks in increasing index order (the carry chain of the division scan)
     size_t seg_slots;                // max over ranks of the segment count
     void *d_segs;                    // device copy of `segs`
+    void *d_all_segs = nullptr;      // device copy of `all_segs`
     // Window tables, ONE SET PER MERGED MSM (its own window width: the optimum depends on the pair count):
     // d_tab[k] holds [nwin_k][res_hi[k] - res_lo[k]] points, window 0 being a copy of the MSM's resident slice.
     pm::MsmTables tables[3];

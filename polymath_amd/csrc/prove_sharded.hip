@@ -506,6 +506,77 @@ __host__ __device__ inline bool filler_has_const(uint64_t a, uint64_t b, uint64_
     return a < 2 || (a < s2 + 3 && b > s2);
 }
 
+// k_seg_chain (phase 3): the carry chain over ALL ranks' segments, on the device (round 2 and the first half of round 3 folded it on
+// the host: ~2 600 segments x a few Fr products = 0.16 ms of host time per proof at N = 8).  One workgroup.  In increasing index
+// order the segments satisfy  H_a(i) = V_i + M_i H_a(i + 1),  M_i = x1^(b_i - a_i),  V_i = c1 P_i + c2 Q_i + constants (from phase
+// 2's exchanged data sums).  Lane t composes the affine maps of its run of segments, a suffix scan over the lanes gives every
+// lane its carry-in, and a second walk writes, for THIS rank's segments, carry[idx] = H at the segment's upper end.  rem[0] = H_0.
+struct SegRefDev { uint64_t a, b; uint32_t rank, idx; };   // == pm_pk::SegRef
+constexpr unsigned CHAIN_THREADS = 512;
+
+template <class P>
+__device__ __forceinline__ Fp<P> seg_value(const SegRefDev &e, const Fp<P> *hall, size_t rec, size_t SS, const NumConsts<P> &nc, const Fp<P> &c1u,
+                                           const Fp<P> &x1, uint64_t n, uint64_t sigma) {
+    const uint64_t s2 = 2 * sigma, s3 = 3 * sigma, s5 = 5 * sigma, s8 = 8 * sigma, a = e.a, b = e.b;
+    const Fp<P> Ps = hall[(size_t)e.rank * rec + 1 + e.idx];
+    if ((a >= s3 && a < s3 + n) || a >= s8) return mul<P>(nc.x2, Ps);                           // witness_u, (u^2)_lo, (u^2)_hi
+    if (a >= s5 && a <= s5 + n) {                                                                  // the u region (n + 1 entries)
+        Fp<P> v = add<P>(mul<P>(c1u, Ps), mul<P>(nc.two_x2_r1, hall[(size_t)e.rank * rec + 1 + SS + e.idx]));
+        if (a == s5) v = add<P>(v, nc.minus_const);                                                // its first index, offset 0
+        return v;
+    }
+    Fp<P> v = Fp<P>::zero();                                                                       // fillers: the constants
+    if (filler_has_const(a, b, sigma)) {
+        const uint64_t pos[5] = {0, 1, s2, s2 + 1, s2 + 2};
+        const Fp<P> val[5] = {nc.x2r0, nc.x2r1, nc.b2[0], nc.b2[1], nc.b2[2]};
+        for (int i = 0; i < 5; ++i)
+            if (pos[i] >= a && pos[i] < b) v = add<P>(v, mul<P>(val[i], pow_u64<P>(x1, pos[i] - a)));
+    }
+    return v;
+}
+
+template <class P>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_seg_chain(const SegRefDev *segs, unsigned T, const Fp<P> *hall, size_t rec, size_t SS, NumConsts<P> nc,
+                                                             Fp<P> x1, Fp<P> x1_pow_common, uint64_t common_len, uint64_t n, uint64_t sigma, uint32_t my_rank,
+                                                             Fp<P> *carry, Fp<P> *rem) {
+    __shared__ Fp<P> shA[CHAIN_THREADS], shB[CHAIN_THREADS];
+    const unsigned t = threadIdx.x, per = (T + CHAIN_THREADS - 1) / CHAIN_THREADS;
+    const unsigned lo = t * per < T ? t * per : T, hi = lo + per < T ? lo + per : T;
+    const Fp<P> c1u = add<P>(Fp<P>::one(), nc.two_x2_r0);
+    auto mult = [&](const SegRefDev &e) { const uint64_t len = e.b - e.a; return len == common_len ? x1_pow_common : pow_u64<P>(x1, len); };
+    // this lane's run as ONE affine map h -> A + B h (h = H at the run's upper end)
+    Fp<P> A = Fp<P>::zero(), B = Fp<P>::one();
+    for (unsigned i = hi; i-- > lo;) {
+        const SegRefDev e = segs[i];
+        const Fp<P> M = mult(e);
+        A = add<P>(seg_value<P>(e, hall, rec, SS, nc, c1u, x1, n, sigma), mul<P>(M, A));
+        B = mul<P>(M, B);
+    }
+    shA[t] = A;
+    shB[t] = B;
+    __syncthreads();
+    // suffix scan of the maps: after it (shA[t], shB[t]) maps the carry-in of the LAST lane (0) to H at the start of lane t's run
+    for (unsigned d = 1; d < CHAIN_THREADS; d <<= 1) {
+        Fp<P> a2 = Fp<P>::zero(), b2 = Fp<P>::one();
+        const bool take = t + d < CHAIN_THREADS;
+        if (take) { a2 = shA[t + d]; b2 = shB[t + d]; }
+        __syncthreads();
+        if (take) {                                    // f_t o f_(t+d):  A_t + B_t (a2 + b2 h)
+            shA[t] = add<P>(shA[t], mul<P>(shB[t], a2));
+            shB[t] = mul<P>(shB[t], b2);
+        }
+        __syncthreads();
+    }
+    // carry-in of lane t = H at the start of lane t + 1's run (0 beyond the last lane: nothing lies above the top index)
+    Fp<P> h = t + 1 < CHAIN_THREADS ? shA[t + 1] : Fp<P>::zero();
+    for (unsigned i = hi; i-- > lo;) {
+        const SegRefDev e = segs[i];
+        if (e.rank == my_rank) carry[e.idx] = h;
+        h = add<P>(seg_value<P>(e, hall, rec, SS, nc, c1u, x1, n, sigma), mul<P>(mult(e), h));
+    }
+    if (t == 0) rem[0] = h;                            // H_0: the remainder of the division (prover.rs:221)
+}
+
 // k_seg_expand (phase 3).  carry[s] = H_b of segment s (from the chain over ALL ranks' segment values).  Suffix scan of the lane values with the
 // constant multiplier X = x1^span (every lane but the last active one owns a full span; the carry-in is folded into the
 // last lane's value), then every lane re-walks its span and writes q_{k-1} = H_k.
@@ -884,53 +955,32 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     Fr *qv = ctx->quotient.as<Fr>(), *laneP = ctx->lvl[0].as<Fr>(), *laneQ = laneP + S * SEG_THREADS_MAX, *carry = ctx->lvl[1].as<Fr>();
     const Fr *u = ctx->u.as<Fr>(), *wit_u = ctx->wit_u.as<Fr>(), *u2lo = ctx->u2.as<Fr>(), *u2hi = u2lo + m, *halo = ctx->halo.as<Fr>();
     const Segment *d_segs = (const Segment *)pk->d_segs;
-    std::vector<Fr> hcarry(S);
-    const Fr *hall = (const Fr *)ctx->seg_all.data();
-    // The chain over ALL segments in descending index order: H_b(s) = carry into s; H_a(s) = V_s + x1^(b-a) H_b(s), with
-    //   V_s = c1 P_s + c2 Q_s + (the constants inside s) x1^(their offset)   -- P_s, Q_s from phase 2's exchange, no exchange here.
-    Fr Hb = Fr::zero();
-    {
-        const uint64_t s3 = 3 * sigma, s5 = 5 * sigma, s8 = 8 * sigma, s2 = 2 * sigma;
-        const Fr c1u = add<P>(Fr::one(), nc.two_x2_r0);
-        auto value_of = [&](const pm_pk::SegRef &e) -> Fr {
-            const Fr Ps = hall[(size_t)e.rank * rec + 1 + e.idx], Qs = hall[(size_t)e.rank * rec + 1 + SS + e.idx];
-            const uint64_t a = e.a, b = e.b;
-            if ((a >= s3 && a < s3 + n) || a >= s8) return mul<P>(nc.x2, Ps);                       // witness_u, (u^2)_lo, (u^2)_hi
-            if (a >= s5 && a <= s5 + n) {                                                              // the u region (n + 1 entries)
-                Fr v = add<P>(mul<P>(c1u, Ps), mul<P>(nc.two_x2_r1, Qs));
-                if (a == s5) v = add<P>(v, nc.minus_const);                                            // its first index, offset 0
-                return v;
-            }
-            Fr v = Fr::zero();                                                                          // fillers: the constants
-            if (filler_has_const(a, b, sigma)) {
-                const uint64_t pos[5] = {0, 1, s2, s2 + 1, s2 + 2};
-                const Fr val[5] = {nc.x2r0, nc.x2r1, nc.b2[0], nc.b2[1], nc.b2[2]};
-                for (int i = 0; i < 5; ++i)
-                    if (pos[i] >= a && pos[i] < b) v = add<P>(v, mul<P>(val[i], pow_u64<P>(x1, pos[i] - a)));
-            }
-            return v;
-        };
-        uint64_t pow_len = 0;
-        Fr pow_val = Fr::one();
-        for (size_t i = pk->all_segs.size(); i-- > 0;) {
-            const auto &e = pk->all_segs[i];
-            if (e.rank == q) hcarry[e.idx] = Hb;
-            const uint64_t len = e.b - e.a;
-            if (len != pow_len) { pow_len = len; pow_val = pow_u64<P>(x1, len); }
-            Hb = add<P>(value_of(e), mul<P>(pow_val, Hb));
-        }
+    // The carry chain over ALL segments (k_seg_chain, one workgroup), then the expansion of this rank's segments; phase 2's
+    // exchanged data sums go up once (N x (1 + 2 SS) Fr, ~80 KB at N = 8), the remainder H_0 comes back with the MSM's result.
+    const size_t T = pk->all_segs.size();
+    PM_HIP(ctx, ctx->lvl[2].reserve(rec * N * sizeof(Fr)));
+    Fr *d_hall = ctx->lvl[2].as<Fr>(), *d_rem = carry + S;
+    if (!ctx->h_pinned && hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+        ctx->h_pinned = nullptr;
+        ctx->err = "pinned result slot allocation failed";
+        return PM_ERR_HIP;
     }
-    hp.mark("chain");
-    if (!Hb.is_zero()) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);   // prover.rs:221 -- the same value on every rank
+    Fr *h_rem = (Fr *)((uint8_t *)ctx->h_pinned + 3072);     // pinned: the copy below must not block the host (msm.hip uses [0, 2052))
+    *h_rem = Fr::one();
     {
         StageTimer t(ctx, T_POLY);
-        PM_HIP(ctx, hipMemcpyAsync(carry, hcarry.data(), S * sizeof(Fr), hipMemcpyHostToDevice, st));
+        PM_HIP(ctx, hipMemcpyAsync(d_hall, ctx->seg_all.data(), rec * N * sizeof(Fr), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_seg_chain<P>, dim3(1), dim3(CHAIN_THREADS), 0, st, (const SegRefDev *)pk->d_all_segs, (unsigned)T, (const Fr *)d_hall, rec, SS,
+                           nc, x1, pow_u64<P>(x1, pk->max_seg), pk->max_seg, n, sigma, q, carry, d_rem);
+        PM_HIP(ctx, hipGetLastError());
         if (seg_threads_512()) hipLaunchKernelGGL((k_seg_expand<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
                                                   (const Fr *)laneP, (const Fr *)laneQ, (const Fr *)carry, qv);
         else hipLaunchKernelGGL((k_seg_expand<P, 1024>), dim3((unsigned)S), dim3(1024), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
                                 (const Fr *)laneP, (const Fr *)laneQ, (const Fr *)carry, qv);
         PM_HIP(ctx, hipGetLastError());
+        PM_HIP(ctx, hipMemcpyAsync(h_rem, d_rem, sizeof(Fr), hipMemcpyDeviceToHost, st));      // lands before the MSM's final synchronisation
     }
+    hp.mark("chain+expand enqueue");
     // [d]_1 = M8, prover.rs:229: this rank's partial sum, then the sum over the ranks (all-gather + local adds, like phase 1)
     {
         struct Rec3 {
@@ -968,6 +1018,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
             PM_TRY(msm_resident<C>(ctx, pk, 2, qv, mine3.xy, &inf_l));
         }
         hp.mark("expand+msm_d");
+        if (!h_rem->is_zero()) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);   // prover.rs:221 -- H_0 is the same value on every rank
         mine3.inf = (uint64_t)inf_l;
         std::vector<Rec3> all3(N);
         PM_TRY(comm_status(ctx, ctx->comm->all_gather(&mine3, all3.data(), sizeof(Rec3), st), "all_gather"));
