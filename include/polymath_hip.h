@@ -188,7 +188,9 @@ int pm_prove_phase1_device(pm_ctx *ctx, const pm_pk *pk, const uint64_t *d_x, co
 /* Phase 2 (prover.rs:132): u(x1), the only O(n) part of a_at_x1; the caller adds r_a(x1)*y1^alpha. */
 int pm_prove_phase2(pm_ctx *ctx, const uint64_t *x1, uint64_t *u_at_x1);
 /* Phase 3 (prover.rs:142-229): assemble the Y^-gamma-scaled numerator, divide by (X - x1),
- * commit the dense quotient: [d]_1.  Returns PM_ERR_REMAINDER_NONZERO like prover.rs:221. */
+ * commit the dense quotient: [d]_1.  Returns PM_ERR_REMAINDER_NONZERO like prover.rs:221.
+ * On a PM_SHARD_VECTOR key x1 must be the x1 of phase 2 (the x1-dependent sums of the division scan were exchanged there);
+ * another value returns PM_ERR_INVALID_ARG. */
 int pm_prove_phase3(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1,
                     const uint64_t *c_at_x1, uint64_t *d_g1_xy, int *d_inf);
 

@@ -948,7 +948,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     const size_t S = pk->segs.size(), SS = pk->seg_slots, rec = 1 + 2 * SS;
     if (memcmp(ctx->x1_host, x1_in, sizeof(Fr)) != 0 || ctx->seg_all.size() != rec * N * sizeof(Fr)) {
         ctx->err = "phase 3 needs the x1 of phase 2 (its data sums of the division scan were taken at that point)";
-        return phase_end.ok(PM_ERR_STATE);      // the same call on every rank
+        return phase_end.ok(PM_ERR_INVALID_ARG);   // the same call on every rank: a verdict they share, the communicator stays usable
     }
     PM_HIP(ctx, ctx->quotient.reserve((pk->res_cnt[2] + 1) * sizeof(Fr)));
     PM_HIP(ctx, ctx->lvl[1].reserve((S + 1) * sizeof(Fr)));            // carries
