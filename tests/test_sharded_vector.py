@@ -248,6 +248,37 @@ def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_vector_sharded_phase3_needs_the_x1_of_phase2():
+    """The division scan's x1-dependent sums are exchanged in phase 2; phase 3 with another x1 is refused on every rank with the
+    same status (PM_ERR_INVALID_ARG: a verdict they share), the communicators stay usable and the proof still goes through."""
+    from polymath_amd import circuits as PC
+    curve, N = "bls12_381", 2
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, 3000)
+    g = PC.SplitMix64(0x3A1)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    f = pms[0].field
+
+    def body(r):
+        pk = pks[r]
+        rc, *_ = pk.phase1(lc.inst_limbs, lc.wit_limbs, f.fr_limbs(r_a))
+        assert rc == 0
+        x1 = f.fr_limbs([12345])[0]
+        rc, _u = pk.phase2(x1)
+        assert rc == 0
+        other = f.fr_limbs([12346])[0]
+        rc, _d, _i = pk.phase3(other, other, other, other)
+        return rc
+    assert _run_ranks(N, body, comms) == [1] * N                       # PM_ERR_INVALID_ARG on both ranks
+    assert not any(cm.failed for cm in comms)
+    again = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms)
+    assert all(p == proofs[0] for p in again)
+    for pk in pks:
+        pk.free()
+
+
+@pytest.mark.gpu
 def test_vector_sharded_mid_size_and_pairs_layout_agree(oracle):
     """2^16-100 gates on 8 ranks (B = 2048 coefficients per block, several sub-segments per stretch): the vector-sharded
     proof, the pairs-sharded proof (vector phases replicated, pm_comm combine) and the single-GPU proof are identical -- and
