@@ -284,31 +284,52 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
             const unsigned low = r0 & (half - 1);
             const size_t jA = FIRST ? (size_t)low : ((size_t)low << s0) + lo0 + c;
             const size_t jB0 = jA, jB1 = FIRST ? (size_t)(low + half) : ((size_t)(low + half) << s0) + lo0 + c;
-            const Tw28<RR> wA = tw[jA << (log_n - sA)], wB0 = tw[jB0 << (log_n - sB)], wB1 = tw[jB1 << (log_n - sB)];
             const unsigned e0 = r0 * cols + (FIRST ? ((c + r0) & cm) : c), e1 = r1 * cols + (FIRST ? ((c + r1) & cm) : c);
             const unsigned e2 = r2 * cols + (FIRST ? ((c + r2) & cm) : c), e3 = r3 * cols + (FIRST ? ((c + r3) & cm) : c);
-            const F28<RR> x0 = l28_load<RR>(t, tile, e0), x1 = l28_load<RR>(t, tile, e1), x2 = l28_load<RR>(t, tile, e2), x3 = l28_load<RR>(t, tile, e3);
-            F28<RR> w;
+            // register budget (4 waves per SIMD = 128 VGPRs, a 64-bit column accumulator of 18 inside every product): one
+            // butterfly's operands at a time -- an element is loaded right before its product, a twiddle right before its stage
+            F28<RR> w, a0, a1, a2, a3;
+            {
+                const Tw28<RR> wA = tw[jA << (log_n - sA)];
 #pragma unroll
-            for (int i = 0; i < RR::N; ++i) w.l[i] = wA.l[i];
-            const F28<RR> p1 = f28_mul<RR>(x1, w), p3 = f28_mul<RR>(x3, w);
-            const F28<RR> a0 = f28_add<RR>(x0, p1), a1 = f28_sub_k4<RR>(x0, p1), a2 = f28_add<RR>(x2, p3), a3 = f28_sub_k4<RR>(x2, p3);
+                for (int i = 0; i < RR::N; ++i) w.l[i] = wA.l[i];
+            }
+            {
+                const F28<RR> p1 = f28_mul<RR>(l28_load<RR>(t, tile, e1), w), x0 = l28_load<RR>(t, tile, e0);
+                a0 = f28_add<RR>(x0, p1);
+                a1 = f28_sub_k4<RR>(x0, p1);
+            }
+            {
+                const F28<RR> p3 = f28_mul<RR>(l28_load<RR>(t, tile, e3), w), x2 = l28_load<RR>(t, tile, e2);
+                a2 = f28_add<RR>(x2, p3);
+                a3 = f28_sub_k4<RR>(x2, p3);
+            }
+            {
+                const Tw28<RR> wB0 = tw[jB0 << (log_n - sB)];
 #pragma unroll
-            for (int i = 0; i < RR::N; ++i) w.l[i] = wB0.l[i];
+                for (int i = 0; i < RR::N; ++i) w.l[i] = wB0.l[i];
+            }
             const F28<RR> q2 = f28_mul<RR>(a2, w);
-#pragma unroll
-            for (int i = 0; i < RR::N; ++i) w.l[i] = wB1.l[i];
-            const F28<RR> q3 = f28_mul<RR>(a3, w);
-            const F28<RR> b0 = f28_add<RR>(a0, q2), b2 = f28_sub_k4<RR>(a0, q2), b1 = f28_add<RR>(a1, q3), b3 = f28_sub_k4<RR>(a1, q3);
+            const F28<RR> b0 = f28_add<RR>(a0, q2), b2 = f28_sub_k4<RR>(a0, q2);
             if (NORM) {
                 l28_store<RR>(t, tile, e0, f28_weak_norm<RR>(b0));
-                l28_store<RR>(t, tile, e1, f28_weak_norm<RR>(b1));
                 l28_store<RR>(t, tile, e2, f28_weak_norm<RR>(b2));
-                l28_store<RR>(t, tile, e3, f28_weak_norm<RR>(b3));
             } else {
                 l28_store<RR>(t, tile, e0, b0);
-                l28_store<RR>(t, tile, e1, b1);
                 l28_store<RR>(t, tile, e2, b2);
+            }
+            {
+                const Tw28<RR> wB1 = tw[jB1 << (log_n - sB)];
+#pragma unroll
+                for (int i = 0; i < RR::N; ++i) w.l[i] = wB1.l[i];
+            }
+            const F28<RR> q3 = f28_mul<RR>(a3, w);
+            const F28<RR> b1 = f28_add<RR>(a1, q3), b3 = f28_sub_k4<RR>(a1, q3);
+            if (NORM) {
+                l28_store<RR>(t, tile, e1, f28_weak_norm<RR>(b1));
+                l28_store<RR>(t, tile, e3, f28_weak_norm<RR>(b3));
+            } else {
+                l28_store<RR>(t, tile, e1, b1);
                 l28_store<RR>(t, tile, e3, b3);
             }
         }
