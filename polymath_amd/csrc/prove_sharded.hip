@@ -154,38 +154,61 @@ __global__ void k_cross_dft(const Fp<P> *in, Fp<P> *out, const Fp<P> *roots, uin
 // (k_cross_dft redoes that for every output: N (N - 1) twiddle products per column), then a radix-2 decimation-in-frequency network
 // in registers -- N/2 log2 N root products instead of N (N - 1) -- whose bit-reversed positions are undone when storing.
 // N = 8: 7 + 12 products per column against 112.
-template <class P, unsigned N>
-__global__ void k_cross_dft_col(const Fp<P> *in, Fp<P> *out, const Fp<P> *roots, uint64_t B, const Fp<P> *tw, uint64_t n, uint64_t k2_base,
-                                int in_twiddle, int out_twiddle, Fp<P> scale, int use_scale) {
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const uint64_t k2 = k2_base + b;
-    Fp<P> x[N];
-#pragma unroll
-    for (unsigned i = 0; i < N; ++i) {
-        x[i] = in[(uint64_t)i * B + b];
-        if (in_twiddle && i) x[i] = mul<P>(x[i], tw_pow<P>(tw, n, (uint64_t)i * k2));
+constexpr unsigned CROSS_COL_THREADS = 128;   // x N x 32 B of LDS per workgroup: 32 KiB at N = 8, 64 KiB at N = 16
+
+// compile-time loop: f(integral_constant<unsigned, I>) for I = FROM .. TO - 1
+template <unsigned FROM, unsigned TO, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (FROM < TO) {
+        f(std::integral_constant<unsigned, FROM>{});
+        static_for<FROM + 1, TO>(f);
     }
+}
+
+// The same butterfly, one lane per COLUMN b for the usual rank counts: the N inputs of a column are loaded and twiddled once
+// (k_cross_dft redoes that for every output: N (N - 1) twiddle products per column), then a radix-2 decimation-in-frequency network
+// -- N/2 log2 N root products instead of N (N - 1) -- whose bit-reversed positions are undone when storing.  N = 8: 7 + 12 products
+// per column against 112.  The column's N values live in LDS, limb-major (one bank per lane for every access): as a private array
+// hipcc (ROCm 7.2) keeps 8 x 32 bytes per lane in SCRATCH whatever the unrolling (measured: 272 bytes of private segment).
+template <class P, unsigned N>
+__global__ __launch_bounds__(CROSS_COL_THREADS) void k_cross_dft_col(const Fp<P> *in, Fp<P> *out, const Fp<P> *roots, uint64_t B, const Fp<P> *tw, uint64_t n,
+                                                                     uint64_t k2_base, int in_twiddle, int out_twiddle, Fp<P> scale, int use_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t *sh = (uint32_t *)smem_raw;                              // [N][P::N limbs][CROSS_COL_THREADS]
+    const unsigned t = threadIdx.x;
+    auto put = [&](unsigned i, const Fp<P> &v) {
 #pragma unroll
-    for (unsigned s = N / 2; s >= 1; s >>= 1) {          // DIF stages: blocks of 2 s, partner distance s
+        for (int l = 0; l < P::N; ++l) sh[(i * P::N + l) * CROSS_COL_THREADS + t] = v.l[l];
+    };
+    auto get = [&](unsigned i) {
+        Fp<P> v;
 #pragma unroll
+        for (int l = 0; l < P::N; ++l) v.l[l] = sh[(i * P::N + l) * CROSS_COL_THREADS + t];
+        return v;
+    };
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + t;
+    if (b >= B) return;                                               // no barrier below: every lane owns its slice of the LDS
+    const uint64_t k2 = k2_base + b;
+    for (unsigned i = 0; i < N; ++i) {
+        Fp<P> v = in[(uint64_t)i * B + b];
+        if (in_twiddle && i) v = mul<P>(v, tw_pow<P>(tw, n, (uint64_t)i * k2));
+        put(i, v);
+    }
+    for (unsigned s = N / 2; s >= 1; s >>= 1) {                      // DIF stages: blocks of 2 s, partner distance s
         for (unsigned j = 0; j < N; ++j) {
-            if ((j & s) == 0) {
-                const Fp<P> a = x[j], c = x[j + s];
-                x[j] = add<P>(a, c);
-                const unsigned e = (j & (s - 1)) * (N / (2 * s));
-                const Fp<P> d = sub<P>(a, c);
-                x[j + s] = e ? mul<P>(d, roots[e]) : d;
-            }
+            if (j & s) continue;
+            const Fp<P> a = get(j), c = get(j + s);
+            put(j, add<P>(a, c));
+            const unsigned e = (j & (s - 1)) * (N / (2 * s));
+            const Fp<P> d = sub<P>(a, c);
+            put(j + s, e ? mul<P>(d, roots[e]) : d);
         }
     }
-#pragma unroll
-    for (unsigned p = 0; p < N; ++p) {                    // position p holds output index bitrev(p)
-        unsigned o = 0;
-#pragma unroll
-        for (unsigned bit = 1, rb = N >> 1; bit < N; bit <<= 1, rb >>= 1)
-            if (p & bit) o |= rb;
-        Fp<P> v = x[p];
+    constexpr int LOGN = N == 2 ? 1 : N == 4 ? 2 : N == 8 ? 3 : 4;
+    static_assert((1u << LOGN) == N, "N in {2, 4, 8, 16}");
+    for (unsigned p = 0; p < N; ++p) {                                // position p holds output index bitrev(p)
+        const unsigned o = __brev(p) >> (32 - LOGN);
+        Fp<P> v = get(p);
         if (use_scale) v = mul<P>(v, scale);
         if (out_twiddle && o) v = mul<P>(v, tw_pow<P>(tw, n, (uint64_t)o * k2));
         out[(uint64_t)o * B + b] = v;
@@ -200,7 +223,8 @@ static void launch_cross_dft(hipStream_t st, const Fp<P> *in, Fp<P> *out, const 
     static const bool col = [] { const char *e = getenv("PM_CROSS_DFT_COL"); return !(e && e[0] == '0'); }();
 #define PM_COL(NN)                                                                                                                          \
     case NN:                                                                                                                                \
-        hipLaunchKernelGGL((k_cross_dft_col<P, NN>), dim3(nblk(L.B)), dim3(256), 0, st, in, out, roots, L.B, tw, L.n, k2_base, in_twiddle,   \
+        hipLaunchKernelGGL((k_cross_dft_col<P, NN>), dim3(nblk(L.B, CROSS_COL_THREADS)), dim3(CROSS_COL_THREADS),                           \
+                           (size_t)NN * sizeof(Fp<P>) * CROSS_COL_THREADS, st, in, out, roots, L.B, tw, L.n, k2_base, in_twiddle,            \
                            out_twiddle, scale, use_scale);                                                                                  \
         return;
     if (col) switch (L.N) {
