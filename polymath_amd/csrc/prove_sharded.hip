@@ -264,23 +264,30 @@ static int shard_roots(pm_ctx *ctx, const pm_pk *pk, const Fp<typename C::FrP> *
     return PM_OK;
 }
 
-// evaluations (cyclic, `x`, destroyed) -> coefficients (blocked, `y`); `tmp`: m elements of scratch
+// evaluations (cyclic, `x`, destroyed) -> coefficients (blocked, `y`); `tmp`: m elements of scratch.
+// `e` = the context whose stream, transform workspace and twiddle cache carry the transform: ctx itself, or its helper context
+// when w's transform runs beside u's chain (PM_NTT_OVERLAP=1).  The communicator and the error slot are always ctx's.
 template <class C>
-static int dist_intt(pm_ctx *ctx, const pm_pk *pk, const Layout &L, Fp<typename C::FrP> *x, Fp<typename C::FrP> *tmp, Fp<typename C::FrP> *y) {
+static int dist_intt(pm_ctx *ctx, pm_ctx *e, const pm_pk *pk, const Layout &L, Fp<typename C::FrP> *x, Fp<typename C::FrP> *tmp, Fp<typename C::FrP> *y) {
     typedef typename C::FrP P;
     typedef Fp<P> Fr;
     unsigned log_m = 0;
     while (((uint64_t)1 << log_m) < L.m) ++log_m;
-    PM_TRY(ntt_run<C>(ctx, x, log_m, true));                                    // N local transforms (this rank's), scaled by 1/m
-    StageTimer t(ctx, T_NTT);
-    PM_TRY(comm_status(ctx, ctx->comm->all_to_all(x, tmp, (size_t)L.B * sizeof(Fr), ctx->stream), "all_to_all"));   // block p -> rank p
+    auto on_e = [&](int st) { if (st != PM_OK && e != ctx) ctx->err = e->err; return st; };
+    PM_TRY(on_e(ntt_run<C>(e, x, log_m, true)));                                // N local transforms (this rank's), scaled by 1/m
+    StageTimer t(e, T_NTT);
+    PM_TRY(comm_status(ctx, ctx->comm->all_to_all(x, tmp, (size_t)L.B * sizeof(Fr), e->stream), "all_to_all"));   // block p -> rank p
     const Fr *rf = nullptr, *ri = nullptr, *tw = nullptr;
     PM_TRY(shard_roots<C>(ctx, pk, &rf, &ri));
-    PM_TRY(twiddles_get<C>(ctx, pk->log_n, true, &tw));
+    PM_TRY(on_e(twiddles_get<C>(e, pk->log_n, true, &tw)));
     const Fr ninv = inverse<P>(from_u64<P>(L.N));
-    launch_cross_dft<P>(ctx->stream, (const Fr *)tmp, y, ri, L, tw, 1, 0, ninv, 1);
+    launch_cross_dft<P>(e->stream, (const Fr *)tmp, y, ri, L, tw, 1, 0, ninv, 1);
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
+}
+template <class C>
+static int dist_intt(pm_ctx *ctx, const pm_pk *pk, const Layout &L, Fp<typename C::FrP> *x, Fp<typename C::FrP> *tmp, Fp<typename C::FrP> *y) {
+    return dist_intt<C>(ctx, ctx, pk, L, x, tmp, y);
 }
 
 // coefficients (blocked, `y`, kept) -> evaluations (cyclic, `x`); `tmp`: m elements of scratch
@@ -771,9 +778,25 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         PM_HIP(ctx, hipGetLastError());
         PM_TRY(dist_intt<C>(ctx, pk, L, tc, ta, wit_u));
     }
+    // PM_NTT_OVERLAP=1 (opt-in): w's transform (N2) runs on the helper context's stream beside u's chain
+    // (N1, then the three transforms of the square) and joins before k_untwist_combine_L, so that on a fabric its all-to-all
+    // travels under u's kernels and u's under w's local passes.  Every rank issues the exchanges in the same order
+    // (u, w, square forward, square inverse); they are on two streams of ONE communicator.
+    const char *ntt_env = getenv("PM_NTT_OVERLAP");           // read per proof: the tests switch it inside one process
+    const bool ntt_beside = ntt_env && ntt_env[0] == '1';
+    pm_ctx *wctx = ctx;
+    if (ntt_beside) {
+        if (!ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
+        if (ctx->aux && ctx->aux->sh_a.reserve(m * sizeof(Fr)) == hipSuccess) wctx = ctx->aux;
+    }
+    if (wctx != ctx) {   // `we` is complete (and k_check_sap_L has read it) at this point of the stream
+        PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
+        PM_HIP(ctx, hipStreamWaitEvent(wctx->stream, ctx->ev_sc_a, 0));
+    }
     PM_TRY(dist_intt<C>(ctx, pk, L, ue, ta, u));
     if (q == 0) PM_HIP(ctx, hipMemcpyAsync(u + m, ra, 2 * sizeof(Fr), hipMemcpyDeviceToDevice, st));   // sc_a = u || r_a on rank 0
-    PM_TRY(dist_intt<C>(ctx, pk, L, we, ta, wv));
+    PM_TRY(dist_intt<C>(ctx, wctx, pk, L, we, wctx != ctx ? wctx->sh_a.as<Fr>() : ta, wv));
+    if (wctx != ctx) PM_HIP(ctx, hipEventRecord(wctx->ev_sc_a, wctx->stream));
     if (sparse_head) {
         const Fr *winv = nullptr;
         PM_TRY(twiddles_get<C>(ctx, pk->log_n, true, &winv));
@@ -793,6 +816,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         hipLaunchKernelGGL(k_square_L<P>, dim3(nblk(m)), dim3(256), 0, st, tc, m);
         PM_HIP(ctx, hipGetLastError());
         PM_TRY(dist_intt<C>(ctx, pk, L, tc, tb, ta));
+        if (wctx != ctx) PM_HIP(ctx, hipStreamWaitEvent(st, wctx->ev_sc_a, 0));   // w's coefficients
         hipLaunchKernelGGL(k_untwist_combine_L<P>, dim3(nblk(m)), dim3(256), 0, st, ta, psi_inv, wv, u2lo, u2hi, L, inverse<P>(from_u64<P>(2)));
         PM_HIP(ctx, hipGetLastError());
     }
@@ -837,7 +861,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         const int en_c = st_a == PM_OK && st_c == PM_OK ? msm_resident_end<C>(ctx, r1->c_xy, &c_inf_l) : (int)PM_OK;
         if (st_a == PM_OK) st_a = msm_resident_end<C>(aux, r1->a_xy, &a_inf_l);      // always drained: its scalars live in this context
         timing_flush(aux);
-        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += aux->timing_ms[s];
+        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL, T_NTT}) ctx->timing_ms[s] += aux->timing_ms[s];
         if (st_a != PM_OK) { ctx->err = aux->err; return st_a; }
         PM_TRY(st_c);
         PM_TRY(en_c);

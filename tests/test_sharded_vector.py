@@ -201,6 +201,43 @@ def test_vector_sharded_proof_equals_single_gpu(oracle, curve, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [2, 8])
+def test_vector_sharded_w_transform_beside_u_chain(oracle, monkeypatch, N):
+    """PM_NTT_OVERLAP=1 (opt-in): w's distributed transform on the helper stream beside u's chain, its all-to-all issued
+    between u's exchanges on a second stream of the same communicator.  Three proofs in a row on the same contexts (the
+    helper's buffers and events are reused) equal the CPU oracle's bytes; w's coefficients equal the oracle's tap; and the
+    switch can be turned off again in the same process."""
+    from polymath_amd import api, circuits as PC
+    curve = "bls12_381"
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, 5000)
+    g = PC.SplitMix64(0x0E11 + N)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    oracle_proof, opk = _oracle_reference(oracle, curve, lc, x, z, r_a)
+    monkeypatch.setenv("PM_NTT_OVERLAP", "1")
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    assert all(p == oracle_proof for p in proofs)
+    n = pks[0].n
+    for w in (2, 3):                                        # u, w: blocked coefficient layout
+        got = np.zeros((n, 4), dtype=np.uint64)
+        for r in range(N):
+            got[api.layout_indices(n, N, r)] = pks[r].tap(w, n)
+        ref = opk.tap(w, 11 * n)
+        k = min(n, len(ref))
+        assert np.array_equal(got[:k], ref[:k]) and not got[k:].any(), w
+    r_b = [g.fr(c.r), g.fr(c.r)]
+    oracle_b, _ = _oracle_reference(oracle, curve, lc, x, z, r_b)
+    for ra, want in ((r_b, oracle_b), (r_a, oracle_proof)):
+        out = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, ra), comms)
+        assert all(p == want for p in out)
+    monkeypatch.setenv("PM_NTT_OVERLAP", "0")
+    out = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_b), comms)
+    assert all(p == oracle_b for p in out)
+    for pk in pks:
+        pk.free()
+
+
+@pytest.mark.gpu
 def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
     """Tiny sub-segments (PM_MAX_SEG_LOG=6: hundreds of segments per rank, several per block), a circuit with 12 public
     inputs (2 m0 > 16: the witness-only part of u takes its own distributed transform), all three transcripts; an
@@ -225,6 +262,7 @@ def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
     lc = LimbCircuit(f, r1cs.m0, r1cs.mw, r1cs.nr, (_csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)), f.fr_limbs(cs.instance), f.fr_limbs(cs.witness))
     x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
     for tname in ("merlin", "keccak256", "blake3"):
+        monkeypatch.setenv("PM_NTT_OVERLAP", "1" if tname == "keccak256" else "0")   # the opt-in two-stream transforms on this shape too
         ref_pm = Polymath(curve, tname, device=0)
         ref_pk = ref_pm.setup(lc, x, z)
         ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
