@@ -150,20 +150,7 @@ __global__ void k_cross_dft(const Fp<P> *in, Fp<P> *out, const Fp<P> *roots, uin
     out[o * B + b] = acc;
 }
 
-// The same butterfly, one lane per COLUMN b for the usual rank counts: the N inputs of a column are loaded and twiddled once
-// (k_cross_dft redoes that for every output: N (N - 1) twiddle products per column), then a radix-2 decimation-in-frequency network
-// in registers -- N/2 log2 N root products instead of N (N - 1) -- whose bit-reversed positions are undone when storing.
-// N = 8: 7 + 12 products per column against 112.
 constexpr unsigned CROSS_COL_THREADS = 128;   // x N x 32 B of LDS per workgroup: 32 KiB at N = 8, 64 KiB at N = 16
-
-// compile-time loop: f(integral_constant<unsigned, I>) for I = FROM .. TO - 1
-template <unsigned FROM, unsigned TO, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (FROM < TO) {
-        f(std::integral_constant<unsigned, FROM>{});
-        static_for<FROM + 1, TO>(f);
-    }
-}
 
 // The same butterfly, one lane per COLUMN b for the usual rank counts: the N inputs of a column are loaded and twiddled once
 // (k_cross_dft redoes that for every output: N (N - 1) twiddle products per column), then a radix-2 decimation-in-frequency network
