@@ -238,6 +238,29 @@ def test_vector_sharded_w_transform_beside_u_chain(oracle, monkeypatch, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tables", ["wide", "0"])
+def test_vector_sharded_without_window_tables(oracle, monkeypatch, tables):
+    """The shards' MSMs on the two table-less pipelines (PM_TABLES=wide: one bucket set per window, what a shard whose
+    tables do not fit HBM runs; PM_TABLES=0: the per-window pipeline): 4 ranks, both MSMs of phase 1 in flight together
+    (msm_begin / msm_end), the same bytes as the CPU oracle."""
+    from polymath_amd import circuits as PC
+    curve, N = "bls12_381", 4
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, 5000)
+    g = PC.SplitMix64(0x71DE)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    oracle_proof, _ = _oracle_reference(oracle, curve, lc, x, z, r_a)
+    monkeypatch.setenv("PM_TABLES", tables)
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    assert all(not pk.msm_plan(k)[3] for pk in pks for k in range(3))          # no MSM of any shard holds tables
+    assert all(p == oracle_proof for p in proofs)
+    out = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms)
+    assert all(p == oracle_proof for p in out)
+    for pk in pks:
+        pk.free()
+
+
+@pytest.mark.gpu
 def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
     """Tiny sub-segments (PM_MAX_SEG_LOG=6: hundreds of segments per rank, several per block), a circuit with 12 public
     inputs (2 m0 > 16: the witness-only part of u takes its own distributed transform), all three transcripts; an
