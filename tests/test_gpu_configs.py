@@ -210,3 +210,46 @@ def test_ntt_bn254_2p21_vs_oracle_and_2p24_roundtrip(gpu_ctx, oracle):
     omega = pow(c.two_adic_root, 1 << (c.two_adicity - 24), c.r)
     for k, got in zip([0, 1, 2, 77777], fs):
         assert got == sum(v * pow(omega, j * k, c.r) for j, v in zip(idx, vals)) % c.r
+
+
+# ------------------------------------------------- one resident key, several contexts proving at once
+def test_three_contexts_prove_concurrently_on_one_resident_key(oracle):
+    """include/polymath_hip.h, threading note: a pm_pk is immutable and shareable, a pm_ctx runs one proof at a time.  Three
+    host threads, each with its own context (stream, workspaces, helper context of the overlapped [a]_1 MSM), prove
+    different r_a against the SAME resident key at the same time, six proofs each: every proof equals the one the CPU
+    oracle computes for that r_a (2^16 - 100 gates: three-level sort, window tables, two transform passes)."""
+    import threading
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    from test_sharded_vector import _oracle_reference
+    curve, K, ROUNDS = "bls12_381", 3, 6
+    c = CURVES[curve]
+    lc = PC.synthetic_r1cs_native(curve, (1 << 16) - 100)
+    g = PC.SplitMix64(0xC0C0)
+    x, z = g.fr(c.r), g.fr(c.r)
+    ras = [[g.fr(c.r), g.fr(c.r)] for _ in range(K)]
+    want = [_oracle_reference(oracle, curve, lc, x, z, ra)[0] for ra in ras]
+    pms = [Polymath(curve, "merlin", device=0) for _ in range(K)]
+    pk = pms[0].setup(lc, x, z)
+    views = [pk] + [pk.view(p.ctx) for p in pms[1:]]
+    got, errs = [[None] * ROUNDS for _ in range(K)], [None] * K
+    start = threading.Barrier(K)
+
+    def body(i):
+        try:
+            start.wait(60)
+            for k in range(ROUNDS):
+                got[i][k] = pms[i].prove_native(views[i], lc.inst_limbs, lc.wit_limbs, ras[(i + k) % K])
+        except BaseException as e:     # noqa: BLE001
+            errs[i] = e
+    th = [threading.Thread(target=body, args=(i,), daemon=True) for i in range(K)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not any(t.is_alive() for t in th)
+    assert errs == [None] * K, errs
+    for i in range(K):
+        for k in range(ROUNDS):
+            assert got[i][k] == want[(i + k) % K], (i, k)
+    pk.free()
