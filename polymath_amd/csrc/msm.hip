@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // (setup.hip: tables_build), so every window's digits share ONE set of 2^(c-1) buckets: c = 22 gives
 // 12 mixed adds per pair instead of 16, no per-window reduction and no doublings.  2^21 buckets do not
 // fit an LDS histogram, so the sort is a three-level MSD radix over (u16 key, u32 table index) entries:
-// k_tbl_count / k_block_scan / k_tbl_partition (64 regions of 2^15 buckets, atomic-free offsets),
+// k_tbl_count / k_block_sums + k_block_offsets / k_tbl_partition (64 regions of 2^15 buckets, atomic-free offsets),
 // k_region_pass<HIST> + k_region_pass_staged<MID> (128 sub-regions of 256 buckets), <HIST> + the bucket
 // scan + k_region_pass_staged<FINAL>; every scatter is staged through LDS and written out coalesced.
 // Reduction: k_reduce_level0 / k_reduce_level1 / k_sum_final (chains of dependent point additions).
@@ -544,7 +544,7 @@ __device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned lo, unsigned c
 }
 
 // Region populations PER WORKGROUP: block_cnt[workgroup][region], with the same workgroup -> scalar mapping
-// as k_tbl_partition (one scalar per lane).  A column-wise scan (k_block_scan) turns them into each
+// as k_tbl_partition (one scalar per lane).  A column-wise scan (k_block_sums, k_block_offsets) turns them into each
 // workgroup's offset inside each region, so neither kernel touches a global atomic: 41 K workgroups x 64
 // regions hammering 64 addresses serialised in L2 and cost more than the rest of the kernel.
 template <class P, unsigned NWIN>
@@ -565,28 +565,82 @@ __global__ __launch_bounds__(512) void k_tbl_count(const Fp<P> *scalars, const u
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) block_cnt[(size_t)blockIdx.x * regions + r] = cnt[r];
 }
 
-// Column r of block_cnt[nblocks][regions] -> exclusive prefix over the workgroups (in place), total -> region_count[r].
-__global__ __launch_bounds__(1024) void k_block_scan(uint32_t *block_cnt, unsigned nblocks, unsigned regions, uint32_t *region_count) {
+// block_cnt[nblocks][regions] -> per region the exclusive prefix over the workgroups (in place), totals -> region_count.
+// Two launches of G workgroups.  Workgroup g owns the block rows [g span, (g + 1) span); lane (j, r) = (t / regions, t % regions),
+// j < rows <= 16, owns `per` consecutive rows of region r, so a wave reads 64 consecutive regions of one row: whole cache lines.
+// (Round 2's form -- one workgroup per REGION, every lane striding through the rows of its column -- kept 64 CUs busy with
+// uncoalesced 4-byte loads: 0.16 ms at 41 K rows x 64 regions, profiles/r03_final_rocprofv3_kernel_stats_bench_2p20.csv.)
+struct BlockScanShape { unsigned G, span, rows, per; };
+static BlockScanShape block_scan_shape(unsigned nblocks, unsigned regions) {
+    BlockScanShape h;
+    h.rows = 1024 / regions < 16 ? 1024 / regions : 16;
+    if (h.rows < 1) h.rows = 1;
+    h.G = (nblocks + 15) / 16 < 256 ? (nblocks + 15) / 16 : 256;
+    if (h.G < 1) h.G = 1;
+    h.span = (nblocks + h.G - 1) / h.G;
+    h.per = (h.span + h.rows - 1) / h.rows;
+    return h;
+}
+__device__ __forceinline__ void block_scan_range(unsigned g, unsigned j, BlockScanShape h, unsigned nblocks, unsigned &lo, unsigned &hi) {
+    const unsigned end = (g + 1) * h.span < nblocks ? (g + 1) * h.span : nblocks;
+    lo = g * h.span + j * h.per;
+    hi = lo + h.per < end ? lo + h.per : end;
+}
+__global__ __launch_bounds__(1024) void k_block_sums(const uint32_t *block_cnt, unsigned nblocks, unsigned regions, BlockScanShape h, uint32_t *partial) {
     __shared__ uint32_t s[1024];
-    const unsigned r = blockIdx.x, t = threadIdx.x;
-    const unsigned per = (nblocks + 1023) / 1024, b0 = t * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-    uint32_t sum = 0;
-    for (unsigned b = b0; b < b1; ++b) sum += block_cnt[(size_t)b * regions + r];
-    s[t] = sum;
+    const unsigned t = threadIdx.x, j = t / regions, r = t % regions;
+    if (j < h.rows) {
+        unsigned lo, hi;
+        block_scan_range(blockIdx.x, j, h, nblocks, lo, hi);
+        uint32_t sum = 0;
+        for (unsigned b = lo; b < hi; ++b) sum += block_cnt[(size_t)b * regions + r];
+        s[t] = sum;
+    }
     __syncthreads();
-    for (unsigned o = 1; o < 1024; o <<= 1) {
-        const uint32_t a = t >= o ? s[t - o] : 0u;
-        __syncthreads();
-        s[t] += a;
-        __syncthreads();
+    if (t < regions) {
+        uint32_t tot = 0;
+        for (unsigned jj = 0; jj < h.rows; ++jj) tot += s[jj * regions + t];
+        partial[(size_t)blockIdx.x * regions + t] = tot;
     }
-    uint32_t run = s[t] - sum;
-    for (unsigned b = b0; b < b1; ++b) {
-        const uint32_t v = block_cnt[(size_t)b * regions + r];
-        block_cnt[(size_t)b * regions + r] = run;
-        run += v;
+}
+__global__ __launch_bounds__(1024) void k_block_offsets(uint32_t *block_cnt, unsigned nblocks, unsigned regions, BlockScanShape h, const uint32_t *partial,
+                                                        uint32_t *region_count) {
+    __shared__ uint32_t s[1024], base[1024];
+    const unsigned t = threadIdx.x, j = t / regions, r = t % regions, g = blockIdx.x;
+    if (j < h.rows) {                                   // the earlier workgroups' totals, rows-way split
+        uint32_t acc = 0;
+        for (unsigned q = j; q < g; q += h.rows) acc += partial[(size_t)q * regions + r];
+        s[t] = acc;
     }
-    if (t == 1023) region_count[r] = s[1023];
+    __syncthreads();
+    if (t < regions) {
+        uint32_t tot = 0;
+        for (unsigned jj = 0; jj < h.rows; ++jj) tot += s[jj * regions + t];
+        base[t] = tot;
+    }
+    __syncthreads();
+    unsigned lo = 0, hi = 0;
+    if (j < h.rows) {
+        block_scan_range(g, j, h, nblocks, lo, hi);
+        uint32_t sum = 0;
+        for (unsigned b = lo; b < hi; ++b) sum += block_cnt[(size_t)b * regions + r];
+        s[t] = sum;
+    }
+    __syncthreads();
+    if (j < h.rows) {
+        uint32_t run = base[r];
+        for (unsigned jj = 0; jj < j; ++jj) run += s[jj * regions + r];
+        for (unsigned b = lo; b < hi; ++b) {
+            const uint32_t v = block_cnt[(size_t)b * regions + r];
+            block_cnt[(size_t)b * regions + r] = run;
+            run += v;
+        }
+    }
+    if (g == gridDim.x - 1 && t < regions) {
+        uint32_t tot = base[t];
+        for (unsigned jj = 0; jj < h.rows; ++jj) tot += s[jj * regions + t];
+        region_count[t] = tot;
+    }
 }
 
 // region_off = exclusive scan of region_count (regions <= 1024); also clears the claim cursors
@@ -1101,14 +1155,17 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
         if (regions > pbd) return PM_ERR_INVALID_ARG;                      // one scan lane per region
         const size_t plds = 2 * 1024 * 4 + (size_t)pbd * nwin * 8;
         const unsigned pblocks = (unsigned)((len + pbd - 1) / pbd);
-        PM_HIP(ctx, ws.block_cnt.reserve((size_t)pblocks * regions * 4));
-        uint32_t *block_cnt = ws.block_cnt.as<uint32_t>();
+        const BlockScanShape bsh = block_scan_shape(pblocks, regions);
+        PM_HIP(ctx, ws.block_cnt.reserve(((size_t)pblocks + bsh.G) * regions * 4));
+        uint32_t *block_cnt = ws.block_cnt.as<uint32_t>(), *block_partial = block_cnt + (size_t)pblocks * regions;
         int launched = 0;
 #define PM_TBL_CASE(NW)                                                                                                     \
         case NW:                                                                                                                \
             hipLaunchKernelGGL((k_tbl_count<FrP, NW>), dim3(pblocks), dim3(pbd), 0, ctx->stream, d_scalars, inf, len, regions,  \
                                block_cnt, win_buckets);                                                                         \
-            hipLaunchKernelGGL(k_block_scan, dim3(regions), dim3(1024), 0, ctx->stream, block_cnt, pblocks, regions, region_count); \
+            hipLaunchKernelGGL(k_block_sums, dim3(bsh.G), dim3(1024), 0, ctx->stream, block_cnt, pblocks, regions, bsh, block_partial); \
+            hipLaunchKernelGGL(k_block_offsets, dim3(bsh.G), dim3(1024), 0, ctx->stream, block_cnt, pblocks, regions, bsh, block_partial, \
+                               region_count);                                                                                  \
             hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, region_count, region_off, region_cursor,  \
                                regions);                                                                                        \
             if (hipFuncSetAttribute((const void *)k_tbl_partition<FrP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
