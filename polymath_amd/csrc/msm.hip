@@ -257,6 +257,9 @@ __global__ __launch_bounds__(1024) void k_scatter(const uint32_t *digits, const 
 // tasks start first.  bin = (seg - L) >> lshift, L in [1, seg].
 constexpr unsigned TASK_MAX_BINS = 8192;
 
+// One lane per BUCKET g (its tasks are task_off[g] .. task_off[g + 1] - 1: all but the last are full, L = seg, bin 0; the last
+// one has the remainder), so a lane issues at most two LDS atomics and no search.  (Round 2 ran one lane per TASK and found
+// the task's bucket by a 21-step binary search over task_off: 0.19 ms for the two launches at 2^21 buckets.)
 template <bool SCATTER>
 __global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, const uint32_t *task_off, size_t G, unsigned seg,
                                                     unsigned lshift, unsigned nbins, uint32_t *len_cnt, const uint32_t *len_off,
@@ -265,20 +268,18 @@ __global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, cons
     uint32_t *h = (uint32_t *)smem_raw;
     for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) h[b] = 0;
     __syncthreads();
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total = task_off[G];
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t t0 = 0, n = 0, rank_full = 0, rank_last = 0;
     unsigned bin = 0;
-    uint32_t rank = 0;
-    if (t < total) {
-        size_t lo = 0, hi = G;
-        while (hi - lo > 1) {
-            size_t mid = (lo + hi) >> 1;
-            if (task_off[mid] <= t) lo = mid; else hi = mid;
+    if (g < G) {
+        t0 = task_off[g];
+        n = task_off[g + 1] - t0;
+        if (n) {
+            const uint32_t L = counts[g] - (n - 1) * seg;           // 1 .. seg
+            bin = (seg - L) >> lshift;
+            if (n > 1) rank_full = atomicAdd(&h[0], n - 1);
+            rank_last = atomicAdd(&h[bin], 1u);
         }
-        const uint32_t rem = counts[lo] - ((uint32_t)t - task_off[lo]) * seg;
-        const uint32_t L = rem < seg ? rem : seg;
-        bin = (seg - L) >> lshift;
-        rank = atomicAdd(&h[bin], 1u);
     }
     __syncthreads();
     if (!SCATTER) {
@@ -292,7 +293,11 @@ __global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, cons
             if (v) h[b] = len_off[b] + atomicAdd(&len_cursor[b], v);
         }
         __syncthreads();
-        if (t < total) order[h[bin] + rank] = (uint32_t)t;
+        if (n) {
+            const uint32_t at = h[0] + rank_full;
+            for (uint32_t k = 0; k + 1 < n; ++k) order[at + k] = t0 + k;       // (a hot bucket: thousands; the rest: none or one)
+            order[h[bin] + rank_last] = t0 + n - 1;
+        }
     }
 }
 
@@ -1008,7 +1013,7 @@ static int task_order(pm_ctx *ctx, const uint32_t *counts, size_t G, size_t seg,
     PM_HIP(ctx, ws.len_bins.reserve((3 * (size_t)nbins + 4) * 4));
     uint32_t *len_cnt = ws.len_bins.as<uint32_t>(), *len_off = len_cnt + nbins, *len_cursor = len_off + nbins + 1;
     PM_HIP(ctx, hipMemsetAsync(len_cnt, 0, (size_t)nbins * 4, ctx->stream));
-    const unsigned blocks = (unsigned)((max_tasks + 1023) / 1024);
+    const unsigned blocks = (unsigned)((G + 1023) / 1024);      // one lane per bucket
     hipLaunchKernelGGL(k_task_bins<false>, dim3(blocks), dim3(1024), nbins * 4, ctx->stream, counts, ws.task_off.as<uint32_t>(), G,
                        (unsigned)seg, lshift, nbins, len_cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     PM_HIP(ctx, hipGetLastError());
