@@ -84,7 +84,7 @@ def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
 def live_traffic(args, timeout_s=None):
     """HBM traffic of k_accumulate measured NOW, by this run: two child processes of this script under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md's HBM section
-    prescribes), PM_MSM_OVERLAP=0 so that every launch runs alone; per-launch bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B
+    prescribes), --opt msm_overlap=0 so that every launch runs alone; per-launch bytes = 2 x FETCH_SIZE (gfx950 tallies 128-B
     requests at 64 B; calibrated on this access pattern by tools/pmc_gather_calib.hip) + WRITE_SIZE, both in KB.
     -> (bytes per launch, description) or (None, reason): the caller then falls back to the committed profile."""
     import csv, shutil, signal, subprocess, tempfile
@@ -101,8 +101,8 @@ def live_traffic(args, timeout_s=None):
         d = tempfile.mkdtemp(prefix="pm_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic",
-               "--log-constraints", str(args.log_constraints), "--curve", args.curve, "--transcript", args.transcript]
-        env = dict(os.environ, PM_MSM_OVERLAP="0", TMPDIR="/tmp")
+               "--log-constraints", str(args.log_constraints), "--curve", args.curve, "--transcript", args.transcript, "--opt", "msm_overlap=0"]
+        env = dict(os.environ, TMPDIR="/tmp")
         try:
             # own session: on a timeout the whole tree (rocprofv3 AND the profiled python) is killed, not just the profiler
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -128,7 +128,7 @@ def live_traffic(args, timeout_s=None):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return (2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"]) * 1024.0, \
-        "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes (PM_MSM_OVERLAP=0, %d launches each); bytes = 2 x FETCH_SIZE + WRITE_SIZE" % launches
+        "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes (msm_overlap = 0, %d launches each); bytes = 2 x FETCH_SIZE + WRITE_SIZE" % launches
 
 
 def msm_micro(ctx, curve, logs, reps=3):
@@ -173,6 +173,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-micro", default="20,22,24,26", help="log2 lengths of the standalone resident MSM legs ('' = none)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure `roofline.traffic`")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="pm_ctx_set_option on the proving context before the key is generated, e.g. --opt msm_overlap=0 --opt tables=wide")
     return ap.parse_args()
 
 
@@ -218,7 +220,6 @@ def worker(args):
     from polymath_amd.launch import Watchdog
     wd = Watchdog(rank) if supervised else None
     comm_timeout_s = int(os.environ.get("BENCH_COMM_TIMEOUT_S", "60"))
-    os.environ.setdefault("PM_COMM_TIMEOUT_MS", str(comm_timeout_s * 1000))     # the library's collective deadline
 
     def stage(name, limit_s):
         if wd:
@@ -265,6 +266,9 @@ def worker(args):
     inst = r1cs.instance
     log(rank, "synthetic R1CS: nr=%d m0=%d mw=%d (%.1f s)" % (nr, r1cs.m0, r1cs.mw, time.time() - t0))
     pm = Polymath(curve, args.transcript, device=local)
+    for kv in args.opt:                              # modes are per-context options of the library, not environment variables
+        name, value = kv.split("=", 1)
+        pm.ctx.set_option(name, int(value) if value.lstrip("-").isdigit() else value)
     g = PC.SplitMix64(0xBE7C4)
     x_trap, z_trap, r_a = g.fr(r), g.fr(r), [g.fr(r), g.fr(r)]
     t0 = time.time()
@@ -377,14 +381,15 @@ def worker(args):
     if native:
         acc_ms, msm_ms, sort_ms, red_ms, phase_ms = [tm3["msm_accumulate"]], [tm3["msm_total"]], [tm3["msm_sort"]], [tm3["msm_reduce"]], [tm3["phase"]]
         acc1_ms = [tm1["msm_accumulate"]]
-    # Roofline sample, outside the timed region: ONE proof with PM_MSM_OVERLAP=0, so that each k_accumulate launch runs
+    # Roofline sample, outside the timed region: ONE proof with PM_OPT_MSM_OVERLAP = 0, so that each k_accumulate launch runs
     # alone on the chip (in the timed proofs the [a] launch shares it with the transforms and the [c] MSM, which
     # inflates its HIP-event duration); these are the durations rocprofv3 --stats of the same configuration prints.
-    os.environ["PM_MSM_OVERLAP"] = "0"
+    overlap_was = pm.ctx.get_option("msm_overlap")
+    pm.ctx.set_option("msm_overlap", 0)
     pm.collect_timings = True
     proof_serial = pm.prove_limbs(pk, inst, x_l, w_l, r_a, py_combine, dev_ptrs).to_bytes()
     pm.collect_timings = False
-    del os.environ["PM_MSM_OVERLAP"]
+    pm.ctx.set_option("msm_overlap", overlap_was)
     assert proof_serial == proof_b
     acc_serial_ms = pm.phase_timings[0]["msm_accumulate"] + pm.phase_timings[2]["msm_accumulate"]
     if os.environ.get("BENCH_PHASES"):             # dev hook: stage timings of all three phases (stderr)
@@ -446,7 +451,7 @@ def worker(args):
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
                          "launches_per_step": launches, "avg_launch_ms": acc_s * 1e3 / launches,
-                         "timing": "HIP events on the library's stream around each launch of one PM_MSM_OVERLAP=0 proof outside the timed region "
+                         "timing": "HIP events on the library's stream around each launch of one msm_overlap = 0 proof outside the timed region "
                                    "(launches run alone); in the timed proofs [a] overlaps other kernels: %.3f ms per proof there" % (acc_overlapped_s * 1e3),
                          "algorithmic_bytes_per_launch": bpp * pairs_rank / launches,
                          "largest_launch": {"pairs": d_pairs_rank, "ms": avg(acc_ms),

@@ -99,6 +99,41 @@ const char *pm_last_error(const pm_ctx *ctx);
  * replaces the reference's start_timer!/end_timer! tracing, prover.rs:32-61). */
 int pm_last_timings(const pm_ctx *ctx, double *ms_out, int n_slots);
 
+/* ---- options -----------------------------------------------------------------------------
+ * What a host may choose, per context.  The reference keeps no global state (src/lib.rs:44-50: `Polymath<E, T>` is a
+ * PhantomData), so neither does the library: every mode below is a field of the context, set through this call, and
+ * contexts with different settings prove side by side.  The environment variables named in the comments only give a
+ * new context its DEFAULTS -- they are read once, in pm_ctx_create, never while a proof runs.  Options marked (key) are
+ * read when a key or a resident base vector is created on the context (pm_pk_generate / pm_pk_load / pm_bases_precompute)
+ * and stay with that key. */
+typedef enum pm_option {
+    PM_OPT_MSM_OVERLAP = 0,       /* 0 / 1: the [a]_1 and [c]_1 MSMs of phase 1 (prover.rs:118-123,132) run concurrently.
+                                   * Default 1 (PM_MSM_OVERLAP). */
+    PM_OPT_NTT_OVERLAP = 1,       /* 0 / 1, multi-GPU proofs: w's distributed transform on a second stream beside u's chain
+                                   * (prover.rs:93-96: the two are independent).  Default 1 (PM_NTT_OVERLAP). */
+    PM_OPT_TABLES = 2,            /* (key) pm_tables_mode.  Default PM_TABLES_AUTO (PM_TABLES = 0 | 1 | wide, PM_WIDE = 0). */
+    PM_OPT_MSM_MAX_PIECE_LOG = 3, /* one bucket pipeline covers at most 2^v pairs, 4 <= v <= 27; longer MSMs run in pieces.
+                                   * Default 27 (PM_MSM_MAX_PIECE_LOG); lower values exercise the piece split at small sizes. */
+    PM_OPT_MAX_SEG_LOG = 4,       /* (key, multi-GPU) sub-segments of the division scan hold at most 2^v indices; 0 = chosen
+                                   * from n and the world size.  Default 0 (PM_MAX_SEG_LOG). */
+    PM_OPT_INFLIGHT_CONTEXTS = 5, /* (key) how many contexts will prove on the key at once: their per-proof vectors and MSM
+                                   * workspaces are left out of the HBM granted to window tables.  Default 1 (PM_INFLIGHT_CONTEXTS). */
+    PM_OPT_MSM_TASK_LEN = 6,      /* entries of one bucket-accumulation task; 0 = twice the mean bucket load.  Default 0 (PM_MSM_SEG). */
+    PM_OPT_TABLE_WINDOW_BITS = 7, /* (key) widest window of the table sets; 0 = the cost model of tables_plan.  Default 0 (PM_TABLE_C). */
+    PM_OPT_MSM_CHUNKS = 8,        /* the quotient MSM [d]_1 (prover.rs:229) is sorted in this many pair chunks, chunk k + 1's sort
+                                   * hidden under chunk k's accumulation, ONE bucket set; 1 = one sort.  Default 2 (PM_MSM_CHUNKS). */
+    PM_NUM_OPTIONS = 9
+} pm_option;
+typedef enum pm_tables_mode {
+    PM_TABLES_OFF = 0,      /* no window tables, no wide mode: every MSM on the per-window pipeline */
+    PM_TABLES_AUTO = 1,     /* tables for the MSMs whose tables fit in HBM, the wide mode for the others */
+    PM_TABLES_WIDE = 2,     /* the wide mode for every MSM (test / tuning) */
+    PM_TABLES_NO_WIDE = 3   /* tables where they fit, the per-window pipeline for the others */
+} pm_tables_mode;
+/* PM_ERR_INVALID_ARG for an unknown option or a value outside its range; PM_ERR_STATE while a proof is in flight. */
+int pm_ctx_set_option(pm_ctx *ctx, int option, long long value);
+int pm_ctx_get_option(const pm_ctx *ctx, int option, long long *value);
+
 /* ---- standalone kernels (unit parity + the "G1 MSM pairs/s" metric) ----------------------- */
 /* Radix-2 NTT over Fr, natural order in and out, like ark-poly Radix2EvaluationDomain::fft /
  * ifft (prover.rs:241,319,325); inverse scales by 1/n.  `data` is a HOST buffer of 2^log_n Fr. */
@@ -273,8 +308,11 @@ int pm_comm_set_timeout_ms(pm_comm *c, long timeout_ms);
 int pm_comm_abort(pm_comm *c, const char *why);
 /* 1 once the communicator has failed (deadline, peer abort, transport error). */
 int pm_comm_failed(const pm_comm *c);
-/* Local group with PM_LOCAL_COMM_SERIALIZE=1 (ranks take turns between collectives: emulation of N GPUs on one): the
- * milliseconds this rank spent running, waits for its peers excluded; 0 for other communicators.  Measurement aid. */
+/* Local group only (measurement aid; any handle of the group, before its first collective): on = 1 makes the ranks take
+ * turns between collectives, so that N ranks emulated on ONE GPU do not time-slice it -- each rank's kernels then take what
+ * they would take alone (tools/shard_emulation.py).  PM_ERR_INVALID_ARG for other transports. */
+int pm_comm_local_set_serialize(pm_comm *c, int on);
+/* Serialised local group: the milliseconds this rank spent running, waits for its peers excluded; 0 for other communicators. */
 double pm_comm_busy_ms(pm_comm *c, int reset);
 int pm_comm_all_gather(pm_comm *c, const void *send, void *recv, size_t bytes);
 int pm_comm_all_to_all(pm_comm *c, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream);

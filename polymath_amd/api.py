@@ -55,7 +55,12 @@ EXPORTS = [
     "pm_pk_load_sharded", "pm_pk_generate_sharded", "pm_layout_indices", "pm_pk_msm_pieces",
     "pm_comm_rccl_unique_id", "pm_comm_rccl_create", "pm_comm_local_create", "pm_comm_from_callbacks", "pm_comm_destroy", "pm_comm_rank",
     "pm_comm_world", "pm_comm_last_error", "pm_comm_kind", "pm_comm_set_timeout_ms", "pm_comm_abort", "pm_comm_failed", "pm_comm_busy_ms", "pm_host_make_vk", "pm_host_verify", "pm_comm_all_gather", "pm_comm_all_to_all", "pm_comm_all_gather_device", "pm_comm_combine_points", "pm_ctx_set_comm",
+    "pm_ctx_set_option", "pm_ctx_get_option", "pm_comm_local_set_serialize",
 ]
+# pm_option / pm_tables_mode (include/polymath_hip.h)
+OPTIONS = {"msm_overlap": 0, "ntt_overlap": 1, "tables": 2, "msm_max_piece_log": 3, "max_seg_log": 4, "inflight_contexts": 5,
+           "msm_task_len": 6, "table_window_bits": 7, "msm_chunks": 8}
+TABLES_MODES = {"off": 0, "auto": 1, "wide": 2, "no_wide": 3}
 SHARD_PAIRS, SHARD_VECTOR = 0, 1
 LAYOUTS = {"pairs": SHARD_PAIRS, "vector": SHARD_VECTOR, 0: 0, 1: 1}
 
@@ -143,6 +148,9 @@ def load_library():
     L.pm_comm_all_gather_device.argtypes = [vp, vp, vp, sz, vp]
     L.pm_comm_combine_points.argtypes = [vp, i, i, u64p, intp]
     L.pm_ctx_set_comm.argtypes = [vp, vp]
+    L.pm_ctx_set_option.argtypes = [vp, i, ct.c_longlong]
+    L.pm_ctx_get_option.argtypes = [vp, i, ct.POINTER(ct.c_longlong)]
+    L.pm_comm_local_set_serialize.argtypes = [vp, i]
     _lib = L
     return L
 
@@ -228,13 +236,18 @@ class Comm:
         self.L, self.h, self._keep = load_library(), handle, keep
 
     @classmethod
-    def local_group(cls, world):
-        """`world` ranks as threads of this process (tests, emulation, single-process multi-GPU)."""
+    def local_group(cls, world, serialize=False):
+        """`world` ranks as threads of this process (tests, emulation, single-process multi-GPU).  serialize: the ranks take turns
+        between collectives (pm_comm_local_set_serialize: the per-rank emulation of N GPUs on one)."""
         L = load_library()
         arr = (ct.c_void_p * world)()
         st = L.pm_comm_local_create(world, arr)
         if st:
             raise PolymathError(st, "pm_comm_local_create")
+        if serialize:
+            st = L.pm_comm_local_set_serialize(ct.c_void_p(arr[0]), 1)
+            if st:
+                raise PolymathError(st, "pm_comm_local_set_serialize")
         return [cls(ct.c_void_p(arr[r])) for r in range(world)]
 
     @staticmethod
@@ -345,6 +358,19 @@ class Context:
         """Join this context to its rank's communicator (needed by PM_SHARD_VECTOR keys)."""
         self.comm = comm
         self.check(self.L.pm_ctx_set_comm(self.h, comm.h if comm is not None else None))
+
+    def set_option(self, name, value):
+        """pm_ctx_set_option: name in OPTIONS (or the pm_option number); "tables" also takes a TABLES_MODES name."""
+        key = OPTIONS[name] if isinstance(name, str) else int(name)
+        if key == OPTIONS["tables"] and isinstance(value, str):
+            value = TABLES_MODES[value]
+        self.check(self.L.pm_ctx_set_option(self.h, key, int(value)))
+
+    def get_option(self, name):
+        key = OPTIONS[name] if isinstance(name, str) else int(name)
+        v = ct.c_longlong(0)
+        self.check(self.L.pm_ctx_get_option(self.h, key, ct.byref(v)))
+        return int(v.value)
 
     def selftest_field(self, products_per_field=4096, seed=1):
         """pm_selftest_field: the device's field products vs the host's CIOS -> mismatch counts {field: n} (all zero when healthy)."""

@@ -27,7 +27,8 @@ static void parallel_chunks(uint64_t count, F body) {
     unsigned T = std::thread::hardware_concurrency();
     if (T > 32) T = 32;
     if (T < 1 || count < ((uint64_t)1 << 16)) T = 1;
-    if (const char *e = getenv("PM_HOST_THREADS")) T = (unsigned)std::max(1, atoi(e));
+    static const int env_threads = [] { const char *e = getenv("PM_HOST_THREADS"); return e ? std::max(1, atoi(e)) : 0; }();   // read once
+    if (env_threads) T = (unsigned)env_threads;
     if (T == 1) { body((uint64_t)0, count, 0u); return; }
     std::vector<std::thread> th;
     std::vector<std::exception_ptr> errs(T);
@@ -72,6 +73,50 @@ extern "C" int pm_device_count(void) {
     return n;
 }
 
+// ---- options (include/polymath_hip.h: pm_option).  The environment gives a NEW context its defaults; it is read here, once per
+// context, and nowhere on a proving path.
+struct OptionSpec { const char *env; long long def, lo, hi; };
+static const OptionSpec OPTION_SPECS[PM_NUM_OPTIONS] = {
+    /* PM_OPT_MSM_OVERLAP       */ {"PM_MSM_OVERLAP", 1, 0, 1},
+    /* PM_OPT_NTT_OVERLAP       */ {"PM_NTT_OVERLAP", 1, 0, 1},
+    /* PM_OPT_TABLES            */ {"PM_TABLES", PM_TABLES_AUTO, PM_TABLES_OFF, PM_TABLES_NO_WIDE},
+    /* PM_OPT_MSM_MAX_PIECE_LOG */ {"PM_MSM_MAX_PIECE_LOG", 27, 4, 27},
+    /* PM_OPT_MAX_SEG_LOG       */ {"PM_MAX_SEG_LOG", 0, 0, 40},
+    /* PM_OPT_INFLIGHT_CONTEXTS */ {"PM_INFLIGHT_CONTEXTS", 1, 1, 64},
+    /* PM_OPT_MSM_TASK_LEN      */ {"PM_MSM_SEG", 0, 0, 1 << 20},
+    /* PM_OPT_TABLE_WINDOW_BITS */ {"PM_TABLE_C", 0, 0, 24},
+    /* PM_OPT_MSM_CHUNKS        */ {"PM_MSM_CHUNKS", 2, 1, 8},
+};
+static void options_defaults(pm_options *o) {
+    for (int k = 0; k < PM_NUM_OPTIONS; ++k) {
+        long long v = OPTION_SPECS[k].def;
+        if (const char *e = getenv(OPTION_SPECS[k].env)) {
+            if (k == PM_OPT_TABLES) v = e[0] == 'w' ? PM_TABLES_WIDE : e[0] == '0' ? PM_TABLES_OFF : PM_TABLES_AUTO;   // 0 | 1 | wide
+            else v = atoll(e);
+            if (v < OPTION_SPECS[k].lo || v > OPTION_SPECS[k].hi) v = OPTION_SPECS[k].def;
+        }
+        o->v[k] = v;
+    }
+    if (o->v[PM_OPT_TABLES] == PM_TABLES_AUTO) {
+        const char *e = getenv("PM_WIDE");
+        if (e && e[0] == '0') o->v[PM_OPT_TABLES] = PM_TABLES_NO_WIDE;
+    }
+}
+
+extern "C" int pm_ctx_set_option(pm_ctx *ctx, int option, long long value) {
+    if (!ctx || option < 0 || option >= PM_NUM_OPTIONS) return PM_ERR_INVALID_ARG;
+    if (value < OPTION_SPECS[option].lo || value > OPTION_SPECS[option].hi) return PM_ERR_INVALID_ARG;
+    if (ctx->pk && ctx->phase >= 1 && ctx->phase < 3) return PM_ERR_STATE;     // between phase 1 and phase 3 of a proof
+    ctx->opt.v[option] = value;
+    if (ctx->aux) ctx->aux->opt.v[option] = value;
+    return PM_OK;
+}
+extern "C" int pm_ctx_get_option(const pm_ctx *ctx, int option, long long *value) {
+    if (!ctx || !value || option < 0 || option >= PM_NUM_OPTIONS) return PM_ERR_INVALID_ARG;
+    *value = ctx->opt.v[option];
+    return PM_OK;
+}
+
 extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     if (!out) return PM_ERR_INVALID_ARG;
     *out = nullptr;
@@ -81,6 +126,7 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     pm_ctx *ctx = new (std::nothrow) pm_ctx();
     if (!ctx) return PM_ERR_INVALID_ARG;
     ctx->device = device;
+    options_defaults(&ctx->opt);
     ctx->pk = nullptr;
     ctx->phase = 0;
     ctx->aux = nullptr;
@@ -112,8 +158,16 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     timing_flush(ctx);
     MsmWorkspace &m = ctx->msm;
-    for (DevBuf *b : {&m.digits, &m.sorted, &m.counts, &m.bucket_off, &m.task_off, &m.cursor, &m.partials, &m.wsum,
-                      &m.region, &m.sub, &m.digits2, &m.order, &m.len_bins, &m.block_cnt, &m.task_cnt, &m.hot, &ctx->scratch, &ctx->flags, &ctx->xw, &ctx->ue, &ctx->we, &ctx->u, &ctx->w,
+    for (MsmSet &q : m.set)
+        for (DevBuf *b : {&q.sorted, &q.counts, &q.bucket_off, &q.task_off, &q.order, &q.partials, &q.task_cnt}) b->release();
+    if (m.sort_stream) (void)hipStreamDestroy(m.sort_stream);
+    if (m.ev_begin) (void)hipEventDestroy(m.ev_begin);
+    for (int k = 0; k < MSM_SETS; ++k) {
+        if (m.ev_sorted[k]) (void)hipEventDestroy(m.ev_sorted[k]);
+        if (m.ev_acc[k]) (void)hipEventDestroy(m.ev_acc[k]);
+    }
+    for (DevBuf *b : {&m.digits, &m.cursor, &m.wsum,
+                      &m.region, &m.sub, &m.digits2, &m.len_bins, &m.block_cnt, &m.hot, &ctx->scratch, &ctx->flags, &ctx->xw, &ctx->ue, &ctx->we, &ctx->u, &ctx->w,
                       &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra, &ctx->sh_a, &ctx->sh_b, &ctx->sh_c, &ctx->halo,
                       &ctx->shard_roots, &ctx->ntt_tmp})
         b->release();
@@ -248,7 +302,7 @@ extern "C" int pm_bases_download(pm_ctx *ctx, const pm_bases *b, size_t offset, 
 template <class C>
 static int bases_precompute_impl(pm_ctx *ctx, pm_bases *b) {
     if (b->tables.c || !b->len) return PM_OK;
-    MsmTables tb = tables_plan(b->len, 1, b->len, (unsigned)C::FrP::BITS);
+    MsmTables tb = tables_plan(b->len, 1, b->len, (unsigned)C::FrP::BITS, (unsigned)ctx->opt.v[PM_OPT_TABLE_WINDOW_BITS]);
     if (!tb.c) return PM_OK;
     void *d_table = nullptr, *d_flags = nullptr;
     int st = PM_OK;
@@ -443,7 +497,7 @@ static int pk_init_layout(pm_ctx *ctx, pm_pk *pk, uint64_t m0, uint64_t mw, uint
         const pmlayout::Layout L = pmlayout::make_layout(n, (uint32_t)shard_count, (uint32_t)shard_rank);
         const pmlayout::KeyShape ks = pmlayout::key_shape(n, m0, mw, nr);
         pk->max_seg = pmlayout::pick_max_seg(n, (uint32_t)shard_count);
-        if (const char *e = getenv("PM_MAX_SEG_LOG")) pk->max_seg = (uint64_t)1 << atoi(e);   // test knob: many tiny sub-segments
+        if (ctx->opt.v[PM_OPT_MAX_SEG_LOG] > 0) pk->max_seg = (uint64_t)1 << ctx->opt.v[PM_OPT_MAX_SEG_LOG];   // test knob: many tiny sub-segments
         pk->segs = pmlayout::quotient_segments(n, (uint32_t)shard_count, (uint32_t)shard_rank, pk->max_seg);
         pk->seg_slots = 0;
         for (uint32_t r = 0; r < (uint32_t)shard_count; ++r) {
@@ -523,11 +577,6 @@ static int for_cat_range(const pm_pk *pk, uint64_t lo, uint64_t hi, Affine<C> *d
     return PM_OK;
 }
 
-static bool tables_disabled_by_env() {
-    const char *e = getenv("PM_TABLES");
-    return e && e[0] == '0';
-}
-
 // Allocates the resident base array and fills it through `fill`; then, when they fit (sized for 288 GB of
 // HBM), builds one set of window tables per merged MSM on the device.
 template <class C, class F>
@@ -547,7 +596,9 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
         }
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (tables_disabled_by_env()) return PM_OK;
+    const long long tmode = ctx->opt.v[PM_OPT_TABLES];
+    pk->max_piece = (uint64_t)msm_max_piece(ctx);
+    if (tmode == PM_TABLES_OFF) return PM_OK;
     // Budget: free HBM minus the per-proof vectors (~40 Fr per domain point; 26 are in use) and the MSM workspaces: 16 B
     // per (pair, window) entry of the sort's two ping-pong arrays and the sorted indices, 13-16 windows, plus the
     // bucket-side arrays -> 256 B per pair of one <= 2^27-pair piece, for the main context's largest MSM and for the
@@ -558,13 +609,12 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
     // PM_INFLIGHT_CONTEXTS: how many contexts will prove on this resident key at once (each owns the per-proof vectors
     // and an MSM workspace; default 1).  The helper context of the overlapped [a]_1 MSM (prove.hip) has a workspace of
     // its own as well.
-    int inflight = 1;
-    if (const char *e = getenv("PM_INFLIGHT_CONTEXTS")) inflight = atoi(e) > 1 ? atoi(e) : 1;
+    const int inflight = (int)ctx->opt.v[PM_OPT_INFLIGHT_CONTEXTS];
     const uint64_t vec_n = pk->layout == PM_SHARD_VECTOR ? pk->n / (uint64_t)pk->shard_count : pk->n;   // length of a rank's vectors
     double budget = 0.9 * (double)free_b - (double)inflight * 64.0 * 40.0 * (double)vec_n;
     {
         const uint64_t len_d = pk->res_cnt[2], len_a = pk->res_cnt[0];
-        budget -= (double)inflight * 256.0 * (double)(len_d < (uint64_t)msm_max_piece() ? len_d : (uint64_t)msm_max_piece());
+        budget -= (double)inflight * 256.0 * (double)(len_d < pk->max_piece ? len_d : pk->max_piece);
         budget -= (double)inflight * 256.0 * (double)len_a;
     }
     int order[3] = {0, 1, 2};
@@ -573,19 +623,17 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
         const int k = order[q];
         const uint64_t len = pk->res_cnt[k];
         if (!len) continue;
-        MsmTables tb = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS);
+        MsmTables tb = tables_plan((size_t)len, 1, (size_t)len, (unsigned)C::FrP::BITS, (unsigned)ctx->opt.v[PM_OPT_TABLE_WINDOW_BITS]);
         // no table plan at all (nwin x points would overflow the u32 table indices: the 335 M-pair [d]_1 of a 2^24-gate key) counts
         // as "does not fit"
         const double need = tb.c ? (double)len * tb.nwin * sizeof(TablePoint<C>) + (double)len : 1e300;
-        const char *te = getenv("PM_TABLES");
-        const bool force_wide = te && te[0] == 'w';          // PM_TABLES=wide: test / tuning knob -- no tables for any MSM, wide mode at any size
+        const bool force_wide = tmode == PM_TABLES_WIDE;      // test / tuning knob -- no tables for any MSM, wide mode at any size
         if (need > budget || force_wide) {
             // No room for this MSM's tables (the 10n-pair [d]_1 of a 2^24-gate key on one GPU: 515 GB): WIDE mode -- the same
             // sort / accumulate / reduce kernels on the plain base array, one bucket set per window, 13 additions per pair
-            // instead of the 16 of the one-shot pipeline.  Costs one infinity-flag byte per point.  PM_WIDE=0 disables.
-            const char *e = getenv("PM_WIDE");
-            const size_t piece = (size_t)(len < (uint64_t)msm_max_piece() ? len : (uint64_t)msm_max_piece());
-            MsmTables wt = (e && e[0] == '0') ? MsmTables() : wide_plan(piece);
+            // instead of the 16 of the one-shot pipeline.  Costs one infinity-flag byte per point.  PM_TABLES_NO_WIDE disables.
+            const size_t piece = (size_t)(len < pk->max_piece ? len : pk->max_piece);
+            MsmTables wt = tmode == PM_TABLES_NO_WIDE ? MsmTables() : wide_plan(piece);
             if (wt.c && (piece >= ((size_t)1 << 18) || force_wide) && (double)len < budget) {
                 budget -= (double)len;
                 PM_HIP(ctx, hipMalloc(&pk->d_tab_inf[k], len));
@@ -837,7 +885,7 @@ extern "C" int pm_pk_msm_plan(const pm_pk *pk, int which, uint64_t *pairs, unsig
         nwin = pk->tables[which].nwin;
         c = pk->tables[which].c;
     } else {
-        const uint64_t piece = len < (uint64_t)msm_max_piece() ? len : (uint64_t)msm_max_piece();
+        const uint64_t piece = len < pk->max_piece ? len : pk->max_piece;
         pm::msm_plan_query((size_t)piece, pk->curve == PM_BLS12_381 ? (unsigned)BlsFrP::BITS : (unsigned)BnFrP::BITS, &nwin, &c);
     }
     if (pairs) *pairs = len;

@@ -3,11 +3,30 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 #include <string>
 
 struct pm_comm {
     int rank = 0, world = 1;
+    // the first failure's message: written under err_mu BEFORE `failed` is published, read through error() -- a watchdog
+    // thread or a peer's abort may fail the communicator while the proving thread looks at it
+    mutable std::mutex err_mu;
     std::string err;
+    std::string error() const {
+        std::lock_guard<std::mutex> lk(err_mu);
+        return err;
+    }
+    void set_error(const std::string &m) {          // a message without failing the communicator (staging allocation, copies)
+        std::lock_guard<std::mutex> lk(err_mu);
+        err = m;
+    }
+    bool fail_once(const std::string &m) {          // true: this call failed the communicator
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (failed.load(std::memory_order_acquire)) return false;
+        err = m;
+        failed.store(true, std::memory_order_release);
+        return true;
+    }
     // Fail-fast contract (include/polymath_hip.h): a collective never waits longer than `timeout_ms` for its peers; a rank
     // whose phase fails for a reason its peers cannot know calls abort().  Either way `failed` becomes sticky and every
     // later collective of the communicator returns PM_ERR_COMM at once.
@@ -27,9 +46,7 @@ struct pm_comm {
     virtual int all_gather_device(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) = 0;
     // this rank gives up: wake / unblock whoever can be reached (local group: all peers at once; RCCL: ncclCommAbort here,
     // the peers run into their own deadline)
-    virtual void abort(const char *why) {
-        if (!failed.exchange(true)) err = why ? why : "aborted";
-    }
+    virtual void abort(const char *why) { (void)fail_once(why ? why : "aborted"); }
     // end of a prover phase: nothing to exchange until the host calls again (local serialised emulation: pass the turn on)
     virtual void phase_end() {}
     virtual void phase_begin() {}

@@ -47,14 +47,11 @@ struct LocalGroup {
     std::vector<void *> recv;
     std::atomic<bool> failed{false};   // sticky: once a rank failed a collective, every later one reports it
     std::string why;                   // first failure (guarded by mu)
-    // PM_LOCAL_COMM_SERIALIZE=1: between collectives only ONE rank runs at a time (a turnstile), so that N ranks emulated on
-    // one GPU do not time-slice it: each rank's kernels then take what they would take alone (bench.py's emulation).
+    // pm_comm_local_set_serialize: between collectives only ONE rank runs at a time (a turnstile), so that N ranks emulated on
+    // one GPU do not time-slice it: each rank's kernels then take what they would take alone (tools/shard_emulation.py).
     bool serialize = false;
     std::mutex turn;
-    explicit LocalGroup(int w) : world(w), send(w), recv(w) {
-        const char *e = getenv("PM_LOCAL_COMM_SERIALIZE");
-        serialize = e && e[0] == '1';
-    }
+    explicit LocalGroup(int w) : world(w), send(w), recv(w) {}
     // false: the group is dead (a peer aborted, or did not arrive within timeout_ms)
     bool barrier(long timeout_ms, int rank) {
         std::unique_lock<std::mutex> lk(mu);
@@ -116,7 +113,7 @@ struct LocalComm : pm_comm {
         dead();
     }
     int dead() {                                        // the group failed: this rank's view of it
-        if (!failed.exchange(true)) err = g->reason();
+        (void)fail_once(g->reason());
         return PM_ERR_COMM;
     }
     int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
@@ -223,7 +220,14 @@ struct RcclComm : pm_comm {
     static constexpr int RING = 32;
     hipEvent_t ring[RING] = {};
     int ring_next = 0;
-    struct Watch { hipEvent_t ev; std::chrono::steady_clock::time_point deadline; };
+    // Two events per collective: `start` in front of it, `ev` behind it.  The deadline runs from the moment `start` completes --
+    // the kernels a phase queued ahead of the collective (first-call twiddle tables, a large circuit's transforms) do not eat
+    // into it -- with a ceiling of UNARMED_FACTOR deadlines from the enqueue for a stream that never gets there.
+    struct Watch { hipEvent_t start, ev; unsigned long long seq; bool armed; std::chrono::steady_clock::time_point deadline; };
+    static constexpr int UNARMED_FACTOR = 8;
+    hipEvent_t ring_start[RING] = {};
+    unsigned long long seq_next = 1;
+    hipEvent_t begun = nullptr;        // start event of the collective being enqueued (watch_begin .. watch)
     std::deque<Watch> pending;
     std::mutex wmu;
     std::condition_variable wcv;
@@ -232,15 +236,14 @@ struct RcclComm : pm_comm {
     const char *kind() const override { return "rccl"; }
     int fail(const char *what, int rc) {
         RcclApi *a = rccl_api();
-        err = std::string(what) + ": " + (a->GetErrorString ? a->GetErrorString(rc) : "rccl error");
-        failed = true;
+        (void)fail_once(std::string(what) + ": " + (a->GetErrorString ? a->GetErrorString(rc) : "rccl error"));
         return PM_ERR_COMM;
     }
     int dead() { return PM_ERR_COMM; }
     void abort_comm(const std::string &why) {          // under wmu
         if (aborted) return;
         aborted = true;
-        if (!failed.exchange(true)) err = why;
+        (void)fail_once(why);
         fprintf(stderr, "[pm_comm rank %d] %s -- aborting the RCCL communicator\n", rank, why.c_str());
         if (comm && rccl_api()->CommAbort) rccl_api()->CommAbort(comm);
     }
@@ -257,13 +260,22 @@ struct RcclComm : pm_comm {
             const Watch w = pending.front();
             lk.unlock();
             const hipError_t q = hipEventQuery(w.ev);
+            const hipError_t qs = w.armed ? hipSuccess : hipEventQuery(w.start);
             int async = 0;
             if (rccl_api()->CommGetAsyncError && comm && !aborted) (void)rccl_api()->CommGetAsyncError(comm, &async);
             lk.lock();
             if (stop) return;
+            // the entry may have been re-armed (ring wrap) or dropped while the lock was released: decide on the CURRENT front
+            if (pending.empty() || pending.front().seq != w.seq) continue;
+            Watch &cur = pending.front();
             if (q == hipSuccess) {
-                if (!pending.empty() && pending.front().ev == w.ev) pending.pop_front();
+                pending.pop_front();
                 continue;
+            }
+            const auto now = std::chrono::steady_clock::now();
+            if (!cur.armed && qs == hipSuccess) {          // the collective is at the head of its stream: the clock starts now
+                cur.armed = true;
+                cur.deadline = now + std::chrono::milliseconds(timeout_ms);
             }
             if (async != 0) {
                 abort_comm(std::string("asynchronous RCCL error: ") + (rccl_api()->GetErrorString ? rccl_api()->GetErrorString(async) : "?"));
@@ -271,27 +283,37 @@ struct RcclComm : pm_comm {
             } else if (q != hipErrorNotReady) {
                 abort_comm("a collective's completion event failed (device error)");
                 pending.clear();
-            } else if (std::chrono::steady_clock::now() > w.deadline) {
-                abort_comm("a collective did not complete within " + std::to_string(timeout_ms) + " ms (peer dead or stalled)");
+            } else if (now > cur.deadline) {
+                abort_comm(cur.armed ? "a collective did not complete within " + std::to_string(timeout_ms) + " ms (peer dead or stalled)"
+                                     : "a collective was not reached by its stream within " + std::to_string((long long)timeout_ms * UNARMED_FACTOR) + " ms");
                 pending.clear();
             } else {
                 wcv.wait_for(lk, std::chrono::milliseconds(5));
             }
         }
     }
+    void watch_begin(hipStream_t stream) {               // in front of a collective about to be enqueued on `stream`
+        std::unique_lock<std::mutex> lk(wmu);
+        begun = ring_start[ring_next];
+        if (hipEventRecord(begun, stream) != hipSuccess) begun = nullptr;
+    }
     void watch(hipStream_t stream) {                     // behind a collective just enqueued on `stream`
         std::unique_lock<std::mutex> lk(wmu);
-        hipEvent_t ev = ring[ring_next];
+        hipEvent_t ev = ring[ring_next], start = begun;
+        begun = nullptr;
         ring_next = (ring_next + 1) % RING;
         for (auto it = pending.begin(); it != pending.end();)   // the ring wrapped: that entry is re-armed below
             it = it->ev == ev ? pending.erase(it) : it + 1;
         if (hipEventRecord(ev, stream) != hipSuccess) return;
-        pending.push_back(Watch{ev, std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms)});
+        const auto now = std::chrono::steady_clock::now();
+        if (start) pending.push_back(Watch{start, ev, seq_next++, false, now + std::chrono::milliseconds((long long)timeout_ms * UNARMED_FACTOR)});
+        else pending.push_back(Watch{ev, ev, seq_next++, true, now + std::chrono::milliseconds(timeout_ms)});
         wcv.notify_all();
     }
     int start() {
         for (int i = 0; i < RING; ++i)
-            if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess) return PM_ERR_HIP;
+            if (hipEventCreateWithFlags(&ring[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ring_start[i], hipEventDisableTiming) != hipSuccess) return PM_ERR_HIP;
         try {
             wd = std::thread([this] { watchdog(); });
         } catch (const std::system_error &) {
@@ -308,14 +330,17 @@ struct RcclComm : pm_comm {
         if (wd.joinable()) wd.join();
         (void)hipSetDevice(device);
         if (comm && !aborted) rccl_api()->CommDestroy(comm);
-        for (int i = 0; i < RING; ++i)
+        for (int i = 0; i < RING; ++i) {
             if (ring[i]) (void)hipEventDestroy(ring[i]);
+            if (ring_start[i]) (void)hipEventDestroy(ring_start[i]);
+        }
         if (d_stage) (void)hipFree(d_stage);
         if (h_stage) (void)hipHostFree(h_stage);
         if (side) (void)hipStreamDestroy(side);
     }
     int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
         if (failed) return dead();
+        watch_begin(stream);
         const int rc = rccl_api()->AllToAll(d_send, d_recv, bytes, NCCL_UINT8, comm, stream);
         if (rc) return fail("ncclAllToAll", rc);
         watch(stream);
@@ -323,6 +348,7 @@ struct RcclComm : pm_comm {
     }
     int all_gather_device(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
         if (failed) return dead();
+        watch_begin(stream);
         const int rc = rccl_api()->AllGather(d_send, d_recv, bytes, NCCL_UINT8, comm, stream);
         if (rc) return fail("ncclAllGather (device)", rc);
         watch(stream);
@@ -338,20 +364,21 @@ struct RcclComm : pm_comm {
             d_stage = h_stage = nullptr;
             stage_bytes = need < 65536 ? 65536 : need;
             if (hipMalloc(&d_stage, stage_bytes) != hipSuccess || hipHostMalloc(&h_stage, stage_bytes, hipHostMallocDefault) != hipSuccess) {
-                err = "all_gather staging allocation failed";
+                set_error("all_gather staging allocation failed");
                 stage_bytes = 0;
                 return PM_ERR_HIP;
             }
         }
         uint8_t *ds = (uint8_t *)d_stage, *dr = ds + bytes, *hs = (uint8_t *)h_stage, *hr = hs + bytes;
         memcpy(hs, send_h, bytes);
-        if (hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, side) != hipSuccess) { err = "all_gather H2D failed"; return PM_ERR_HIP; }
+        if (hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, side) != hipSuccess) { set_error("all_gather H2D failed"); return PM_ERR_HIP; }
+        watch_begin(side);
         const int rc = rccl_api()->AllGather(ds, dr, bytes, NCCL_UINT8, comm, side);
         if (rc) return fail("ncclAllGather", rc);
         watch(side);
         if (hipMemcpyAsync(hr, dr, bytes * (size_t)world, hipMemcpyDeviceToHost, side) != hipSuccess || hipStreamSynchronize(side) != hipSuccess) {
             if (failed) return dead();
-            err = "all_gather D2H failed";
+            set_error("all_gather D2H failed");
             return PM_ERR_HIP;
         }
         if (failed) return dead();                       // the watchdog ended the wait: the bytes are not the peers'
@@ -367,7 +394,7 @@ struct CallbackComm : pm_comm {
     pm_comm_ops ops;
     const char *kind() const override { return "callbacks"; }
     int done(int st, const char *what) {
-        if (st != PM_OK && !failed.exchange(true)) err = std::string(what) + " callback failed with status " + std::to_string(st);
+        if (st != PM_OK) (void)fail_once(std::string(what) + " callback failed with status " + std::to_string(st));
         return st == PM_OK ? (int)PM_OK : (int)PM_ERR_COMM;
     }
     int all_to_all(const void *d_send, void *d_recv, size_t bytes, hipStream_t stream) override {
@@ -389,12 +416,12 @@ struct CallbackComm : pm_comm {
             if (d_rep) (void)hipFree(d_rep);
             d_rep = nullptr;
             rep_bytes = 0;
-            if (hipMalloc(&d_rep, need) != hipSuccess) { err = "all_gather_device staging allocation failed"; return PM_ERR_HIP; }
+            if (hipMalloc(&d_rep, need) != hipSuccess) { set_error("all_gather_device staging allocation failed"); return PM_ERR_HIP; }
             rep_bytes = need;
         }
         for (int p = 0; p < world; ++p)
             if (hipMemcpyAsync((uint8_t *)d_rep + (size_t)p * bytes, d_send, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
-                err = "all_gather_device replicate failed";
+                set_error("all_gather_device replicate failed");
                 return PM_ERR_HIP;
             }
         return all_to_all(d_rep, d_recv, bytes, stream);
@@ -471,7 +498,20 @@ extern "C" double pm_comm_busy_ms(pm_comm *c, int reset) {
     if (reset) c->busy_ms = 0.0;
     return v;
 }
-extern "C" const char *pm_comm_last_error(const pm_comm *c) { return c ? c->err.c_str() : "null comm"; }
+extern "C" const char *pm_comm_last_error(const pm_comm *c) {
+    if (!c) return "null comm";
+    static thread_local std::string copy;    // taken under the communicator's lock: the watchdog may be writing the original
+    copy = c->error();
+    return copy.c_str();
+}
+extern "C" int pm_comm_local_set_serialize(pm_comm *c, int on) {
+    LocalComm *l = dynamic_cast<LocalComm *>(c);
+    if (!l) return PM_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lk(l->g->mu);
+    if (l->g->generation != 0 || l->holds_turn) return PM_ERR_STATE;   // before the group's first collective only
+    l->g->serialize = on != 0;
+    return PM_OK;
+}
 extern "C" const char *pm_comm_kind(const pm_comm *c) { return c ? c->kind() : "none"; }
 extern "C" int pm_comm_set_timeout_ms(pm_comm *c, long timeout_ms) {
     if (!c || timeout_ms <= 0) return PM_ERR_INVALID_ARG;

@@ -82,8 +82,18 @@ enum TimingSlot {
     T_NUM_SLOTS = 8
 };
 
+// What one bucket pipeline hands from its sort to its accumulation and from there to the reduction.  The table pipeline can sort an
+// MSM's pairs in CHUNKS (PM_OPT_MSM_CHUNKS; msm.hip: msm_piece_tables): chunk k + 1 is sorted on `sort_stream` while chunk k
+// accumulates, and chunk k + 1's tasks continue from chunk k's partials -- three slots in rotation.  Slot 0 serves every other path.
+struct MsmSet {
+    DevBuf sorted, counts, bucket_off, task_off, order, partials, task_cnt;
+};
+constexpr int MSM_SETS = 3;
 struct MsmWorkspace {
-    DevBuf digits, sorted, counts, bucket_off, task_off, cursor, partials, wsum, region, sub, digits2, order, len_bins, block_cnt, task_cnt, hot;
+    MsmSet set[MSM_SETS];
+    DevBuf digits, cursor, wsum, region, sub, digits2, len_bins, block_cnt, hot;
+    hipStream_t sort_stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_sorted[MSM_SETS] = {nullptr, nullptr, nullptr}, ev_acc[MSM_SETS] = {nullptr, nullptr, nullptr};
 };
 
 // Window tables of a resident base vector (setup.hip: tables_build): point (w, i) = 2^(c w) P_i lives at
@@ -159,6 +169,7 @@ struct pm_pk {
     uint64_t res_cnt[3];
     std::vector<pmlayout::Segment> segs;
     uint64_t max_seg;
+    uint64_t max_piece = (uint64_t)1 << 27;   // msm_max_piece of the creating context (pm_pk_msm_plan reports plans without a context)
     struct SegRef { uint64_t a, b; uint32_t rank, idx; };
     std::vector<SegRef> all_segs;    // the segments of ALL ranks in increasing index order (the carry chain of the division scan)
     size_t seg_slots;                // max over ranks of the segment count
@@ -222,6 +233,11 @@ struct pm_worker {
     }
 };
 
+// pm_option values of a context (include/polymath_hip.h); defaults and their environment names in api.hip: options_defaults
+struct pm_options {
+    long long v[PM_NUM_OPTIONS];
+};
+
 struct PendingTimer {
     int slot;
     hipEvent_t a, b;
@@ -229,6 +245,7 @@ struct PendingTimer {
 
 struct pm_ctx {
     int device;
+    pm_options opt;           // pm_ctx_set_option; the helper context `aux` carries a copy
     std::vector<PendingTimer> pending_timers;
     std::vector<hipEvent_t> event_pool;   // recycled stage-timer events: ~50 create / destroy pairs per proof are 0.2 ms of host time
     hipStream_t stream;
@@ -320,20 +337,19 @@ int msm_resident_end(pm_ctx *ctx, uint64_t *out_xy, int *out_inf);
 // msm_reduce.hip: the bucket reduction of the table-mode MSM (one set of NB >= 4096 buckets whose task partials sit in ctx->msm),
 // three launches on ctx->stream; *out = the sum sum_b (b + 1) B_b, internal form, inside the workspace.
 template <class C>
-int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets = 1);
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets = 1, const MsmSet *S = nullptr /* default: slot 0 */);
 
 // One bucket pipeline covers at most this many pairs (sorted-entry positions are u32: windows x pairs < 2^32); longer
-// MSMs run in pieces summed on the host.  2^27 in production; PM_MSM_MAX_PIECE_LOG (developer / test knob) lowers it
+// MSMs run in pieces summed on the host.  2^27 in production; PM_OPT_MSM_MAX_PIECE_LOG (developer / test knob) lowers it
 // so that the piece-split path can be exercised at small sizes.
-inline size_t msm_max_piece() {
-    const char *e = getenv("PM_MSM_MAX_PIECE_LOG");   // read per call: tests toggle it inside one process
-    const int lg = e ? atoi(e) : 27;
+inline size_t msm_max_piece(const pm_ctx *ctx) {
+    const long long lg = ctx->opt.v[PM_OPT_MSM_MAX_PIECE_LOG];
     return (size_t)1 << (lg < 4 ? 4 : lg > 27 ? 27 : lg);
 }
 
 // choose c and the number of windows for a key whose longest MSM has `max_len` pairs
 void msm_plan_query(size_t len, unsigned scalar_bits, unsigned *nwin, unsigned *c);
-MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits);
+MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits, unsigned force_c = 0);
 // the plan of an MSM that gets no tables (MsmTables::wide); c == 0 if none applies (short MSMs: the per-window pipeline)
 MsmTables wide_plan(size_t piece);
 // window 0 of d_table <- the `count` internal-form affine points at d_points; then windows 1..nwin-1
@@ -382,6 +398,14 @@ template <class C>
 int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1, const uint64_t *x2, const uint64_t *a_at_x1, const uint64_t *c_at_x1, uint64_t *d_xy,
                          int *d_inf);
 
+// The helper context of `ctx` (own stream, own MSM workspace), created on first use with a copy of ctx's options; nullptr if it
+// cannot be created (the callers then run their two jobs back to back).
+inline pm_ctx *ctx_aux(pm_ctx *ctx) {
+    if (!ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
+    if (ctx->aux) ctx->aux->opt = ctx->opt;
+    return ctx->aux;
+}
+
 inline void timing_reset(pm_ctx *ctx) {
     for (int i = 0; i < T_NUM_SLOTS; ++i) ctx->timing_ms[i] = 0;
 }
@@ -398,16 +422,17 @@ struct StageTimer {
         if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); return true; }
         return hipEventCreate(e) == hipSuccess;
     }
-    StageTimer(pm_ctx *c, int s) : ctx(c), slot(s), ok(false) {
+    hipStream_t stream;
+    StageTimer(pm_ctx *c, int s, hipStream_t on = nullptr) : ctx(c), slot(s), ok(false), stream(on ? on : c->stream) {
         if (!take(c, &a)) return;
         if (!take(c, &b)) { c->event_pool.push_back(a); return; }
-        ok = hipEventRecord(a, ctx->stream) == hipSuccess;
+        ok = hipEventRecord(a, stream) == hipSuccess;
         if (!ok) { c->event_pool.push_back(a); c->event_pool.push_back(b); }
     }
     void stop() {
         if (!ok) return;
         ok = false;
-        (void)hipEventRecord(b, ctx->stream);
+        (void)hipEventRecord(b, stream);
         ctx->pending_timers.push_back(PendingTimer{slot, a, b});
     }
     ~StageTimer() { stop(); }

@@ -43,7 +43,7 @@ struct MsmPlan {
     size_t max_tasks;
 };
 
-static MsmPlan make_plan(size_t len, unsigned scalar_bits) {
+static MsmPlan make_plan(size_t len, unsigned scalar_bits, unsigned task_len = 0) {
     MsmPlan p;
     p.len = len;
     // choose c minimising  W(c) * (len + 6 * 2^(c-1))   (6 ~ cost of the reduce per bucket in madds)
@@ -64,13 +64,7 @@ static MsmPlan make_plan(size_t len, unsigned scalar_bits) {
     p.chunk = 1u << 15;   // scalars per (chunk, window) histogram / scatter workgroup (tools/msm_bench.py sweep)
     if (len < p.chunk) p.chunk = (unsigned)(len ? len : 1);
     p.nchunks = (unsigned)((len + p.chunk - 1) / p.chunk);
-    // developer knobs for tuning sweeps (tools/msm_bench.py); unset in production
-    if (const char *e = getenv("PM_MSM_CHUNK_LOG")) {
-        p.chunk = 1u << atoi(e);
-        if (len < p.chunk) p.chunk = (unsigned)(len ? len : 1);
-        p.nchunks = (unsigned)((len + p.chunk - 1) / p.chunk);
-    }
-    if (const char *e = getenv("PM_MSM_SEG")) p.seg = (unsigned)atoi(e);
+    if (task_len) p.seg = task_len;   // PM_OPT_MSM_TASK_LEN (tuning sweeps)
     p.max_tasks = (size_t)p.nwin * p.nbuckets + ((size_t)p.nwin * len) / p.seg + 1;
     return p;
 }
@@ -150,18 +144,22 @@ __global__ __launch_bounds__(1024) void k_hist(const uint32_t *digits, uint32_t 
 // (+ totals at index G).  A lane owns SCAN_PER contiguous counters (64 B), a workgroup SCAN_TILE.
 constexpr unsigned SCAN_PER = 16, SCAN_TILE = 256 * SCAN_PER;
 
+// prev_task_off != nullptr (a later chunk of a chunked MSM, msm_piece_tables): a bucket that had a task in the PREVIOUS chunk gets at
+// least one task here even without entries, so that its partial sum is carried forward from chunk to chunk (k_accumulate: `prev`).
 __global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *counts, uint32_t *bucket_off, uint32_t *task_off,
-                                                    uint32_t *tile_tot, size_t G, unsigned seg) {
+                                                    uint32_t *tile_tot, size_t G, unsigned seg, const uint32_t *prev_task_off) {
     __shared__ uint32_t s_a[256], s_b[256];
     const unsigned tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)tid * SCAN_PER;
-    uint32_t c[SCAN_PER];
+    uint32_t c[SCAN_PER], nt[SCAN_PER];
     uint32_t sa = 0, sb = 0;
 #pragma unroll
     for (unsigned k = 0; k < SCAN_PER; ++k) {
         c[k] = base + k < G ? counts[base + k] : 0u;
+        nt[k] = (c[k] + seg - 1) / seg;
+        if (prev_task_off && base + k < G && nt[k] == 0 && prev_task_off[base + k + 1] != prev_task_off[base + k]) nt[k] = 1;
         sa += c[k];
-        sb += (c[k] + seg - 1) / seg;
+        sb += nt[k];
     }
     s_a[tid] = sa;
     s_b[tid] = sb;
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *counts, uint
     for (unsigned k = 0; k < SCAN_PER; ++k) {
         if (base + k < G) { bucket_off[base + k] = ra; task_off[base + k] = rb; }
         ra += c[k];
-        rb += (c[k] + seg - 1) / seg;
+        rb += nt[k];
     }
     if (tid == 255) { tile_tot[2 * blockIdx.x] = s_a[255]; tile_tot[2 * blockIdx.x + 1] = s_b[255]; }
 }
@@ -275,7 +273,8 @@ __global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, cons
         t0 = task_off[g];
         n = task_off[g + 1] - t0;
         if (n) {
-            const uint32_t L = counts[g] - (n - 1) * seg;           // 1 .. seg
+            uint32_t L = counts[g] - (n - 1) * seg;                 // 1 .. seg (0: a chunked MSM's carried-forward task without entries)
+            if (L == 0) L = 1;
             bin = (seg - L) >> lshift;
             if (n > 1) rank_full = atomicAdd(&h[0], n - 1);
             rank_last = atomicAdd(&h[bin], 1u);
@@ -306,11 +305,15 @@ __global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, cons
 // dense affine array of the per-window pipeline).  The accumulator lives in reduced-radix registers (fq28.cuh): 10 carry-free
 // Montgomery products and 7 lazy add/sub per mixed add.  `bases` are in INTERNAL Montgomery form.
 // The exceptional case acc == +-point (doubling / cancellation) is resolved on the dense path.
+// prev_* (a later chunk of a chunked MSM): the first task of bucket g starts from the bucket's partial sum of the previous chunk
+// instead of zero -- ONE record: the previous chunk's fold (fold_hot_buckets with fold_min = 1) has summed the tasks of every bucket
+// that was longer than the task length there.
 template <class C, bool TABLE>
 __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, const uint32_t *counts,
                                                     const uint32_t *bucket_off, const uint32_t *task_off,
                                                     const uint32_t *order, const void *points, XYZZ<C> *partials, size_t G,
-                                                    unsigned seg) {
+                                                    unsigned seg, const XYZZ<C> *prev_partials, const uint32_t *prev_task_off,
+                                                    const uint32_t *prev_task_cnt) {
     typedef typename C::FqRR RR;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = task_off[G];
@@ -329,6 +332,10 @@ __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, cons
     if (start + seg < end) end = start + seg;
     XYZZ28<C> acc;
     acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
+    if (prev_partials && k == 0) {
+        const uint32_t q0 = prev_task_off[g], qn = prev_task_cnt[g];
+        if (qn) acc = xyzz28_load<C>(prev_partials[q0]);
+    }
     for (uint32_t e = start; e < end; ++e) {
         const uint32_t v = sorted[e];
         const bool neg = (v & 1u) != 0;
@@ -377,7 +384,7 @@ __device__ __forceinline__ void lds_tree_sum(XYZZ28<C> *sh) {
 constexpr uint32_t FOLD_MIN = 8, FOLD_BLOCK_MIN = 1024;
 
 __global__ void k_task_counts(const uint32_t *task_off, size_t G, uint32_t *task_cnt, uint32_t *hot_a, uint32_t *hot_b,
-                              uint32_t *hot_counts /*[2], zeroed*/, uint32_t cap) {
+                              uint32_t *hot_counts /*[2], zeroed*/, uint32_t cap, uint32_t fold_min) {
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     const uint32_t n = task_off[g + 1] - task_off[g];
@@ -385,7 +392,7 @@ __global__ void k_task_counts(const uint32_t *task_off, size_t G, uint32_t *task
     if (n > FOLD_BLOCK_MIN) {
         const uint32_t i = atomicAdd(&hot_counts[0], 1u);
         if (i < cap) hot_a[i] = (uint32_t)g;   // an unlisted bucket keeps its sequential sum
-    } else if (n > FOLD_MIN) {
+    } else if (n > fold_min) {
         const uint32_t i = atomicAdd(&hot_counts[1], 1u);
         if (i < cap) hot_b[i] = (uint32_t)g;
     }
@@ -982,45 +989,47 @@ static void host_finish(const XYZZ<C> *S /*[nwin], internal form*/, unsigned nwi
 
 // effective task counts for the reduction + parallel fold of hot buckets (k_task_counts / k_task_fold);
 // enqueued after k_accumulate, before the bucket reduction
+// fold_min = FOLD_MIN before a reduction (its lanes add up to FOLD_MIN partials of a bucket themselves); 1 between the chunks of a
+// chunked MSM: EVERY bucket with more than one task is folded, the next chunk continues from one record per bucket.
 template <class C>
-static int fold_hot_buckets(pm_ctx *ctx, size_t G, size_t max_tasks) {
+static int fold_hot_buckets(pm_ctx *ctx, MsmSet &S, size_t G, size_t max_tasks, uint32_t fold_min = FOLD_MIN) {
     MsmWorkspace &ws = ctx->msm;
-    size_t cap = max_tasks > G ? max_tasks - G + 1 : 1;          // a listed bucket has > FOLD_MIN tasks
-    cap = cap / FOLD_MIN + 1;
-    PM_HIP(ctx, ws.task_cnt.reserve(G * 4));
+    size_t cap = max_tasks > G ? max_tasks - G + 1 : 1;          // a listed bucket has > fold_min tasks: at most (tasks - buckets) / fold_min
+    cap = cap / fold_min + 1;
+    PM_HIP(ctx, S.task_cnt.reserve(G * 4));
     PM_HIP(ctx, ws.hot.reserve((2 * cap + 2) * 4));
     uint32_t *hot_counts = ws.hot.as<uint32_t>(), *hot_a = hot_counts + 2, *hot_b = hot_a + cap;
     PM_HIP(ctx, hipMemsetAsync(hot_counts, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_task_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx->stream, ws.task_off.as<uint32_t>(), G,
-                       ws.task_cnt.as<uint32_t>(), hot_a, hot_b, hot_counts, (uint32_t)cap);
+    hipLaunchKernelGGL(k_task_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx->stream, S.task_off.as<uint32_t>(), G,
+                       S.task_cnt.as<uint32_t>(), hot_a, hot_b, hot_counts, (uint32_t)cap, fold_min);
     PM_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL((k_task_fold<C, 256>), dim3(256), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, ws.partials.as<XYZZ<C>>(),
-                       ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), hot_a, hot_counts, (uint32_t)cap);
+    hipLaunchKernelGGL((k_task_fold<C, 256>), dim3(256), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, S.partials.as<XYZZ<C>>(),
+                       S.task_off.as<uint32_t>(), S.task_cnt.as<uint32_t>(), hot_a, hot_counts, (uint32_t)cap);
     PM_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL((k_task_fold<C, 64>), dim3(1024), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, ws.partials.as<XYZZ<C>>(),
-                       ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), hot_b, hot_counts + 1, (uint32_t)cap);
+    hipLaunchKernelGGL((k_task_fold<C, 64>), dim3(1024), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, S.partials.as<XYZZ<C>>(),
+                       S.task_off.as<uint32_t>(), S.task_cnt.as<uint32_t>(), hot_b, hot_counts + 1, (uint32_t)cap);
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
 }
 
-// order[] for k_accumulate (see k_task_bins); enqueued on the context's stream after the bucket scan.
-static int task_order(pm_ctx *ctx, const uint32_t *counts, size_t G, size_t seg, size_t max_tasks) {
+// order[] for k_accumulate (see k_task_bins); enqueued on `st` (the stream of the sort) after the bucket scan.
+static int task_order(pm_ctx *ctx, hipStream_t st, MsmSet &S, const uint32_t *counts, size_t G, size_t seg, size_t max_tasks) {
     MsmWorkspace &ws = ctx->msm;
     unsigned lshift = 0;
     while (((seg - 1) >> lshift) + 1 > TASK_MAX_BINS) ++lshift;
     const unsigned nbins = (unsigned)(((seg - 1) >> lshift) + 1);
-    PM_HIP(ctx, ws.order.reserve(max_tasks * 4));
+    PM_HIP(ctx, S.order.reserve(max_tasks * 4));
     PM_HIP(ctx, ws.len_bins.reserve((3 * (size_t)nbins + 4) * 4));
     uint32_t *len_cnt = ws.len_bins.as<uint32_t>(), *len_off = len_cnt + nbins, *len_cursor = len_off + nbins + 1;
-    PM_HIP(ctx, hipMemsetAsync(len_cnt, 0, (size_t)nbins * 4, ctx->stream));
+    PM_HIP(ctx, hipMemsetAsync(len_cnt, 0, (size_t)nbins * 4, st));
     const unsigned blocks = (unsigned)((G + 1023) / 1024);      // one lane per bucket
-    hipLaunchKernelGGL(k_task_bins<false>, dim3(blocks), dim3(1024), nbins * 4, ctx->stream, counts, ws.task_off.as<uint32_t>(), G,
+    hipLaunchKernelGGL(k_task_bins<false>, dim3(blocks), dim3(1024), nbins * 4, st, counts, S.task_off.as<uint32_t>(), G,
                        (unsigned)seg, lshift, nbins, len_cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     PM_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, len_cnt, len_off, len_cursor, nbins);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, len_cnt, len_off, len_cursor, nbins);
     PM_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_task_bins<true>, dim3(blocks), dim3(1024), nbins * 4, ctx->stream, counts, ws.task_off.as<uint32_t>(), G,
-                       (unsigned)seg, lshift, nbins, (uint32_t *)nullptr, len_off, len_cursor, ws.order.as<uint32_t>());
+    hipLaunchKernelGGL(k_task_bins<true>, dim3(blocks), dim3(1024), nbins * 4, st, counts, S.task_off.as<uint32_t>(), G,
+                       (unsigned)seg, lshift, nbins, (uint32_t *)nullptr, len_off, len_cursor, S.order.as<uint32_t>());
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
 }
@@ -1033,22 +1042,23 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
                      int *h_inf) {
     typedef typename C::FrP FrP;
     StageTimer t_total(ctx, T_MSM_TOTAL);
-    MsmPlan p = make_plan(len, (unsigned)FrP::BITS);
+    MsmPlan p = make_plan(len, (unsigned)FrP::BITS, (unsigned)ctx->opt.v[PM_OPT_MSM_TASK_LEN]);
     MsmWorkspace &ws = ctx->msm;
+    MsmSet &S = ws.set[0];
     const size_t G = (size_t)p.nwin * p.nbuckets;
     PM_HIP(ctx, ws.digits.reserve((size_t)p.nwin * len * 4));
-    PM_HIP(ctx, ws.sorted.reserve((size_t)p.nwin * len * 4));
-    PM_HIP(ctx, ws.counts.reserve(2 * G * 4));  // counts | cursor, one memset
-    PM_HIP(ctx, ws.bucket_off.reserve((G + 1) * 4));
-    PM_HIP(ctx, ws.task_off.reserve((G + 1) * 4));
+    PM_HIP(ctx, S.sorted.reserve((size_t)p.nwin * len * 4));
+    PM_HIP(ctx, S.counts.reserve(2 * G * 4));  // counts | cursor, one memset
+    PM_HIP(ctx, S.bucket_off.reserve((G + 1) * 4));
+    PM_HIP(ctx, S.task_off.reserve((G + 1) * 4));
     PM_HIP(ctx, ws.cursor.reserve(((G + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));  // scan tile totals
-    PM_HIP(ctx, ws.partials.reserve(p.max_tasks * sizeof(XYZZ<C>)));
+    PM_HIP(ctx, S.partials.reserve(p.max_tasks * sizeof(XYZZ<C>)));
     const unsigned red_lanes = (p.nbuckets + RED_K - 1) / RED_K;      // lanes per window
     unsigned red_block = 64;
     while (red_block < red_lanes && red_block < 256) red_block <<= 1;
     const unsigned bpw = (red_lanes + red_block - 1) / red_block;
     PM_HIP(ctx, ws.wsum.reserve(((size_t)p.nwin * bpw + p.nwin) * sizeof(XYZZ<C>)));
-    uint32_t *counts = ws.counts.as<uint32_t>(), *cursor = counts + G;
+    uint32_t *counts = S.counts.as<uint32_t>(), *cursor = counts + G;
     {
         StageTimer t(ctx, T_MSM_SORT);
         PM_HIP(ctx, hipMemsetAsync(counts, 0, 2 * G * 4, ctx->stream));
@@ -1064,35 +1074,35 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
                            len, p.chunk, p.nbuckets);
         PM_HIP(ctx, hipGetLastError());
         const unsigned ntiles = (unsigned)((G + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, counts, ws.bucket_off.as<uint32_t>(),
-                           ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), G, p.seg);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, counts, S.bucket_off.as<uint32_t>(),
+                           S.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), G, p.seg, (const uint32_t *)nullptr);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, ws.cursor.as<uint32_t>(), ntiles,
-                           ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), G);
+                           S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), G);
         PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, ctx->stream, ws.bucket_off.as<uint32_t>(),
-                           ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), G);
+        hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, ctx->stream, S.bucket_off.as<uint32_t>(),
+                           S.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), G);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_scatter, dim3(p.nchunks, p.nwin), dim3(1024), lds, ctx->stream, ws.digits.as<uint32_t>(),
-                           ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>(), len, p.chunk, p.nbuckets);
+                           S.bucket_off.as<uint32_t>(), cursor, S.sorted.as<uint32_t>(), len, p.chunk, p.nbuckets);
         PM_HIP(ctx, hipGetLastError());
-        PM_TRY(task_order(ctx, counts, G, p.seg, p.max_tasks));
+        PM_TRY(task_order(ctx, ctx->stream, S, counts, G, p.seg, p.max_tasks));
     }
     {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
         size_t blocks = (p.max_tasks + 127) / 128;
-        hipLaunchKernelGGL((k_accumulate<C, false>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(),
-                           counts, ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), (const void *)d_bases,
-                           ws.partials.as<XYZZ<C>>(), G, p.seg);
+        hipLaunchKernelGGL((k_accumulate<C, false>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, S.sorted.as<uint32_t>(),
+                           counts, S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), S.order.as<uint32_t>(), (const void *)d_bases,
+                           S.partials.as<XYZZ<C>>(), G, p.seg, (const XYZZ<C> *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
         PM_HIP(ctx, hipGetLastError());
     }
     std::vector<XYZZ<C>> hS(p.nwin);
     {
         StageTimer t(ctx, T_MSM_REDUCE);
-        PM_TRY(fold_hot_buckets<C>(ctx, G, p.max_tasks));
+        PM_TRY(fold_hot_buckets<C>(ctx, S, G, p.max_tasks));
         XYZZ<C> *parts = ws.wsum.as<XYZZ<C>>(), *dS = parts + (size_t)p.nwin * bpw;
         hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(p.nwin * bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
-                           ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), p.nbuckets, red_lanes, bpw, parts);
+                           S.partials.as<XYZZ<C>>(), S.task_off.as<uint32_t>(), S.task_cnt.as<uint32_t>(), p.nbuckets, red_lanes, bpw, parts);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_sum_parts<C>, dim3(p.nwin), dim3(64), 0, ctx->stream, parts, bpw, dS);
         PM_HIP(ctx, hipGetLastError());
@@ -1108,6 +1118,33 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
 // bucket set and the window sums are combined on the host.  Otherwise the window tables of tb.
 // async_res != nullptr (table mode only): everything is ENQUEUED on ctx->stream, the reduced point (internal form) is copied to
 // *async_res -- pinned host memory -- and the call returns without waiting; the caller synchronises and finishes (msm_end).
+//
+// CHUNKS (PM_OPT_MSM_CHUNKS, round 4).  The sort is memory-bound, the accumulation ALU-bound, and an MSM that
+// runs alone -- the quotient commitment [d]_1 (prover.rs:229): 71 % of a proof's pairs -- pays for its sort in full before its
+// first point addition (3.2 ms of 41 at 2^20 gates).  With K chunks the pairs are sorted in K slices into the SAME bucket set:
+// chunk k + 1's sort runs on `sort_stream` under chunk k's accumulation, and chunk k + 1's first task of a bucket starts from the
+// bucket's partial sum of chunk k (k_accumulate: prev_*), so the reduction still sees one record per bucket -- no second bucket set
+// to reduce (what PM_MSM_SPLIT_D cost in round 3).  A bucket without entries in a chunk keeps a task there that only carries its
+// sum forward (k_scan_tiles: prev_task_off).  Price: one real addition per bucket and later chunk where the first entry used to be
+// a copy.  Three slots rotate: the accumulation of chunk k reads slots k and k - 1 while the sort of chunk k + 1 fills slot k + 1.
+constexpr size_t MSM_CHUNK_MIN_PAIRS = (size_t)1 << 20;    // shorter MSMs: one sort (their sort front end is launch-bound)
+
+static int chunk_streams(pm_ctx *ctx) {
+    MsmWorkspace &ws = ctx->msm;
+    if (ws.sort_stream) return PM_OK;
+    {
+        int lo_p = 0, hi_p = 0;     // (greatest numeric priority, least numeric priority) = (lowest, highest)
+        PM_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+        PM_HIP(ctx, hipStreamCreateWithPriority(&ws.sort_stream, hipStreamNonBlocking, hi_p));
+    }
+    PM_HIP(ctx, hipEventCreateWithFlags(&ws.ev_begin, hipEventDisableTiming));
+    for (int k = 0; k < MSM_SETS; ++k) {
+        PM_HIP(ctx, hipEventCreateWithFlags(&ws.ev_sorted[k], hipEventDisableTiming));
+        PM_HIP(ctx, hipEventCreateWithFlags(&ws.ev_acc[k], hipEventDisableTiming));
+    }
+    return PM_OK;
+}
+
 template <class C>
 static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename C::FrP> *d_scalars,
                             size_t len, Affine<C> *h_out, int *h_inf, const Affine<C> *plain = nullptr, XYZZ<C> *async_res = nullptr) {
@@ -1123,60 +1160,85 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     const unsigned lo_buckets = (unsigned)(NB < ((size_t)1 << LO_BITS) ? NB : ((size_t)1 << LO_BITS));
     const unsigned regions = (unsigned)(NB / lo_buckets);
     if (regions > 1024 || (size_t)regions * lo_buckets != NB) return PM_ERR_INVALID_ARG;   // whole regions only (wide mode: nwin 2^(c-1) buckets)
-    const size_t Emax = (size_t)nwin * len;
+    for (unsigned w = 0; w < nwin; ++w)   // the kernels derive the layout from nwin alone
+        if (tb.off[w] != win_off(nwin, w) || tb.width[w] != win_width(nwin, w)) return PM_ERR_INVALID_ARG;
+    const bool two_level = NB1 >= 4096;                // msm_reduce.hip: k_reduce_level0 / level1 / final
+    if (wide && !two_level) return PM_ERR_INVALID_ARG;  // wide plans have c >= 16 (setup.hip: wide_plan)
+    // chunks of pairs: [len k / K, len (k + 1) / K)
+    unsigned K = 1;
+    if (!wide && len >= MSM_CHUNK_MIN_PAIRS) K = (unsigned)ctx->opt.v[PM_OPT_MSM_CHUNKS];
+    if (K < 1) K = 1;
+    if (K > 1) PM_TRY(chunk_streams(ctx));
+    const size_t len_max = (len + K - 1) / K;              // the longest chunk
+    const size_t Emax = (size_t)nwin * len_max;            // entries of one chunk
     size_t seg = 2 * (Emax / NB + 1);
     if (seg < 64) seg = 64;
-    if (const char *e = getenv("PM_MSM_SEG")) seg = (size_t)atoi(e);
+    if (ctx->opt.v[PM_OPT_MSM_TASK_LEN] > 0) seg = (size_t)ctx->opt.v[PM_OPT_MSM_TASK_LEN];
     const size_t max_tasks = NB + Emax / seg + 1;
     const unsigned chunk = 1u << RS_CHUNK_LOG;
     const size_t keys_bytes = (Emax * 2 + 15) & ~(size_t)15;
     PM_HIP(ctx, ws.digits.reserve(keys_bytes + Emax * 4));
-    PM_HIP(ctx, ws.sorted.reserve(Emax * 4));
-    PM_HIP(ctx, ws.counts.reserve(2 * NB * 4));
     PM_HIP(ctx, ws.region.reserve((3 * (size_t)regions + 4) * 4));
-    PM_HIP(ctx, ws.bucket_off.reserve((NB + 1) * 4));
-    PM_HIP(ctx, ws.task_off.reserve((NB + 1) * 4));
     PM_HIP(ctx, ws.cursor.reserve(((NB + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
-    PM_HIP(ctx, ws.partials.reserve(max_tasks * sizeof(XYZZ<C>)));
-    const bool two_level = NB1 >= 4096;                // msm_reduce.hip: k_reduce_level0 / level1 / final
-    if (wide && !two_level) return PM_ERR_INVALID_ARG;  // wide plans have c >= 16 (setup.hip: wide_plan)
+    const int nslots = K == 1 ? 1 : (K == 2 ? 2 : MSM_SETS);
+    for (int q = 0; q < nslots; ++q) {
+        MsmSet &S = ws.set[q];
+        PM_HIP(ctx, S.sorted.reserve(Emax * 4));
+        PM_HIP(ctx, S.counts.reserve(2 * NB * 4));
+        PM_HIP(ctx, S.bucket_off.reserve((NB + 1) * 4));
+        PM_HIP(ctx, S.task_off.reserve((NB + 1) * 4));
+        PM_HIP(ctx, S.partials.reserve(max_tasks * sizeof(XYZZ<C>)));
+        PM_HIP(ctx, S.task_cnt.reserve(NB * 4));
+    }
     const unsigned red_lanes = (unsigned)((NB + RED_K - 1) / RED_K);              // single-level path (small NB)
     unsigned red_block = 64;
     while (red_block < red_lanes && red_block < 256) red_block <<= 1;
     const unsigned bpw = (red_lanes + red_block - 1) / red_block;
     if (!two_level) PM_HIP(ctx, ws.wsum.reserve(((size_t)bpw + 4) * sizeof(XYZZ<C>)));
-    const unsigned char *inf = tb.inf + tb.base_index;
     uint16_t *keys = (uint16_t *)ws.digits.p;
     uint32_t *vals = (uint32_t *)((uint8_t *)ws.digits.p + keys_bytes);
-    uint32_t *counts = ws.counts.as<uint32_t>(), *cursor = counts + NB;
     uint32_t *region_count = ws.region.as<uint32_t>(), *region_off = region_count + regions, *region_cursor = region_off + regions + 1;
+    const unsigned pbd = nwin <= 16 ? 512 : 256;                       // scalars per partition workgroup
+    if (regions > pbd) return PM_ERR_INVALID_ARG;                      // one scan lane per region
+    const size_t plds = 2 * 1024 * 4 + (size_t)pbd * nwin * 8;
     {
-        StageTimer t(ctx, T_MSM_SORT);
-        PM_HIP(ctx, hipMemsetAsync(counts, 0, 2 * NB * 4, ctx->stream));
-        PM_HIP(ctx, hipMemsetAsync(region_count, 0, (size_t)regions * 4, ctx->stream));
-        for (unsigned w = 0; w < nwin; ++w)   // the kernels derive the layout from nwin alone
-            if (tb.off[w] != win_off(nwin, w) || tb.width[w] != win_width(nwin, w)) return PM_ERR_INVALID_ARG;
-        const unsigned pbd = nwin <= 16 ? 512 : 256;                       // scalars per partition workgroup
-        if (regions > pbd) return PM_ERR_INVALID_ARG;                      // one scan lane per region
-        const size_t plds = 2 * 1024 * 4 + (size_t)pbd * nwin * 8;
-        const unsigned pblocks = (unsigned)((len + pbd - 1) / pbd);
+        const unsigned pblocks_max = (unsigned)((len_max + pbd - 1) / pbd);
+        const BlockScanShape bsh_max = block_scan_shape(pblocks_max, regions);
+        PM_HIP(ctx, ws.block_cnt.reserve(((size_t)pblocks_max + bsh_max.G) * regions * 4));
+    }
+    const unsigned SUB_BINS = 128, FIN_BINS = 256, FIN_BITS = 8;
+    const unsigned nsub = regions * SUB_BINS;
+    if (lo_buckets == (1u << LO_BITS)) {
+        PM_HIP(ctx, ws.sub.reserve((3 * (size_t)nsub + 4) * 4));
+        PM_HIP(ctx, ws.digits2.reserve(keys_bytes + Emax * 4));
+    }
+
+    // ---- the sort of pairs [lo, lo + cnt) into slot S, on stream `st`; prev: the previous chunk's slot (tasks carried forward)
+    auto sort_chunk = [&](hipStream_t st, size_t lo, size_t cnt, MsmSet &S, const MsmSet *prev) -> int {
+        StageTimer t(ctx, T_MSM_SORT, st);
+        const size_t E = (size_t)nwin * cnt;
+        const unsigned char *inf = tb.inf + tb.base_index + lo;
+        const Fp<FrP> *sc = d_scalars + lo;
+        uint32_t *counts = S.counts.as<uint32_t>(), *cursor = counts + NB;
+        PM_HIP(ctx, hipMemsetAsync(counts, 0, 2 * NB * 4, st));
+        PM_HIP(ctx, hipMemsetAsync(region_count, 0, (size_t)regions * 4, st));
+        const unsigned pblocks = (unsigned)((cnt + pbd - 1) / pbd);
         const BlockScanShape bsh = block_scan_shape(pblocks, regions);
-        PM_HIP(ctx, ws.block_cnt.reserve(((size_t)pblocks + bsh.G) * regions * 4));
         uint32_t *block_cnt = ws.block_cnt.as<uint32_t>(), *block_partial = block_cnt + (size_t)pblocks * regions;
         int launched = 0;
 #define PM_TBL_CASE(NW)                                                                                                     \
         case NW:                                                                                                                \
-            hipLaunchKernelGGL((k_tbl_count<FrP, NW>), dim3(pblocks), dim3(pbd), 0, ctx->stream, d_scalars, inf, len, regions,  \
+            hipLaunchKernelGGL((k_tbl_count<FrP, NW>), dim3(pblocks), dim3(pbd), 0, st, sc, inf, cnt, regions,                  \
                                block_cnt, win_buckets);                                                                         \
-            hipLaunchKernelGGL(k_block_sums, dim3(bsh.G), dim3(1024), 0, ctx->stream, block_cnt, pblocks, regions, bsh, block_partial); \
-            hipLaunchKernelGGL(k_block_offsets, dim3(bsh.G), dim3(1024), 0, ctx->stream, block_cnt, pblocks, regions, bsh, block_partial, \
+            hipLaunchKernelGGL(k_block_sums, dim3(bsh.G), dim3(1024), 0, st, block_cnt, pblocks, regions, bsh, block_partial);  \
+            hipLaunchKernelGGL(k_block_offsets, dim3(bsh.G), dim3(1024), 0, st, block_cnt, pblocks, regions, bsh, block_partial, \
                                region_count);                                                                                  \
-            hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, ctx->stream, region_count, region_off, region_cursor,  \
+            hipLaunchKernelGGL(k_region_offsets, dim3(1), dim3(1024), 0, st, region_count, region_off, region_cursor,           \
                                regions);                                                                                        \
             if (hipFuncSetAttribute((const void *)k_tbl_partition<FrP, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                     (int)plds) != hipSuccess) break;                                                            \
-            hipLaunchKernelGGL((k_tbl_partition<FrP, NW>), dim3(pblocks), dim3(pbd), plds, ctx->stream, d_scalars, inf, len,    \
-                               regions, region_off, block_cnt, wide ? (size_t)0 : tb.stride, tb.base_index, keys, vals,         \
+            hipLaunchKernelGGL((k_tbl_partition<FrP, NW>), dim3(pblocks), dim3(pbd), plds, st, sc, inf, cnt,                    \
+                               regions, region_off, block_cnt, wide ? (size_t)0 : tb.stride, tb.base_index + lo, keys, vals,    \
                                win_buckets);                                                                                    \
             launched = 1;                                                                                                       \
             break;
@@ -1190,73 +1252,108 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
 #undef PM_TBL_CASE
         if (!launched) return PM_ERR_INVALID_ARG;
         PM_HIP(ctx, hipGetLastError());
-        const unsigned sblocks = (unsigned)((Emax + chunk - 1) / chunk);
+        const unsigned sblocks = (unsigned)((E + chunk - 1) / chunk);
         const unsigned ntiles = (unsigned)((NB + SCAN_TILE - 1) / SCAN_TILE);
         auto bucket_scan = [&]() -> int {
-            hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, counts, ws.bucket_off.as<uint32_t>(),
-                               ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB, (unsigned)seg);
+            hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, st, counts, S.bucket_off.as<uint32_t>(),
+                               S.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB, (unsigned)seg,
+                               prev ? prev->task_off.as<uint32_t>() : (const uint32_t *)nullptr);
             PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, ws.cursor.as<uint32_t>(), ntiles,
-                               ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), NB);
+            hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, ws.cursor.as<uint32_t>(), ntiles,
+                               S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), NB);
             PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, ctx->stream, ws.bucket_off.as<uint32_t>(),
-                               ws.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB);
+            hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, st, S.bucket_off.as<uint32_t>(),
+                               S.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB);
             PM_HIP(ctx, hipGetLastError());
             return PM_OK;
         };
         if (lo_buckets == (1u << LO_BITS)) {
             // three levels: regions (2^15 buckets) -> 128 sub-regions of 256 buckets -> buckets
-            const unsigned SUB_BINS = 128, FIN_BINS = 256, FIN_BITS = 8;
-            const unsigned nsub = regions * SUB_BINS;
-            PM_HIP(ctx, ws.sub.reserve((3 * (size_t)nsub + 4) * 4));
-            PM_HIP(ctx, ws.digits2.reserve(keys_bytes + Emax * 4));
             uint32_t *sub_count = ws.sub.as<uint32_t>(), *sub_off = sub_count + nsub, *sub_cursor = sub_off + nsub + 1;
             uint16_t *keys2 = (uint16_t *)ws.digits2.p;
             uint32_t *vals2 = (uint32_t *)((uint8_t *)ws.digits2.p + keys_bytes);
-            PM_HIP(ctx, hipMemsetAsync(sub_count, 0, (size_t)nsub * 4, ctx->stream));
-            hipLaunchKernelGGL(k_hist_small, dim3(sblocks), dim3(1024), 0, ctx->stream, keys, region_off, regions, FIN_BITS, SUB_BINS, chunk,
+            PM_HIP(ctx, hipMemsetAsync(sub_count, 0, (size_t)nsub * 4, st));
+            hipLaunchKernelGGL(k_hist_small, dim3(sblocks), dim3(1024), 0, st, keys, region_off, regions, FIN_BITS, SUB_BINS, chunk,
                                sub_count);
             PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, sub_count, sub_off, sub_cursor, nsub);
+            hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, sub_count, sub_off, sub_cursor, nsub);
             PM_HIP(ctx, hipGetLastError());
-            const unsigned stblocks = (unsigned)((Emax + ST_CHUNK - 1) / ST_CHUNK);
-            hipLaunchKernelGGL(k_region_pass_staged<RS_MID>, dim3(stblocks), dim3(1024), 0, ctx->stream, keys, vals, region_off, regions,
+            const unsigned stblocks = (unsigned)((E + ST_CHUNK - 1) / ST_CHUNK);
+            hipLaunchKernelGGL(k_region_pass_staged<RS_MID>, dim3(stblocks), dim3(1024), 0, st, keys, vals, region_off, regions,
                                FIN_BITS, SUB_BINS, sub_off, sub_cursor, (uint32_t *)nullptr, keys2, vals2);
             PM_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(k_hist_small, dim3(sblocks), dim3(1024), 0, ctx->stream, keys2, sub_off, nsub, 0u, FIN_BINS, chunk, counts);
+            hipLaunchKernelGGL(k_hist_small, dim3(sblocks), dim3(1024), 0, st, keys2, sub_off, nsub, 0u, FIN_BINS, chunk, counts);
             PM_HIP(ctx, hipGetLastError());
             PM_TRY(bucket_scan());
-            hipLaunchKernelGGL(k_region_pass_staged<RS_FINAL>, dim3(stblocks), dim3(1024), 0, ctx->stream, keys2, vals2, sub_off, nsub, 0u,
-                               FIN_BINS, ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>(), (uint16_t *)nullptr,
+            hipLaunchKernelGGL(k_region_pass_staged<RS_FINAL>, dim3(stblocks), dim3(1024), 0, st, keys2, vals2, sub_off, nsub, 0u,
+                               FIN_BINS, S.bucket_off.as<uint32_t>(), cursor, S.sorted.as<uint32_t>(), (uint16_t *)nullptr,
                                (uint32_t *)nullptr);
             PM_HIP(ctx, hipGetLastError());
         } else {
             // small bucket sets (< 2^15): one region, sorted directly with an nbuckets-entry LDS table
             const size_t lds = (size_t)lo_buckets * 4;
-            hipLaunchKernelGGL(k_region_pass<RS_HIST>, dim3(sblocks), dim3(1024), lds, ctx->stream, keys, vals, region_off, regions, 0u,
+            hipLaunchKernelGGL(k_region_pass<RS_HIST>, dim3(sblocks), dim3(1024), lds, st, keys, vals, region_off, regions, 0u,
                                lo_buckets, chunk, counts, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                (uint16_t *)nullptr, (uint32_t *)nullptr);
             PM_HIP(ctx, hipGetLastError());
             PM_TRY(bucket_scan());
-            hipLaunchKernelGGL(k_region_pass<RS_FINAL>, dim3(sblocks), dim3(1024), lds, ctx->stream, keys, vals, region_off, regions, 0u,
-                               lo_buckets, chunk, (uint32_t *)nullptr, ws.bucket_off.as<uint32_t>(), cursor, ws.sorted.as<uint32_t>(),
+            hipLaunchKernelGGL(k_region_pass<RS_FINAL>, dim3(sblocks), dim3(1024), lds, st, keys, vals, region_off, regions, 0u,
+                               lo_buckets, chunk, (uint32_t *)nullptr, S.bucket_off.as<uint32_t>(), cursor, S.sorted.as<uint32_t>(),
                                (uint16_t *)nullptr, (uint32_t *)nullptr);
             PM_HIP(ctx, hipGetLastError());
         }
-        PM_TRY(task_order(ctx, counts, NB, seg, max_tasks));
-    }
-    {
+        PM_TRY(task_order(ctx, st, S, counts, NB, seg, max_tasks));
+        return PM_OK;
+    };
+    // ---- the accumulation of slot S on ctx->stream; prev: the previous chunk's slot, whose partials its first tasks continue
+    auto accumulate_chunk = [&](MsmSet &S, const MsmSet *prev) -> int {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
-        size_t blocks = (max_tasks + 127) / 128;
+        const size_t blocks = (max_tasks + 127) / 128;
+        const XYZZ<C> *pp = prev ? prev->partials.as<XYZZ<C>>() : (const XYZZ<C> *)nullptr;
+        const uint32_t *po = prev ? prev->task_off.as<uint32_t>() : (const uint32_t *)nullptr;
+        const uint32_t *pc = prev ? prev->task_cnt.as<uint32_t>() : (const uint32_t *)nullptr;
         if (wide)
-            hipLaunchKernelGGL((k_accumulate<C, false>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
-                               ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), (const void *)plain,
-                               ws.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
+            hipLaunchKernelGGL((k_accumulate<C, false>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, S.sorted.as<uint32_t>(), S.counts.as<uint32_t>(),
+                               S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), S.order.as<uint32_t>(), (const void *)plain,
+                               S.partials.as<XYZZ<C>>(), NB, (unsigned)seg, pp, po, pc);
         else
-            hipLaunchKernelGGL((k_accumulate<C, true>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, ws.sorted.as<uint32_t>(), counts,
-                               ws.bucket_off.as<uint32_t>(), ws.task_off.as<uint32_t>(), ws.order.as<uint32_t>(), tb.table,
-                               ws.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
+            hipLaunchKernelGGL((k_accumulate<C, true>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, S.sorted.as<uint32_t>(), S.counts.as<uint32_t>(),
+                               S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), S.order.as<uint32_t>(), tb.table,
+                               S.partials.as<XYZZ<C>>(), NB, (unsigned)seg, pp, po, pc);
         PM_HIP(ctx, hipGetLastError());
+        return PM_OK;
+    };
+
+    MsmSet *last = &ws.set[0];
+    if (K == 1) {
+        PM_TRY(sort_chunk(ctx->stream, 0, len, ws.set[0], nullptr));
+        PM_TRY(accumulate_chunk(ws.set[0], nullptr));
+    } else {
+        // ctx->stream: sort 0 | acc 0 | fold 0 | acc 1 | fold 1 | ...      sort_stream:        sort 1 | sort 2 | ...
+        // sort k + 1 starts when acc k starts (after sort k and after acc k - 1, whose slot k - 2 = k + 1 (mod 3) it overwrites)
+        auto slot_of = [&](unsigned k) -> MsmSet & { return ws.set[k % (unsigned)nslots]; };
+        PM_TRY(sort_chunk(ctx->stream, 0, len / K, slot_of(0), nullptr));
+        PM_HIP(ctx, hipEventRecord(ws.ev_begin, ctx->stream));
+        PM_HIP(ctx, hipStreamWaitEvent(ws.sort_stream, ws.ev_begin, 0));
+        for (unsigned k = 0; k < K; ++k) {
+            if (k + 1 < K) {
+                const size_t lo = len * (k + 1) / K, hi = len * (k + 2) / K;
+                PM_TRY(sort_chunk(ws.sort_stream, lo, hi - lo, slot_of(k + 1), &slot_of(k)));
+                PM_HIP(ctx, hipEventRecord(ws.ev_sorted[(k + 1) % MSM_SETS], ws.sort_stream));
+            }
+            if (k > 0) PM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ws.ev_sorted[k % MSM_SETS], 0));
+            PM_TRY(accumulate_chunk(slot_of(k), k ? &slot_of(k - 1) : nullptr));
+            if (k + 1 < K) {
+                // the next chunk's first tasks continue from ONE record per bucket: every bucket with several tasks is folded here
+                StageTimer t(ctx, T_MSM_REDUCE);
+                PM_TRY(fold_hot_buckets<C>(ctx, slot_of(k), NB, max_tasks, 1u));
+                // sort k + 2 overwrites slot k + 2 = k - 1 (mod 3), which acc k has just read as `prev`, and the sort temporaries
+                // are free once sort k + 1 is done (stream order): it may start when acc k + 1 does -- i.e. after this point
+                PM_HIP(ctx, hipEventRecord(ws.ev_acc[k % MSM_SETS], ctx->stream));
+                PM_HIP(ctx, hipStreamWaitEvent(ws.sort_stream, ws.ev_acc[k % MSM_SETS], 0));
+            }
+        }
+        last = &slot_of(K - 1);
     }
     if (wide) {
         // all windows' bucket sets reduced by ONE set of launches; then sum_w 2^(off_w) S_w by Horner from the top window: a chain
@@ -1264,9 +1361,9 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
         std::vector<XYZZ<C>> hS(nwin);
         {
             StageTimer t(ctx, T_MSM_REDUCE);
-            PM_TRY(fold_hot_buckets<C>(ctx, NB, max_tasks));
+            PM_TRY(fold_hot_buckets<C>(ctx, *last, NB, max_tasks));
             XYZZ<C> *dres = nullptr;
-            PM_TRY(reduce_two_level<C>(ctx, NB1, &dres, nwin));
+            PM_TRY(reduce_two_level<C>(ctx, NB1, &dres, nwin, last));
             PM_HIP(ctx, hipMemcpyAsync(hS.data(), dres, nwin * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
         }
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1282,15 +1379,15 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     XYZZ<C> hres;
     {
         StageTimer t(ctx, T_MSM_REDUCE);
-        PM_TRY(fold_hot_buckets<C>(ctx, NB, max_tasks));
+        PM_TRY(fold_hot_buckets<C>(ctx, *last, NB, max_tasks));
         XYZZ<C> *dres = nullptr;
         if (two_level) {
-            PM_TRY(reduce_two_level<C>(ctx, NB, &dres));
+            PM_TRY(reduce_two_level<C>(ctx, NB, &dres, 1, last));
         } else {
             XYZZ<C> *parts = ws.wsum.as<XYZZ<C>>();
             dres = parts + bpw;
             hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
-                               ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), (unsigned)NB, red_lanes, bpw, parts);
+                               last->partials.as<XYZZ<C>>(), last->task_off.as<uint32_t>(), last->task_cnt.as<uint32_t>(), (unsigned)NB, red_lanes, bpw, parts);
             PM_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(k_sum_parts<C>, dim3(1), dim3(64), 0, ctx->stream, parts, bpw, dres);
             PM_HIP(ctx, hipGetLastError());
@@ -1314,7 +1411,7 @@ int msm_run(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_
         return PM_OK;
     }
     const bool tbl = tables && tables->c;
-    const size_t MSM_MAX_PIECE = msm_max_piece();
+    const size_t MSM_MAX_PIECE = msm_max_piece(ctx);
     const bool wide = tbl && tables->wide;
     if (len <= MSM_MAX_PIECE)
         return tbl ? msm_piece_tables<C>(ctx, *tables, d_scalars, len, h_out, h_inf, wide ? d_bases : nullptr)
@@ -1353,7 +1450,7 @@ int msm_begin(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *
     }
     Affine<C> *slot_pt = (Affine<C> *)((uint8_t *)ctx->h_pinned + 1024);
     int *slot_inf = (int *)((uint8_t *)ctx->h_pinned + 2048);
-    if (len == 0 || !tbl || len > msm_max_piece()) {           // synchronous: result parked in the slot
+    if (len == 0 || !tbl || len > msm_max_piece(ctx)) {           // synchronous: result parked in the slot
         PM_TRY(msm_run<C>(ctx, d_bases, d_scalars, len, slot_pt, slot_inf, tables));
         ctx->msm_async = 2;
         return PM_OK;

@@ -5,19 +5,6 @@
 
 namespace pm {
 
-// sh[threadIdx.x] holds each lane's value on entry; on exit sh[0] holds the workgroup sum
-template <class C>
-__device__ __forceinline__ void lds_tree_sum(XYZZ28<C> *sh) {
-    __syncthreads();
-    for (unsigned off = blockDim.x >> 1; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            const XYZZ28<C> b = sh[threadIdx.x + off];
-            xyzz28_add_into_full<C>(&sh[threadIdx.x], b);
-        }
-        __syncthreads();
-    }
-}
-
 // Table-mode bucket reduction  S = sum_b (b + 1) B_b  over ONE set of NB buckets.  Every step below is a
 // chain of DEPENDENT point additions (~21 us each on a lone wave), so the layout minimises chain length,
 // not work:
@@ -52,128 +39,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Several bucket SETS in one launch (the wide-window MSM without tables reduces all of its windows at once): the level-0 outputs
 // of set s are lanes [s set_lanes, (s + 1) set_lanes) and the weight of lane t is its index INSIDE its set; set_lanes is a multiple
 // of the lanes a level-1 workgroup covers, so no workgroup straddles two sets.
-template <class C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_reduce_level1(const XYZZ<C> *A, const XYZZ<C> *Acc, size_t lanes0, unsigned K0,
-                                                       unsigned R, XYZZ<C> *out, size_t set_lanes) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
-    typedef typename C::FqRR RR;
-    // lane j owns level-0 outputs t in [jR, jR + R):  sum_t (t K0) A_t + acc_t
-    //   = K0 * (jR * sum_i A_{jR+i} + sum_i i A_{jR+i}) + sum_i acc_{jR+i}
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t0 = j * R;
-    XYZZ28<C> *acc = &sh[threadIdx.x];
-    acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
-    if (t0 < lanes0) {
-        XYZZ28<C> run = *acc;
-        for (int i = (int)R - 1; i >= 0; --i) {
-            if (t0 + i >= lanes0) continue;
-            xyzz28_add_full<C>(run, xyzz28_load<C>(A[t0 + i]));
-            if (i > 0) xyzz28_add_into_full<C>(acc, run);          // weight i
-        }
-        const size_t tw = t0 % set_lanes;                            // position inside the bucket set
-        if (tw) {                                                    // acc += tw * run
-            XYZZ28<C> m = run;
-            for (int b = 62 - __clzll((long long)tw); b >= 0; --b) {
-                xyzz28_dbl<C>(m);
-                if ((tw >> b) & 1) xyzz28_add_full<C>(m, run);
-            }
-            xyzz28_add_into_full<C>(acc, m);
-        }
-        run = *acc;
-        for (unsigned k = 1; k < K0; k <<= 1) xyzz28_dbl<C>(run);  // K0 is a power of two
-        for (unsigned i = 0; i < R; ++i)
-            if (t0 + i < lanes0) xyzz28_add_full<C>(run, xyzz28_load<C>(Acc[t0 + i]));
-        *acc = run;
-    }
-    lds_tree_sum<C>(sh);
-    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
-}
 
-// ---------------------------------------------------------------------------------- lane pairs
+// ------------------------------------------------------------------------------ lane groups
 // Levels 1 and the final sum are chains of DEPENDENT point operations on a chip that is at most a quarter full, so what counts is
-// the latency of one operation, and a point addition is 12 products + 2 squares of which only the critical path of 5 has to be
-// sequential.  Here lanes 2k and 2k + 1 hold the SAME point and each computes half of the products (role = lane & 1), swapping
-// field elements through DPP (quad_perm [1, 0, 3, 2]: a register move, no LDS):
-//   add:  role 0  U1, U2 | P, PP | PPP, Q       | X3, R QX, S1 (4p - PPP) -> Y3          6 M + 1 S per lane instead of 12 M + 2 S
-//         role 1  S1, S2 | R, RR | ZZ1 ZZ2, ZZZ1 ZZZ2 | ZZ3, ZZZ3
-//   dbl:  role 0  V = (2Y)^2 | W = 2Y V, S = X V | ZZ3 = V ZZ, ZZZ3 = W ZZZ               4 M + 1 S instead of 4.5 M + 3 S
-//         role 1  X^2 -> M   | M^2               | X3, M (S - X3), Y (4p - W) -> Y3
-// Both lanes run ONE instruction stream: operands are picked per role with v_cndmask, the role-specific limb arithmetic is executed
-// by both (on don't-care values in the other role).  Same formulas, bounds and invariants as xyzz28_add / xyzz28_dbl (X: W < 14p,
-// Y: W < 6p, ZZ, ZZZ: T); Y3 is the sum of two products here (tight + tight, then a carry propagation) instead of one fused one.
-template <class RR>
-__device__ __forceinline__ F28<RR> f28_partner(const F28<RR> &a) {
-    F28<RR> r;
-#pragma unroll
-    for (int i = 0; i < RR::N; ++i) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xF, 0xF, true);
-    return r;
-}
+// the latency of one operation, and a point addition is 12 products + 2 squares of which only the critical path has to be
+// sequential.  The four lanes of a group hold the SAME point and each computes one product per step, exchanging field elements
+// through DPP quad permutations (register moves, no LDS).  The four lanes run ONE instruction stream: operands are picked per role
+// with v_cndmask.  Same formulas, bounds and invariants as xyzz28_add / xyzz28_dbl (X: W < 14p, Y: W < 6p, ZZ, ZZZ: T); Y3 is the
+// sum of two products here (tight + tight, then a carry propagation) instead of one fused one.  (One lane and two lanes per point,
+// round 2's PM_RED_PAIR = 0 / 2, measured 1.70 / 1.48 ms against 1.39 at 2^21 buckets and 1.01 / 0.77 against 0.66 at 2^19:
+// profiles/r02_m_reduce_pair_sweep.txt; removed in round 4.)
 template <class RR>
 __device__ __forceinline__ F28<RR> f28_pick(bool c, const F28<RR> &a, const F28<RR> &b) {   // c ? a : b
     F28<RR> r;
 #pragma unroll
     for (int i = 0; i < RR::N; ++i) r.l[i] = c ? a.l[i] : b.l[i];
     return r;
-}
-__device__ __forceinline__ int pair_or(int v) { return v | __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
-
-// a += b, both lanes of the pair hold (a, b); false: the exceptional case (same x), a untouched
-template <class C>
-__device__ __forceinline__ bool xyzz28_add_pair(XYZZ28<C> &a, const XYZZ28<C> &b, bool r1) {
-    typedef typename C::FqRR RR;
-    typedef F28<RR> F;
-    if (f28_all_zero<RR>(b.ZZ)) return true;
-    if (f28_all_zero<RR>(a.ZZ)) { a = b; return true; }
-    const F T1 = f28_mul<RR>(f28_pick<RR>(r1, a.Y, a.X), f28_pick<RR>(r1, b.ZZZ, b.ZZ));     // U1 | S1          W x T -> T
-    const F T2 = f28_mul<RR>(f28_pick<RR>(r1, b.Y, b.X), f28_pick<RR>(r1, a.ZZZ, a.ZZ));     // U2 | S2
-    const F D = f28_sub_k4<RR>(T2, T1);                                                      // P  | R           L e<=1.6, < 6p
-    const F DD = f28_sqr<RR>(D);                                                             // PP | RR
-    if (pair_or(!r1 && f28_is_zero_mod_p<RR>(DD))) return false;
-    const F V1 = f28_mul<RR>(f28_pick<RR>(r1, a.ZZ, D), f28_pick<RR>(r1, b.ZZ, DD));         // PPP | ZZ1 ZZ2
-    const F V2 = f28_mul<RR>(f28_pick<RR>(r1, a.ZZZ, T1), f28_pick<RR>(r1, b.ZZZ, DD));      // Q = U1 PP | ZZZ1 ZZZ2
-    const F xD = f28_partner<RR>(D), xDD = f28_partner<RR>(DD), xV1 = f28_partner<RR>(V1), xT1 = f28_partner<RR>(T1);
-    // role 0 (role 1 runs it on don't-care values): X3 = RR - PPP - 2Q, QX = Q - X3, 4p - PPP
-    F X3 = f28_sub_k4<RR>(xDD, V1);
-    X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(X3, f28_add<RR>(V2, V2)));                         // W, < 14p
-    const F QX = f28_sub_k16<RR>(V2, X3);                                                    // L e<=1.6, < 18p
-    const F nPPP = f28_sub_k4<RR>(f28_zero<RR>(), V1);                                       // limbs < 2^29, < 4p
-    const F W1 = f28_mul<RR>(f28_pick<RR>(r1, V1, xD), f28_pick<RR>(r1, xDD, QX));           // R QX | ZZ3 = (ZZ1 ZZ2) PP
-    const F W2 = f28_mul<RR>(f28_pick<RR>(r1, V2, xT1), f28_pick<RR>(r1, xV1, nPPP));        // S1 (4p - PPP) | ZZZ3 = (ZZZ1 ZZZ2) PPP
-    const F Y3 = f28_weak_norm<RR>(f28_add<RR>(W1, W2));                                     // W, < 4p
-    const F pX = f28_partner<RR>(X3), pY = f28_partner<RR>(Y3), pW1 = f28_partner<RR>(W1), pW2 = f28_partner<RR>(W2);
-    a.X = f28_pick<RR>(r1, pX, X3);
-    a.Y = f28_pick<RR>(r1, pY, Y3);
-    a.ZZ = f28_pick<RR>(r1, W1, pW1);
-    a.ZZZ = f28_pick<RR>(r1, W2, pW2);
-    return true;
-}
-template <class C>
-__device__ __forceinline__ void xyzz28_add_pair_full(XYZZ28<C> &a, const XYZZ28<C> &b, bool r1) {
-    if (!xyzz28_add_pair<C>(a, b, r1)) a = xyzz28_add_exceptional<C>(a, b);     // both lanes, the same result
-}
-template <class C>
-__device__ __forceinline__ void xyzz28_dbl_pair(XYZZ28<C> &a, bool r1) {
-    typedef typename C::FqRR RR;
-    typedef F28<RR> F;
-    if (f28_all_zero<RR>(a.ZZ)) return;
-    const F U = f28_add<RR>(a.Y, a.Y);                                          // limbs < 2^29, < 12p
-    const F A = f28_sqr<RR>(f28_pick<RR>(r1, a.X, U));                          // V = U^2 | X^2
-    const F M = f28_add<RR>(f28_add<RR>(A, A), A);                              // role 1: 3 X^2, limbs < 3 2^28, < 6p
-    const F B1 = f28_mul<RR>(f28_pick<RR>(r1, M, U), f28_pick<RR>(r1, M, A));   // W = U V | M^2
-    const F B2 = f28_mul<RR>(a.X, A);                                           // S = X V | (unused)
-    const F S = f28_partner<RR>(B2), Wv = f28_partner<RR>(B1);                  // role 1 receives S and W
-    // role 1: X3 = M^2 - 2S, SX = S - X3, 4p - W
-    const F X3 = f28_weak_norm<RR>(f28_sub_k8<RR>(B1, f28_add<RR>(S, S)));      // W, < 10p
-    const F SX = f28_sub_k16<RR>(S, X3);                                        // L e<=1.6, < 18p
-    const F nW = f28_sub_k4<RR>(f28_zero<RR>(), Wv);
-    const F C1 = f28_mul<RR>(f28_pick<RR>(r1, M, A), f28_pick<RR>(r1, SX, a.ZZ));      // ZZ3 = V ZZ | M (S - X3)
-    const F C2 = f28_mul<RR>(f28_pick<RR>(r1, a.Y, B1), f28_pick<RR>(r1, nW, a.ZZZ));  // ZZZ3 = W ZZZ | Y (4p - W)
-    const F Y3 = f28_weak_norm<RR>(f28_add<RR>(C1, C2));                        // role 1: W, < 4p
-    const F pX = f28_partner<RR>(X3), pY = f28_partner<RR>(Y3), pC1 = f28_partner<RR>(C1), pC2 = f28_partner<RR>(C2);
-    a.X = f28_pick<RR>(r1, X3, pX);
-    a.Y = f28_pick<RR>(r1, Y3, pY);
-    a.ZZ = f28_pick<RR>(r1, pC1, C1);
-    a.ZZZ = f28_pick<RR>(r1, pC2, C2);
 }
 
 // ---- four lanes per point: the critical path of an addition is 3M + 1S (U/S products | P^2, R^2 | PPP, Q, ZZ1 ZZ2, ZZZ1 ZZZ2 |
@@ -246,15 +127,16 @@ __device__ __forceinline__ void xyzz28_dbl_quad(XYZZ28<C> &a, unsigned role) {
     a.ZZZ = f28_dpp<QP_B2, RR>(Cc);
 }
 
-// one interface for the kernels: LP lanes per point (2 or 4), role = lane % LP
+// one interface for the kernels: LP = 4 lanes per point, role = lane % LP
 template <class C, unsigned LP>
 __device__ __forceinline__ void xyzz28_add_coop(XYZZ28<C> &a, const XYZZ28<C> &b, unsigned role) {
-    const bool ok = LP == 2 ? xyzz28_add_pair<C>(a, b, role & 1) : xyzz28_add_quad<C>(a, b, role);
-    if (!ok) a = xyzz28_add_exceptional<C>(a, b);     // every lane of the group, the same result
+    static_assert(LP == 4, "four lanes per point");
+    if (!xyzz28_add_quad<C>(a, b, role)) a = xyzz28_add_exceptional<C>(a, b);     // every lane of the group, the same result
 }
 template <class C, unsigned LP>
 __device__ __forceinline__ void xyzz28_dbl_coop(XYZZ28<C> &a, unsigned role) {
-    if (LP == 2) xyzz28_dbl_pair<C>(a, role & 1); else xyzz28_dbl_quad<C>(a, role);
+    static_assert(LP == 4, "four lanes per point");
+    xyzz28_dbl_quad<C>(a, role);
 }
 
 // sh[k], k < blockDim.x / LP: the value of lane group k on entry (written by its role-0 lane); on exit sh[0] = the workgroup sum
@@ -340,39 +222,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
 }
 
-// out[0] = sum of parts[0 .. count) by one 256-lane workgroup
-template <class C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sum_final(const XYZZ<C> *parts, unsigned count, XYZZ<C> *out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    XYZZ28<C> *sh = (XYZZ28<C> *)smem_raw;
-    typedef typename C::FqRR RR;
-    XYZZ28<C> *acc = &sh[threadIdx.x];
-    acc->X = acc->Y = acc->ZZ = acc->ZZZ = f28_zero<RR>();
-    parts += (size_t)blockIdx.x * count;
-    for (unsigned i = threadIdx.x; i < count; i += 256) xyzz28_add_into_full<C>(acc, xyzz28_load<C>(parts[i]));
-    lds_tree_sum<C>(sh);
-    if (threadIdx.x == 0) out[blockIdx.x] = xyzz28_store<C>(sh[0]);
-}
-
 // sum_b (b + 1) B_b over each of `nsets` sets of NB buckets (set s = buckets [s NB, (s + 1) NB)) whose (folded) task partials sit in
 // ctx->msm: three launches on ctx->stream, the nsets results (internal form) at (*out)[0 .. nsets) in the workspace.  nsets = 1:
 // the shared bucket set of the window-table MSM; nsets = windows: the wide-window MSM without tables.
 template <class C>
-int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets) {
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets, const MsmSet *S) {
     MsmWorkspace &ws = ctx->msm;
+    if (!S) S = &ws.set[0];
     if (nsets == 0 || (NB & (NB - 1)) != 0) return PM_ERR_INVALID_ARG;
     const size_t total = NB * nsets;
     unsigned K0 = 4;                                   // level-0 fan-in: <= 2^17 lanes = 2 waves per SIMD, one round of the chip
     while (total / K0 > ((size_t)1 << 17) && K0 < 64) K0 <<= 1;   // (swept in profiles/r02_levers.jsonl: K0 = 2 doubles level 1's work and loses)
-    if (const char *e = getenv("PM_RED_K0")) K0 = (unsigned)atoi(e);        // developer knobs (powers of two)
-    // levels 1 and final on lane GROUPS (2 or 4 lanes per point, a share of the products each): 256 / LP points per workgroup, and
-    // R = 2 LP keeps level 1 at 2^16 lanes = one wave per SIMD (its register budget).  PM_RED_PAIR = 0: one lane per point, 2: pairs.
-    unsigned coop = 4;
-    if (const char *e = getenv("PM_RED_PAIR")) coop = e[0] == '0' ? 0u : e[0] == '2' ? 2u : 4u;
-    unsigned R1 = coop ? 2 * coop : 2;                 // swept on MI355X (tools/sweep_reduce.sh, profiles/r02_m_reduce_pair_sweep.txt)
-    if (const char *e = getenv("PM_RED_R")) R1 = (unsigned)atoi(e);
-    if (K0 == 0 || R1 == 0 || (K0 & (K0 - 1)) != 0) return PM_ERR_INVALID_ARG;
-    const unsigned per_block1 = coop ? 256 / coop : 256;      // points per level-1 workgroup
+    // levels 1 and final on lane GROUPS (4 lanes per point, a share of the products each): 256 / LP points per workgroup, and
+    // R = 2 LP keeps level 1 at 2^16 lanes = one wave per SIMD (its register budget); K0 and R swept on MI355X in round 2
+    // (profiles/r02_levers.jsonl, r02_m_reduce_pair_sweep.txt)
+    constexpr unsigned coop = 4;
+    unsigned R1 = 2 * coop;
+    const unsigned per_block1 = 256 / coop;                   // points per level-1 workgroup
     const size_t set_lanes = (NB + K0 - 1) / K0;              // level-0 outputs per bucket set
     if (nsets > 1) {   // no level-1 workgroup may straddle two sets
         while (set_lanes % ((size_t)R1 * per_block1) != 0 && R1 > 1) R1 >>= 1;
@@ -383,31 +249,19 @@ int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets) {
     PM_HIP(ctx, ws.wsum.reserve((2 * lanes0 + (blocks0 > blocks1 ? blocks0 : blocks1) + 4 + nsets) * sizeof(XYZZ<C>)));
     XYZZ<C> *A = ws.wsum.as<XYZZ<C>>(), *Acc = A + lanes0, *parts = Acc + lanes0, *dres = parts + (blocks0 > blocks1 ? blocks0 : blocks1);
     hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
-                       ws.partials.as<XYZZ<C>>(), ws.task_off.as<uint32_t>(), ws.task_cnt.as<uint32_t>(), total, lanes0, K0, A, Acc);
+                       S->partials.as<XYZZ<C>>(), S->task_off.as<uint32_t>(), S->task_cnt.as<uint32_t>(), total, lanes0, K0, A, Acc);
     PM_HIP(ctx, hipGetLastError());
     const unsigned per_set = (unsigned)(blocks1 / nsets);     // level-1 workgroups (= partials) per set; exact when nsets > 1
-    if (coop == 4) {
-        hipLaunchKernelGGL((k_reduce_level1_coop<C, 4>), dim3((unsigned)blocks1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
-                           lanes0, K0, R1, parts, set_lanes);
-        PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((k_sum_final_coop<C, 4>), dim3(nsets), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, parts, per_set, dres);
-    } else if (coop == 2) {
-        hipLaunchKernelGGL((k_reduce_level1_coop<C, 2>), dim3((unsigned)blocks1), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
-                           lanes0, K0, R1, parts, set_lanes);
-        PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((k_sum_final_coop<C, 2>), dim3(nsets), dim3(256), 128 * sizeof(XYZZ28<C>), ctx->stream, parts, per_set, dres);
-    } else {
-        hipLaunchKernelGGL(k_reduce_level1<C>, dim3((unsigned)blocks1), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, A, Acc, lanes0,
-                           K0, R1, parts, set_lanes);
-        PM_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_sum_final<C>, dim3(nsets), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, parts, per_set, dres);
-    }
+    hipLaunchKernelGGL((k_reduce_level1_coop<C, 4>), dim3((unsigned)blocks1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
+                       lanes0, K0, R1, parts, set_lanes);
+    PM_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL((k_sum_final_coop<C, 4>), dim3(nsets), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, parts, per_set, dres);
     PM_HIP(ctx, hipGetLastError());
     *out = dres;
     return PM_OK;
 }
 
-template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **, unsigned);
-template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **, unsigned);
+template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **, unsigned, const MsmSet *);
+template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **, unsigned, const MsmSet *);
 
 }  // namespace pm

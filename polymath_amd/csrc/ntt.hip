@@ -138,66 +138,6 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const Fp<P> *a, Fp<P> *dst, co
     }
 }
 
-// FIRST pass with the bit reversal folded into its loads (no k_bitrev round trip): stages [0, ns) of the DIT network
-// need, for every value `hi` of the upper H = log_n - ns index bits, the 2^ns elements src[brev(hi 2^ns + r)] =
-// src[(brev_ns(r) << H) + brev_H(hi)].  A workgroup takes the 2^log_cols values of hi whose brev_H are CONSECUTIVE
-// (8g .. 8g + 7): its loads are then 256-byte-contiguous segments like every other pass's, and it writes, for each of
-// its hi, 2^ns contiguous outputs.  Reads and writes touch different positions, so the pass goes src -> dst.
-// The tile is swizzled (column (c + r) & (cols - 1)) so that the column-major store phase is bank-conflict free.
-template <class P, class RR>
-__global__ __launch_bounds__(256) void k_ntt_first_pass(const Fp<P> *src, Fp<P> *dst, const Fp<P> *tw, unsigned log_n, unsigned ns,
-                                                         unsigned log_cols) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Fp<P> *tile = (Fp<P> *)smem_raw;  // [2^ns][cols], swizzled
-    const unsigned cols = 1u << log_cols, rows = 1u << ns, H = log_n - ns, cm = cols - 1;
-    const size_t g = blockIdx.x;
-    const unsigned tid = threadIdx.x;
-    for (unsigned e = tid; e < rows * cols; e += blockDim.x) {
-        const unsigned rb = e >> log_cols, c = e & cm;
-        const unsigned r = __brev(rb) >> (32 - ns);
-        tile[r * cols + ((c + r) & cm)] = src[((size_t)rb << H) + (g << log_cols) + c];
-    }
-    __syncthreads();
-    const unsigned nbf = (rows >> 1) * cols;
-    for (unsigned t = 0; t < ns; ++t) {
-        const unsigned s = t + 1, half = 1u << t;
-        auto bfly = [&](unsigned r0, unsigned c, const Fp<P> &w) {
-            const unsigned r1 = r0 + half;
-            Fp<P> *p0 = &tile[r0 * cols + ((c + r0) & cm)], *p1 = &tile[r1 * cols + ((c + r1) & cm)];
-            const Fp<P> x = *p0, y0 = *p1;
-            Fp<P> y;
-            f28_pack_reduced<RR>(f28_mul<RR>(f28_unpack<RR>(y0.l), f28_unpack<RR>(w.l)), y.l);
-            *p0 = add<P>(x, y);
-            *p1 = sub<P>(x, y);
-        };
-        if (nbf == 4 * blockDim.x) {   // issue the four twiddle loads of this lane's butterflies before the arithmetic
-            Fp<P> w[4];
-            unsigned r0v[4], cv[4];
-#pragma unroll
-            for (unsigned q = 0; q < 4; ++q) {
-                const unsigned e = tid + q * blockDim.x, k = e >> log_cols;
-                cv[q] = e & cm;
-                r0v[q] = ((k >> t) << (t + 1)) | (k & (half - 1));
-                w[q] = tw[(size_t)(r0v[q] & (half - 1)) << (log_n - s)];
-            }
-#pragma unroll
-            for (unsigned q = 0; q < 4; ++q) bfly(r0v[q], cv[q], w[q]);
-        } else {
-            for (unsigned e = tid; e < nbf; e += blockDim.x) {
-                const unsigned c = e & cm, k = e >> log_cols;
-                const unsigned r0 = ((k >> t) << (t + 1)) | (k & (half - 1));
-                bfly(r0, c, tw[(size_t)(r0 & (half - 1)) << (log_n - s)]);
-            }
-        }
-        __syncthreads();
-    }
-    for (unsigned e = tid; e < rows * cols; e += blockDim.x) {
-        const unsigned c = e >> ns, r = e & (rows - 1);
-        const size_t hi = __brevll((unsigned long long)((g << log_cols) + c)) >> (64 - H);
-        dst[(hi << ns) + r] = tile[r * cols + ((c + r) & cm)];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Round-2 pass kernels: the tile lives in LDS in REDUCED RADIX (C::FrNttRR: 9 x u32 limbs of 29 bits per element, limb-major
 // planes -- one bank per lane for every access), so a butterfly is one carry-free product (fq28.cuh) plus lazy limb-wise add / sub:
@@ -443,7 +383,12 @@ __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     }
 }
 
-// first pass with the bit reversal folded into its loads (see k_ntt_first_pass), src -> dst
+// FIRST pass with the bit reversal folded into its loads (no k_bitrev round trip): stages [0, ns) of the DIT network
+// need, for every value `hi` of the upper H = log_n - ns index bits, the 2^ns elements src[brev(hi 2^ns + r)] =
+// src[(brev_ns(r) << H) + brev_H(hi)].  A workgroup takes the 2^log_cols values of hi whose brev_H are CONSECUTIVE
+// (8g .. 8g + 7): its loads are then 256-byte-contiguous segments like every other pass's, and it writes, for each of
+// its hi, 2^ns contiguous outputs.  Reads and writes touch different positions, so the pass goes src -> dst.
+// (src -> dst.)  The tile is swizzled (column (c + r) & (cols - 1)) so that the column-major store phase is bank-conflict free.
 template <class P, class RR>
 __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned ns,
                                                                    unsigned log_cols, int pair_stages) {
@@ -480,15 +425,11 @@ __global__ void k_scale(Fp<P> *a, size_t n, Fp<P> s) {
     if (i < n) a[i] = mul<P>(a[i], s);
 }
 
-static bool ntt_fused_enabled() {
-    static const bool v = [] { const char *e = getenv("PM_NTT_FUSED"); return !(e && e[0] == '0'); }();
-    return v;
-}
-// domains transformed by the 28-bit-limb tile kernels (their twiddle records are then kept on 28-bit limbs too)
+// domains transformed by the reduced-radix tile kernels (their twiddle records are then kept on reduced-radix limbs too); smaller
+// ones run k_bitrev + k_ntt_pass (+ k_scale)
 static bool ntt_l28_domain(unsigned log_n) {
-    static const bool l28 = [] { const char *e = getenv("PM_NTT_L28"); return !(e && e[0] == '0'); }();
     const unsigned tile_log = log_n > 24 ? (unsigned)LOG_TILE + 1 : (unsigned)LOG_TILE;
-    return ntt_fused_enabled() && l28 && log_n >= tile_log + 3;
+    return log_n >= tile_log + 3;
 }
 
 template <class C>
@@ -568,7 +509,6 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
     // (512 rows x 4 columns, the same 64 KiB of LDS) so that 2^25..2^27 points still need only three passes
     const unsigned tile_log = log_n > 24 ? (unsigned)LOG_TILE + 1 : (unsigned)LOG_TILE;
     const Fr ninv = inv_dir ? inverse<P>(from_u64<P>((uint64_t)n)) : Fr::one();
-    const bool fused = ntt_fused_enabled();
     if (ntt_l28_domain(log_n)) {
         // the same pass structure on the reduced-radix tiles (k_ntt_pass28, 9 limbs of 29 bits): 2^11 elements x 36 B = 72 KiB of LDS per workgroup
         PM_HIP(ctx, ctx->ntt_tmp.reserve(n * sizeof(Fr)));
@@ -590,7 +530,7 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         // passes balanced over the stages, every tile 2^11 elements (21 = 7 + 7 + 7 with 16-column tiles, not 8 + 8 + 5 with a
         // last pass whose workgroups hold 2^8 elements; 17 and 18 take two 9-stage passes instead of three)
         const unsigned p8 = (log_n + 7) / 8, p9 = (log_n + 8) / 9, npass = p9 < p8 ? p9 : p8;
-        static const int pair_stages = [] { const char *e = getenv("PM_NTT_RADIX4"); return e && e[0] == '0' ? 0 : 1; }();
+        const int pair_stages = 1;   // two stages per LDS round trip (profiles/r03_ntt_two_stage_ab.txt: -7 ... -13 % per transform)
         unsigned s0 = 0;
         for (unsigned k = 0; k < npass; ++k) {
             const unsigned ns = log_n / npass + (k < log_n % npass ? 1 : 0);
@@ -605,31 +545,6 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
                                    ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)tmp, last ? d : tmp, tw28, log_n, s0, ns,
                                    log_cols, scale_int, last && inv_dir ? 1 : 0, pair_stages);
             }
-            PM_HIP(ctx, hipGetLastError());
-            s0 += ns;
-        }
-        return PM_OK;
-    }
-    if (fused && log_n >= tile_log + 3) {
-        // >= 2 passes: d -> tmp (bit reversal folded into the first pass's loads), middle passes in place on tmp,
-        // tmp -> d (n^-1 folded into the last pass's stores): no k_bitrev and no k_scale round trip through HBM
-        PM_HIP(ctx, ctx->ntt_tmp.reserve(n * sizeof(Fr)));
-        Fr *tmp = ctx->ntt_tmp.as<Fr>();
-        {
-            const unsigned ns = tile_log, log_cols = 11 - ns;
-            hipLaunchKernelGGL((k_ntt_first_pass<P, typename C::FrRR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(256),
-                               ((size_t)1 << (ns + log_cols)) * sizeof(Fr), ctx->stream, (const Fr *)d, tmp, tw, log_n, ns, log_cols);
-            PM_HIP(ctx, hipGetLastError());
-        }
-        unsigned s0 = tile_log;
-        while (s0 < log_n) {
-            const unsigned ns = log_n - s0 < tile_log ? log_n - s0 : tile_log;
-            unsigned log_cols = 11 - ns < 3 ? 11 - ns : 3;
-            if (s0 < log_cols) log_cols = s0;
-            const bool last = s0 + ns == log_n;
-            hipLaunchKernelGGL((k_ntt_pass<P, typename C::FrRR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(256),
-                               ((size_t)1 << (ns + log_cols)) * sizeof(Fr), ctx->stream, (const Fr *)tmp, last ? d : tmp, tw, log_n, s0, ns, log_cols,
-                               ninv, last && inv_dir ? 1 : 0);
             PM_HIP(ctx, hipGetLastError());
             s0 += ns;
         }

@@ -447,10 +447,10 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     // [a]_1 = M1 + M2 needs only u and r_a, and is independent of [c]_1 = M7 + M6 + M3 + M4 + M5: it runs on a helper
     // context (own stream and workspace) from a second host thread, started HERE -- its sort, bucket reduction and
     // host finish are dependent chains that leave the chip mostly idle, and hide under the remaining transforms and
-    // the larger MSM's accumulation.  The helper stream waits on an event, the host does not.  PM_MSM_OVERLAP=0
+    // the larger MSM's accumulation.  The helper stream waits on an event, the host does not.  PM_OPT_MSM_OVERLAP = 0
     // runs the two MSMs back to back after the checks.
-    const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();   // per call: bench.py toggles it
-    if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
+    const bool overlap = ctx->opt.v[PM_OPT_MSM_OVERLAP] != 0;
+    pm_ctx *const aux_ctx = overlap ? ctx_aux(ctx) : nullptr;
     int st_a = PM_OK;   // written by the helper thread: declared before the joiner so that it outlives the join
     struct Joiner {     // an early error return must not leave the helper job running into freed stack variables
         pm_worker *w;
@@ -458,10 +458,8 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
         void join() { if (pending) { w->wait(); pending = false; } }
         ~Joiner() { join(); }
     } helper{&ctx->worker, false};
-    // PM_A_LATE=1 (experiment, measured NEUTRAL on one GPU: profiles/r03_a_late_msm_single_gpu_ab.txt): do not start [a]_1 here;
-    // enqueue it next to [c]_1 after the transforms, both from this thread (msm_resident_begin / _end, as the sharded prover does)
-    const bool a_late = overlap && ctx->aux && [] { const char *e = getenv("PM_A_LATE"); return e && e[0] == '1'; }();
-    bool a_early = overlap && ctx->aux && !a_late;
+    // (Enqueueing [a]_1 late, next to [c]_1 after the transforms, measured neutral on one GPU: profiles/r03_a_late_msm_single_gpu_ab.txt.)
+    bool a_early = aux_ctx != nullptr;
     if (a_early) {
         pm_ctx *aux = ctx->aux;
         hipLaunchKernelGGL(k_sc_a<P>, dim3(nblk(n)), dim3(256), 0, st, u, ra, sc_a, n);
@@ -528,21 +526,7 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     PM_HIP(ctx, hipStreamSynchronize(st));
     if (hflags & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
     if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
-    if (a_late) {
-        pm_ctx *aux = ctx->aux;
-        timing_reset(aux);
-        PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
-        PM_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0));
-        int s_a = msm_resident_begin<C>(aux, pk, 0, sc_a + pk->res_lo[0]);
-        const int s_c = s_a == PM_OK ? msm_resident_begin<C>(ctx, pk, 1, sc_c + pk->res_lo[1]) : (int)PM_OK;
-        const int e_c = s_a == PM_OK && s_c == PM_OK ? msm_resident_end<C>(ctx, c_xy, c_inf) : (int)PM_OK;
-        if (s_a == PM_OK) s_a = msm_resident_end<C>(aux, a_xy, a_inf);
-        timing_flush(aux);
-        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += aux->timing_ms[s];
-        if (s_a != PM_OK) { ctx->err = aux->err; return s_a; }
-        PM_TRY(s_c);
-        PM_TRY(e_c);
-    } else if (a_early) {
+    if (a_early) {
         const int st_c = msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
         helper.join();
         for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];

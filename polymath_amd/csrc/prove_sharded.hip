@@ -21,13 +21,13 @@ using pmlayout::Segment;
 
 // a collective's status -> the phase's status (the communicator's message goes to pm_last_error)
 static int comm_status(pm_ctx *ctx, int st, const char *what) {
-    if (st) ctx->err = std::string(what) + ": " + ctx->comm->err;
+    if (st) ctx->err = std::string(what) + ": " + ctx->comm->error();
     return st;
 }
 // end of a phase: whatever the watchdog cut short must not be taken for a result
 static int comm_alive(pm_ctx *ctx) {
     if (!ctx->comm->failed) return PM_OK;
-    ctx->err = "communicator failed: " + ctx->comm->err;
+    ctx->err = "communicator failed: " + ctx->comm->error();
     return PM_ERR_COMM;
 }
 
@@ -207,17 +207,16 @@ template <class P>
 static void launch_cross_dft(hipStream_t st, const Fp<P> *in, Fp<P> *out, const Fp<P> *roots, const Layout &L, const Fp<P> *tw, int in_twiddle,
                              int out_twiddle, Fp<P> scale, int use_scale) {
     const uint64_t k2_base = (uint64_t)L.q * L.B;
-    static const bool col = [] { const char *e = getenv("PM_CROSS_DFT_COL"); return !(e && e[0] == '0'); }();
 #define PM_COL(NN)                                                                                                                          \
     case NN:                                                                                                                                \
         hipLaunchKernelGGL((k_cross_dft_col<P, NN>), dim3(nblk(L.B, CROSS_COL_THREADS)), dim3(CROSS_COL_THREADS),                           \
                            (size_t)NN * sizeof(Fp<P>) * CROSS_COL_THREADS, st, in, out, roots, L.B, tw, L.n, k2_base, in_twiddle,            \
                            out_twiddle, scale, use_scale);                                                                                  \
         return;
-    if (col) switch (L.N) {
-            PM_COL(2) PM_COL(4) PM_COL(8) PM_COL(16)
-            default: break;
-        }
+    switch (L.N) {
+        PM_COL(2) PM_COL(4) PM_COL(8) PM_COL(16)
+        default: break;
+    }
 #undef PM_COL
     hipLaunchKernelGGL(k_cross_dft<P>, dim3(nblk(L.m)), dim3(256), 0, st, in, out, roots, L.N, L.B, tw, L.n, k2_base, in_twiddle, out_twiddle, scale,
                        use_scale);
@@ -512,11 +511,8 @@ __global__ __launch_bounds__(SEG_THREADS) void k_seg_base(const Segment *segs, S
 }
 
 // 512 lanes per segment: with ~256-400 segments per rank every CU holds one or two workgroups at 2-4 waves per SIMD (1024 lanes and
-// half as many segments left a third of the chip idle and four waves queueing on each busy SIMD); PM_SEG_THREADS=1024: round 2
-static bool seg_threads_512() {
-    static const bool v = [] { const char *e = getenv("PM_SEG_THREADS"); return !(e && atoi(e) == 1024); }();
-    return v;
-}
+// half as many segments left a third of the chip idle and four waves queueing on each busy SIMD: profiles/r03_k_*)
+constexpr unsigned SEG_LANES = 512;
 
 // does [a, b) contain one of the numerator's constants (indices 0, 1, 2 sigma .. 2 sigma + 2)?
 __host__ __device__ inline bool filler_has_const(uint64_t a, uint64_t b, uint64_t sigma) {
@@ -765,16 +761,15 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         PM_HIP(ctx, hipGetLastError());
         PM_TRY(dist_intt<C>(ctx, pk, L, tc, ta, wit_u));
     }
-    // PM_NTT_OVERLAP=1 (opt-in): w's transform (N2) runs on the helper context's stream beside u's chain
+    // PM_OPT_NTT_OVERLAP: w's transform (N2) runs on the helper context's stream beside u's chain
     // (N1, then the three transforms of the square) and joins before k_untwist_combine_L, so that on a fabric its all-to-all
     // travels under u's kernels and u's under w's local passes.  Every rank issues the exchanges in the same order
     // (u, w, square forward, square inverse); they are on two streams of ONE communicator.
-    const char *ntt_env = getenv("PM_NTT_OVERLAP");           // read per proof: the tests switch it inside one process
-    const bool ntt_beside = ntt_env && ntt_env[0] == '1';
+    const bool ntt_beside = ctx->opt.v[PM_OPT_NTT_OVERLAP] != 0;
     pm_ctx *wctx = ctx;
     if (ntt_beside) {
-        if (!ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
-        if (ctx->aux && ctx->aux->sh_a.reserve(m * sizeof(Fr)) == hipSuccess) wctx = ctx->aux;
+        pm_ctx *aux = ctx_aux(ctx);
+        if (aux && aux->sh_a.reserve(m * sizeof(Fr)) == hipSuccess) wctx = aux;
     }
     if (wctx != ctx) {   // `we` is complete (and k_check_sap_L has read it) at this point of the stream
         PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
@@ -834,12 +829,10 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     // [a]_1 and [c]_1 are independent MSMs: both pipelines are ENQUEUED before either is waited for -- [a]_1 on the helper
     // context's stream and workspace, behind an event on this stream; [c]_1 here -- so the smaller one's latency-bound sort
     // front end and bucket reduction run under the larger one's accumulation.  One host thread, no collective in between
-    // (the single-GPU prover starts [a]_1 earlier, from a second thread: prove.hip).  PM_MSM_OVERLAP=0: one after the other.
+    // (the single-GPU prover starts [a]_1 earlier, from a second thread: prove.hip).  PM_OPT_MSM_OVERLAP = 0: one after the other.
     int a_inf_l = 1, c_inf_l = 1;
-    const bool overlap = [] { const char *e = getenv("PM_MSM_OVERLAP"); return !(e && e[0] == '0'); }();
-    if (overlap && !ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
-    if (overlap && ctx->aux) {
-        pm_ctx *aux = ctx->aux;
+    const bool overlap = ctx->opt.v[PM_OPT_MSM_OVERLAP] != 0;
+    if (pm_ctx *aux = overlap ? ctx_aux(ctx) : nullptr) {
         timing_reset(aux);
         PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
         PM_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0));
@@ -933,12 +926,8 @@ int prove_phase2_sharded(pm_ctx *ctx, const uint64_t *x1_in, uint64_t *u_at_x1) 
         const Fr *u = ctx->u.as<Fr>(), *wit_u = ctx->wit_u.as<Fr>(), *u2lo = ctx->u2.as<Fr>(), *u2hi = u2lo + m, *halo = ctx->halo.as<Fr>();
         const Segment *d_segs = (const Segment *)pk->d_segs;
         PM_HIP(ctx, hipMemsetAsync(out + 1, 0, 2 * SS * sizeof(Fr), st));
-        if (seg_threads_512())
-            hipLaunchKernelGGL((k_seg_base<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, u, wit_u, u2lo, u2hi, halo, x1, laneP, laneQ, out + 1,
-                               out + 1 + SS);
-        else
-            hipLaunchKernelGGL((k_seg_base<P, 1024>), dim3((unsigned)S), dim3(1024), 0, st, d_segs, sd, u, wit_u, u2lo, u2hi, halo, x1, laneP, laneQ,
-                               out + 1, out + 1 + SS);
+        hipLaunchKernelGGL((k_seg_base<P, SEG_LANES>), dim3((unsigned)S), dim3(SEG_LANES), 0, st, d_segs, sd, u, wit_u, u2lo, u2hi, halo, x1, laneP, laneQ,
+                           out + 1, out + 1 + SS);
         PM_HIP(ctx, hipGetLastError());
     }
     std::vector<Fr> mine(rec);
@@ -1008,10 +997,8 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
         hipLaunchKernelGGL(k_seg_chain<P>, dim3(1), dim3(CHAIN_THREADS), 0, st, (const SegRefDev *)pk->d_all_segs, (unsigned)T, (const Fr *)d_hall, rec, SS,
                            nc, x1, pow_u64<P>(x1, pk->max_seg), pk->max_seg, n, sigma, q, carry, d_rem);
         PM_HIP(ctx, hipGetLastError());
-        if (seg_threads_512()) hipLaunchKernelGGL((k_seg_expand<P, 512>), dim3((unsigned)S), dim3(512), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
-                                                  (const Fr *)laneP, (const Fr *)laneQ, (const Fr *)carry, qv);
-        else hipLaunchKernelGGL((k_seg_expand<P, 1024>), dim3((unsigned)S), dim3(1024), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
-                                (const Fr *)laneP, (const Fr *)laneQ, (const Fr *)carry, qv);
+        hipLaunchKernelGGL((k_seg_expand<P, SEG_LANES>), dim3((unsigned)S), dim3(SEG_LANES), 0, st, d_segs, sd, nc, u, wit_u, u2lo, u2hi, halo, x1,
+                           (const Fr *)laneP, (const Fr *)laneQ, (const Fr *)carry, qv);
         PM_HIP(ctx, hipGetLastError());
         PM_HIP(ctx, hipMemcpyAsync(h_rem, d_rem, sizeof(Fr), hipMemcpyDeviceToHost, st));      // lands before the MSM's final synchronisation
     }
@@ -1023,35 +1010,9 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
             uint64_t inf;
         } mine3;
         int inf_l = 1;
-        // PM_MSM_SPLIT_D=1 (experiment): the quotient MSM as two half-length pipelines enqueued back to back on the helper
-        // context and on this one, like [a]_1 / [c]_1 of phase 1 -- each half's sort front end, tail and bucket reduction under
-        // the other's accumulation, for a second bucket set to reduce
-        const bool split_d = [] { const char *e = getenv("PM_MSM_SPLIT_D"); return e && e[0] == '1'; }();
-        if (split_d && pk->tables[2].c && !pk->tables[2].wide && (ctx->aux || pm_ctx_create(ctx->device, &ctx->aux) == PM_OK)) {
-            pm_ctx *aux = ctx->aux;
-            const uint64_t len = pk->res_cnt[2], half = len / 2;
-            timing_reset(aux);
-            PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
-            PM_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0));
-            uint64_t xy2[sizeof(Affine<C>) / 8];
-            int inf2 = 1;
-            int s1 = msm_resident_begin<C>(aux, pk, 2, qv, 0, half);
-            const int s2 = s1 == PM_OK ? msm_resident_begin<C>(ctx, pk, 2, qv, half, len - half) : (int)PM_OK;
-            const int e2 = s1 == PM_OK && s2 == PM_OK ? msm_resident_end<C>(ctx, mine3.xy, &inf_l) : (int)PM_OK;
-            if (s1 == PM_OK) s1 = msm_resident_end<C>(aux, xy2, &inf2);
-            timing_flush(aux);
-            for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += aux->timing_ms[s];
-            if (s1 != PM_OK) { ctx->err = aux->err; return s1; }
-            PM_TRY(s2);
-            PM_TRY(e2);
-            uint64_t two[2 * (sizeof(Affine<C>) / 8)];
-            int infs2[2] = {inf_l, inf2};
-            memcpy(two, mine3.xy, sizeof(Affine<C>));
-            memcpy(two + sizeof(Affine<C>) / 8, xy2, sizeof(Affine<C>));
-            PM_TRY(pm_g1_sum(C::ID, two, infs2, 2, mine3.xy, &inf_l));
-        } else {
-            PM_TRY(msm_resident<C>(ctx, pk, 2, qv, mine3.xy, &inf_l));
-        }
+        // (Two half-length pipelines with a bucket set each lost 0.6 ms per rank at N = 8: profiles/r03_n_*; the chunked sort of
+        // PM_OPT_MSM_CHUNKS keeps ONE bucket set.)
+        PM_TRY(msm_resident<C>(ctx, pk, 2, qv, mine3.xy, &inf_l));
         hp.mark("expand+msm_d");
         if (!h_rem->is_zero()) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);   // prover.rs:221 -- H_0 is the same value on every rank
         mine3.inf = (uint64_t)inf_l;

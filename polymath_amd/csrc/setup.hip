@@ -313,7 +313,7 @@ static void tables_layout(MsmTables &t, unsigned nwin) {
     t.c = base + (rem ? 1 : 0);
 }
 
-MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits) {
+MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits, unsigned force_c) {
     (void)scalar_bits;
     MsmTables best_t;
     double best = 1e300;
@@ -329,10 +329,8 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
         double cost = acc + (double)n_msm * (3.3e6 + 3.3 * NB);
         if (cost < best) { best = cost; best_t = t; }
     }
-    if (const char *e = getenv("PM_TABLE_C")) {   // developer knob for tuning sweeps: widest window
-        unsigned c = (unsigned)atoi(e);
-        if (c >= 4 && c <= 24) tables_layout(best_t, (256 + c - 1) / c);   // 24: the 11-window experiment (profiles/r02_levers_*.jsonl)
-    }
+    // PM_OPT_TABLE_WINDOW_BITS (developer knob for tuning sweeps): widest window; 24 = the 11-window experiment (profiles/r02_levers_*.jsonl)
+    if (force_c >= 4 && force_c <= 24) tables_layout(best_t, (256 + force_c - 1) / force_c);
     best_t.stride = resident_points;
     return best_t;
 }

@@ -26,3 +26,17 @@ def gpu_ctx():
     ctx = api.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(autouse=True)
+def _gpu_ctx_options_restored(request):
+    """The session's GPU context is shared: whatever pm_ctx_set_option calls a test makes are undone after it."""
+    if "gpu_ctx" not in request.fixturenames:
+        yield
+        return
+    from polymath_amd import api
+    ctx = request.getfixturevalue("gpu_ctx")
+    before = {k: ctx.get_option(k) for k in api.OPTIONS}
+    yield
+    for k, v in before.items():
+        ctx.set_option(k, v)

@@ -26,6 +26,31 @@ def test_header_symbols_exported():
     assert sorted(api.EXPORTS) == syms
 
 
+def test_integration_md_binds_every_symbol():
+    """INTEGRATION.md's `extern "C"` block (what a Rust maintainer would paste) names exactly the header's entry points, and the
+    counts quoted in its prose are the real one."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    bound = sorted(set(re.findall(r"pub fn (pm_[a-z0-9_]+)", text)))
+    syms = declared_symbols()
+    assert bound == syms
+    for m in re.finditer(r"(\d+) (?:entry points|symbols)", text):
+        assert int(m.group(1)) == len(syms), m.group(0)
+
+
+def test_no_getenv_on_the_proving_path():
+    """Modes are per-context options (pm_ctx_set_option): the library reads the environment only for a new context's
+    defaults and three process-wide developer aids -- never per proof (at most 8 sites)."""
+    sites = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "polymath_amd")):
+        for f in files:
+            if f.endswith((".hip", ".cuh", ".h", ".hpp")):
+                for ln, line in enumerate(open(os.path.join(dirpath, f), errors="ignore"), 1):
+                    if "getenv(" in line:
+                        sites.append((f, ln))
+    assert len(sites) <= 8, sites
+    assert {f for f, _ in sites} <= {"api.hip", "comm.hip", "internal.h"}, sites
+
+
 def test_no_cpu_fallback_without_gpu():
     from polymath_amd import api
     L = api.load_library()

@@ -5,7 +5,7 @@ Everything goes through the C ABI; integer arithmetic, exact equality."""
 import numpy as np
 import pytest
 
-from helpers import rand_fr_limbs
+from helpers import TABLES_OPT, rand_fr_limbs
 from oracle import driver as DR
 from oracle.pyref import circuits as CI, transcripts as T
 from oracle.pyref.fields import CURVES
@@ -37,13 +37,13 @@ def _accepts(curve, vk, proof, public_inputs, tname="merlin"):
 @pytest.mark.parametrize("log_nr,tables", [(16, "1"), (16, "0"), (16, "wide"), (18, "1"), (18, "0"), (18, "wide")])
 def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, log_nr, tables, monkeypatch):
     """2^16-100 and 2^18-100 synthetic gates (n = 2^17 / 2^19: three-pass NTT, per-MSM window tables with 12-13 windows,
-    three-level sort, two-level bucket reduction), both curves, with the key's tables, with PM_TABLES=0 (the per-window
-    pipeline) and with PM_TABLES=wide (no tables, one bucket set per window on the table pipeline's kernels: what a key whose
+    three-level sort, two-level bucket reduction), both curves, with the key's tables, with PM_OPT_TABLES = off (the per-window
+    pipeline) and = wide (no tables, one bucket set per window on the table pipeline's kernels: what a key whose
     tables do not fit HBM runs -- the 10n-pair [d]_1 of a 2^24-gate circuit on one GPU).
     The CPU restatement's key is seeded with the GPU's exported bases (their parity is tested at mid size: the CPU
     setup would take minutes here); proof, challenges and all 8 intermediate vectors must be identical."""
     import os
-    monkeypatch.setenv("PM_TABLES", tables)
+    gpu_ctx.set_option("tables", TABLES_OPT[tables])        # read by pm_pk_generate below; restored by conftest
     from polymath_amd import circuits as PC
     from polymath_amd.polymath import Polymath
     c = CURVES[curve]
@@ -136,11 +136,48 @@ def test_config_bn254_2p20():
     assert all(p[3] for p in plans)                                  # all three MSMs on window tables
 
 
+# ------------------------------------------------------------------ chunked sort of the table pipeline (round 4)
+@pytest.mark.parametrize("curve", CURVE_LIST)
+def test_msm_chunked_sort_one_bucket_set_vs_oracle(gpu_ctx, oracle, api, curve):
+    """PM_OPT_MSM_CHUNKS (msm.hip: msm_piece_tables): the pairs of a table-mode MSM sorted in K slices into ONE bucket set, slice
+    k + 1's sort under slice k's accumulation, the first task of every bucket continuing from the previous slice's partial.
+    2^20 + 4321 pairs (ragged slices), K = 1, 2, 3, 5 and 8, against the CPU oracle's point:
+      * uniform scalars;
+      * scalars that are zero in the second half of the pairs -- later slices have NO entries, every bucket's sum is only
+        carried forward (k_scan_tiles: prev_task_off) -- and zero in the FIRST half (the first slice is empty);
+      * one scalar value for all pairs: every window's digit lands in one bucket (thousands of tasks per slice, folded to one
+        record between the slices: fold_hot_buckets with fold_min = 1) -- and two values alternating by halves."""
+    n = (1 << 20) + 4321
+    bases = api.Bases.multiples(gpu_ctx, curve, n)
+    bases.precompute()
+    hb = bases.download()
+    uni = rand_fr_limbs(curve, n, 9191)
+    tail_zero, head_zero = uni.copy(), uni.copy()
+    tail_zero[n // 2:] = 0
+    head_zero[:n // 2 + 17] = 0
+    one_value = np.repeat(uni[:1], n, axis=0)
+    two_values = one_value.copy()
+    two_values[n // 2:] = uni[1]
+    for name, sc in (("uniform", uni), ("tail zero", tail_zero), ("head zero", head_zero), ("one value", one_value), ("two values", two_values)):
+        ref, rinf = oracle.msm(curve, hb, sc, 16)
+        for K in (1, 2, 3, 5, 8):
+            gpu_ctx.set_option("msm_chunks", K)
+            out, inf = bases.msm(sc)
+            assert inf == rinf and np.array_equal(out, ref), (name, K)
+    # shorter than the chunking threshold: the option is ignored, same point
+    gpu_ctx.set_option("msm_chunks", 4)
+    m = 300000
+    out, inf = bases.msm(uni[:m])
+    ref, rinf = oracle.msm(curve, hb[:m], uni[:m], 16)
+    assert inf == rinf and np.array_equal(out, ref)
+    bases.free()
+
+
 # ---------------------------------------------------------------------------- piece-split MSM at small size
 @pytest.mark.parametrize("curve", CURVE_LIST)
 @pytest.mark.parametrize("tables", [False, True])
 def test_msm_piece_split_paths_vs_oracle(gpu_ctx, oracle, api, curve, tables, monkeypatch):
-    """PM_MSM_MAX_PIECE_LOG=18: a 2^20-pair (and a ragged 2^20 - 12345) MSM runs as 4 pieces summed on the host, on the
+    """PM_OPT_MSM_MAX_PIECE_LOG = 18: a 2^20-pair (and a ragged 2^20 - 12345) MSM runs as 4 pieces summed on the host, on the
     per-window pipeline and on the window-table pipeline (tb.base_index += off); equal to the one-piece result and to
     the CPU restatement."""
     n = 1 << 20
@@ -151,12 +188,12 @@ def test_msm_piece_split_paths_vs_oracle(gpu_ctx, oracle, api, curve, tables, mo
     whole, inf0 = bases.msm(sc)
     ref, _ = oracle.msm(curve, bases.download(), sc, 16)
     assert inf0 == 0 and np.array_equal(whole, ref)
-    monkeypatch.setenv("PM_MSM_MAX_PIECE_LOG", "18")
+    gpu_ctx.set_option("msm_max_piece_log", 18)
     split, inf1 = bases.msm(sc)
     assert inf1 == 0 and np.array_equal(split, whole)
     m = n - 12345
     ragged, _ = bases.msm(sc[:m], offset=777)
-    monkeypatch.delenv("PM_MSM_MAX_PIECE_LOG")
+    gpu_ctx.set_option("msm_max_piece_log", 27)
     one, _ = bases.msm(sc[:m], offset=777)
     assert np.array_equal(ragged, one)
     bases.free()
@@ -164,7 +201,7 @@ def test_msm_piece_split_paths_vs_oracle(gpu_ctx, oracle, api, curve, tables, mo
 
 def test_prove_with_piece_split_msms_equals_whole(gpu_ctx, oracle, api, monkeypatch):
     """A whole proof (5000 gates) whose three merged MSMs are forced through 2^12-pair pieces -- with tables for all
-    three, and with PM_TABLES=0 -- gives the same bytes as the unsplit run."""
+    three, without tables and in the wide mode -- gives the same bytes as the unsplit run."""
     from polymath_amd import circuits as PC
     from polymath_amd.polymath import Polymath
     curve = "bls12_381"
@@ -173,14 +210,14 @@ def test_prove_with_piece_split_msms_equals_whole(gpu_ctx, oracle, api, monkeypa
     pm = Polymath(curve, "keccak256", ctx=gpu_ctx)
     first = None
     for tables in ("1", "0", "wide"):
-        monkeypatch.setenv("PM_TABLES", tables)
+        gpu_ctx.set_option("tables", TABLES_OPT[tables])
         pk = pm.setup(lc, 0xABCDEF, 0x123457)
         ref = pm.prove_native(pk, lc.inst_limbs, lc.wit_limbs, [5, 7])
         first = first or ref
         assert ref == first
-        monkeypatch.setenv("PM_MSM_MAX_PIECE_LOG", "12")
+        gpu_ctx.set_option("msm_max_piece_log", 12)
         assert pm.prove_native(pk, lc.inst_limbs, lc.wit_limbs, [5, 7]) == ref
-        monkeypatch.delenv("PM_MSM_MAX_PIECE_LOG")
+        gpu_ctx.set_option("msm_max_piece_log", 27)
         pk.free()
 
 
@@ -217,7 +254,10 @@ def test_three_contexts_prove_concurrently_on_one_resident_key(oracle):
     """include/polymath_hip.h, threading note: a pm_pk is immutable and shareable, a pm_ctx runs one proof at a time.  Three
     host threads, each with its own context (stream, workspaces, helper context of the overlapped [a]_1 MSM), prove
     different r_a against the SAME resident key at the same time, six proofs each: every proof equals the one the CPU
-    oracle computes for that r_a (2^16 - 100 gates: three-level sort, window tables, two transform passes)."""
+    oracle computes for that r_a (2^16 - 100 gates: three-level sort, window tables, two transform passes).
+    Each context runs in a DIFFERENT mode, chosen through pm_ctx_set_option (the library keeps no process-wide state, like the
+    reference's `Polymath<E, T>`, lib.rs:44-50): context 0 the defaults ([a]_1 / [c]_1 concurrently, the quotient MSM's sort in
+    two chunks), context 1 everything back to back in one piece, context 2 every MSM in 2^14-pair pieces summed on the host."""
     import threading
     from polymath_amd import circuits as PC
     from polymath_amd.polymath import Polymath
@@ -230,6 +270,13 @@ def test_three_contexts_prove_concurrently_on_one_resident_key(oracle):
     ras = [[g.fr(c.r), g.fr(c.r)] for _ in range(K)]
     want = [_oracle_reference(oracle, curve, lc, x, z, ra)[0] for ra in ras]
     pms = [Polymath(curve, "merlin", device=0) for _ in range(K)]
+    pms[0].ctx.set_option("msm_chunks", 2)
+    pms[1].ctx.set_option("msm_overlap", 0)
+    pms[1].ctx.set_option("msm_chunks", 1)
+    pms[2].ctx.set_option("msm_max_piece_log", 14)
+    assert [p.ctx.get_option("msm_overlap") for p in pms] == [1, 0, 1] and pms[2].ctx.get_option("msm_max_piece_log") == 14
+    with pytest.raises(Exception):
+        pms[0].ctx.set_option("msm_chunks", 99)             # out of range: PM_ERR_INVALID_ARG
     pk = pms[0].setup(lc, x, z)
     views = [pk] + [pk.view(p.ctx) for p in pms[1:]]
     got, errs = [[None] * ROUNDS for _ in range(K)], [None] * K

@@ -269,8 +269,8 @@ def _prove_both(api, gpu_ctx, oracle, curve, q, inst, wit, seed, compare_bases=T
 @pytest.mark.parametrize("tables", ["1", "0"])
 def test_prove_synthetic_mid_size_vs_oracle(gpu_ctx, oracle, api, curve, tables, monkeypatch):
     """SURVEY.md §8d synthetic R1CS, 3000 gates -> n = 8192, both curves; with the key's window tables
-    (default) and with PM_TABLES=0 (per-window Pippenger)."""
-    monkeypatch.setenv("PM_TABLES", tables)
+    (default) and with PM_OPT_TABLES = off (per-window Pippenger)."""
+    gpu_ctx.set_option("tables", {"1": "auto", "0": "off"}[tables])       # restored by conftest
     q, inst, wit = CI.synthetic_r1cs(CURVES[curve], 3000)
     _prove_both(api, gpu_ctx, oracle, curve, q, inst, wit, 77)
 
@@ -644,16 +644,12 @@ def test_reference_bench_circuit_skew(oracle):
     pk.free()
     # the same skew through the WIDE mode (no tables, one bucket set per window: the hot bucket of every window is folded inside
     # its own set) and through the per-window pipeline: identical bytes
-    import os
-    for mode in ("wide", "0"):
-        os.environ["PM_TABLES"] = mode
-        try:
-            pk2 = pm.setup((r1cs, inst, wit), x, z)
-            assert not pk2.msm_plan(1)[3]
-            assert pm.prove_limbs(pk2, inst, xl, wl, r_a).to_bytes() == proof.to_bytes(), mode
-            pk2.free()
-        finally:
-            del os.environ["PM_TABLES"]
+    for mode in ("wide", "off"):
+        pm.ctx.set_option("tables", mode)                  # the test's own context
+        pk2 = pm.setup((r1cs, inst, wit), x, z)
+        assert not pk2.msm_plan(1)[3]
+        assert pm.prove_limbs(pk2, inst, xl, wl, r_a).to_bytes() == proof.to_bytes(), mode
+        pk2.free()
 
 
 def test_phase1_device_resident_assignment_equals_host(gpu_ctx, oracle, api):
@@ -774,7 +770,7 @@ def test_msm_equal_bucket_sums_take_the_doubling_paths(gpu_ctx, oracle, api, cur
     of the four-lane cooperative additions of levels 1 / final (msm.hip: xyzz28_add_quad returns false on every lane of the
     quad, all four take the complete formulas).  Also with one scalar value only (all entries in one bucket: the hot-bucket
     fold).  Same point as the CPU oracle's MSM."""
-    monkeypatch.setenv("PM_TABLE_C", "16")                 # 2^15 buckets: the two-level reduction (>= 4096 buckets)
+    gpu_ctx.set_option("table_window_bits", 16)            # 2^15 buckets: the two-level reduction (>= 4096 buckets)
     n, nb = 1 << 17, 1 << 15
     g = oracle.g1_multiples(curve, 1)
     hb = np.repeat(g, n, axis=0)

@@ -126,13 +126,16 @@ def _oracle_reference(oracle, curve, lc, x, z, r_a, transcript="merlin"):
     return SE.ser_proof(c, po), opk
 
 
-def _sharded_proofs(curve, lc, x, z, r_a, N, transcript="merlin", device_assignment=False):
+def _sharded_proofs(curve, lc, x, z, r_a, N, transcript="merlin", device_assignment=False, options=None):
+    """options: {pm_option name: value} set on every rank's context (pm_ctx_set_option) before its key is generated"""
     from polymath_amd import api
     from polymath_amd.polymath import Polymath
     comms = api.Comm.local_group(N)
     pms = [Polymath(curve, transcript, device=0) for _ in range(N)]
     for r in range(N):
         pms[r].ctx.set_comm(comms[r])
+        for k, v in (options or {}).items():
+            pms[r].ctx.set_option(k, v)
     pks = [pms[r].setup(lc, x, z, shard_rank=r, shard_count=N, layout="vector") for r in range(N)]
     proofs = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms)
     return pms, pks, comms, proofs
@@ -203,7 +206,7 @@ def test_vector_sharded_proof_equals_single_gpu(oracle, curve, N):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", [2, 8])
 def test_vector_sharded_w_transform_beside_u_chain(oracle, monkeypatch, N):
-    """PM_NTT_OVERLAP=1 (opt-in): w's distributed transform on the helper stream beside u's chain, its all-to-all issued
+    """PM_OPT_NTT_OVERLAP = 1 (the default since round 4): w's distributed transform on the helper stream beside u's chain, its all-to-all issued
     between u's exchanges on a second stream of the same communicator.  Three proofs in a row on the same contexts (the
     helper's buffers and events are reused) equal the CPU oracle's bytes; w's coefficients equal the oracle's tap; and the
     switch can be turned off again in the same process."""
@@ -214,8 +217,7 @@ def test_vector_sharded_w_transform_beside_u_chain(oracle, monkeypatch, N):
     g = PC.SplitMix64(0x0E11 + N)
     x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
     oracle_proof, opk = _oracle_reference(oracle, curve, lc, x, z, r_a)
-    monkeypatch.setenv("PM_NTT_OVERLAP", "1")
-    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, options={"ntt_overlap": 1})
     assert all(p == oracle_proof for p in proofs)
     n = pks[0].n
     for w in (2, 3):                                        # u, w: blocked coefficient layout
@@ -230,7 +232,8 @@ def test_vector_sharded_w_transform_beside_u_chain(oracle, monkeypatch, N):
     for ra, want in ((r_b, oracle_b), (r_a, oracle_proof)):
         out = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, ra), comms)
         assert all(p == want for p in out)
-    monkeypatch.setenv("PM_NTT_OVERLAP", "0")
+    for pm in pms:
+        pm.ctx.set_option("ntt_overlap", 0)
     out = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_b), comms)
     assert all(p == oracle_b for p in out)
     for pk in pks:
@@ -240,8 +243,8 @@ def test_vector_sharded_w_transform_beside_u_chain(oracle, monkeypatch, N):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tables", ["wide", "0"])
 def test_vector_sharded_without_window_tables(oracle, monkeypatch, tables):
-    """The shards' MSMs on the two table-less pipelines (PM_TABLES=wide: one bucket set per window, what a shard whose
-    tables do not fit HBM runs; PM_TABLES=0: the per-window pipeline): 4 ranks, both MSMs of phase 1 in flight together
+    """The shards' MSMs on the two table-less pipelines (PM_OPT_TABLES = wide: one bucket set per window, what a shard whose
+    tables do not fit HBM runs; = off: the per-window pipeline): 4 ranks, both MSMs of phase 1 in flight together
     (msm_begin / msm_end), the same bytes as the CPU oracle."""
     from polymath_amd import circuits as PC
     curve, N = "bls12_381", 4
@@ -250,8 +253,7 @@ def test_vector_sharded_without_window_tables(oracle, monkeypatch, tables):
     g = PC.SplitMix64(0x71DE)
     x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
     oracle_proof, _ = _oracle_reference(oracle, curve, lc, x, z, r_a)
-    monkeypatch.setenv("PM_TABLES", tables)
-    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, options={"tables": {"wide": "wide", "0": "off"}[tables]})
     assert all(not pk.msm_plan(k)[3] for pk in pks for k in range(3))          # no MSM of any shard holds tables
     assert all(p == oracle_proof for p in proofs)
     out = _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms)
@@ -262,7 +264,7 @@ def test_vector_sharded_without_window_tables(oracle, monkeypatch, tables):
 
 @pytest.mark.gpu
 def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
-    """Tiny sub-segments (PM_MAX_SEG_LOG=6: hundreds of segments per rank, several per block), a circuit with 12 public
+    """Tiny sub-segments (PM_OPT_MAX_SEG_LOG = 6: hundreds of segments per rank, several per block), a circuit with 12 public
     inputs (2 m0 > 16: the witness-only part of u takes its own distributed transform), all three transcripts; an
     unsatisfied witness makes EVERY rank return PM_ERR_REMAINDER_NONZERO (no rank is left waiting in a collective)."""
     from polymath_amd import circuits as PC
@@ -270,7 +272,6 @@ def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
     from polymath_amd import api
     curve, N = "bls12_381", 4
     c = CURVES[curve]
-    monkeypatch.setenv("PM_MAX_SEG_LOG", "6")
     f = Field(curve)
     cs = ConstraintSystem(c.r)
     g = PC.SplitMix64(1212)
@@ -285,11 +286,12 @@ def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
     lc = LimbCircuit(f, r1cs.m0, r1cs.mw, r1cs.nr, (_csr(f, r1cs.a), _csr(f, r1cs.b), _csr(f, r1cs.c)), f.fr_limbs(cs.instance), f.fr_limbs(cs.witness))
     x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
     for tname in ("merlin", "keccak256", "blake3"):
-        monkeypatch.setenv("PM_NTT_OVERLAP", "1" if tname == "keccak256" else "0")   # the opt-in two-stream transforms on this shape too
         ref_pm = Polymath(curve, tname, device=0)
         ref_pk = ref_pm.setup(lc, x, z)
         ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
-        pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, transcript=tname)
+        # the two-stream transforms on (keccak256) and off on this shape too
+        pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, transcript=tname,
+                                                  options={"max_seg_log": 6, "ntt_overlap": 1 if tname == "keccak256" else 0})
         assert all(p == ref for p in proofs), tname
         ref_pk.free()
     bad = lc.wit_limbs.copy()
@@ -697,8 +699,7 @@ def test_config_2p24_eight_ranks_vector_sharded(monkeypatch):
     ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
     ref_pk.free()
     ref_pm.ctx.close()
-    monkeypatch.setenv("PM_TABLES", "0")
-    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N)
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, options={"tables": "off"})
     assert all(p == ref for p in proofs)
     for pk in pks:
         pk.free()

@@ -15,9 +15,12 @@ ap.add_argument("--len", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--curve", default="bls12_381")
 ap.add_argument("--tables", action="store_true", help="pm_bases_precompute: window tables")
+ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="pm_ctx_set_option, e.g. --opt table_window_bits=24 --opt msm_task_len=256")
 a = ap.parse_args()
 n = a.len or (1 << a.log_len)
 ctx = api.Context(0)
+for kv in a.opt:
+    ctx.set_option(kv.split("=", 1)[0], int(kv.split("=", 1)[1]))
 t0 = time.time()
 bases = api.Bases.multiples(ctx, a.curve, n)
 gen_s = time.time() - t0
@@ -41,5 +44,5 @@ for rep in range(a.reps + 1):
 best = min(r[0] for r in res)
 tm = res[-1][1]
 print(json.dumps({"curve": a.curve, "len": n, "best_ms": best * 1e3, "pairs_per_sec": n / best, "gen_s": gen_s, "tables": a.tables, "tables_s": tbl_s,
-                  "env": {k: v for k, v in os.environ.items() if k.startswith("PM_MSM")},
+                  "options": {k: ctx.get_option(k) for k in api.OPTIONS},
                   "stage_ms": {k: round(v, 3) for k, v in tm.items() if k.startswith("msm")}}))

@@ -39,4 +39,4 @@ for lg in (int(v) for v in a.logs.split(",")):
     print(json.dumps({"curve": a.curve, "log_n": lg, "fwd_ms": best[False] * 1e3, "inv_ms": best[True] * 1e3,
                       "algorithmic_GBps_fwd": 64.0 * n / best[False] / 1e9, "algorithmic_GBps_inv": 64.0 * n / best[True] / 1e9,
                       "hbm_frac_fwd": 64.0 * n / best[False] / 1e9 / 8000.0, "round_trips_ok": ok,
-                      "fused": os.environ.get("PM_NTT_FUSED", "1") != "0", "gpu_ms_last": ctx.timings()["ntt"]}))
+                      "gpu_ms_last": ctx.timings()["ntt"]}))

@@ -1,16 +1,15 @@
 #!/usr/bin/env python3
 """Per-rank cost of an N-GPU PM_SHARD_VECTOR proof, emulated on ONE GPU (no 8-GPU node needed): the N ranks run as N
-threads over pm_comm_local_create with PM_LOCAL_COMM_SERIALIZE=1 -- between collectives only one rank runs at a time, so
+threads over pm_comm_local_create with pm_comm_local_set_serialize -- between collectives only one rank runs at a time, so
 every rank's kernels take what they would take alone; the exchanges are device-to-device copies (their xGMI cost is NOT
 in the number).  per-rank ms = wall time of K proofs / (K N).
   python tools/shard_emulation.py --ranks 8 --log-constraints 20 --steps 3 [--layout pairs]"""
 import argparse, json, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PM_LOCAL_COMM_SERIALIZE"] = "1"
-# PM_MSM_OVERLAP (default on): a rank enqueues its [a] and [c] MSM pipelines on two streams from ONE host thread, with no collective
+# PM_OPT_MSM_OVERLAP (default on): a rank enqueues its [a] and [c] MSM pipelines on two streams from ONE host thread, with no collective
 # in between, so the overlap happens entirely inside the rank's turn -- as it does on a GPU of its own.  (Round 2's helper THREAD
-# escaped the turnstile; the emulation then ran with PM_MSM_OVERLAP=0.)
+# escaped the turnstile; the emulation then ran with the overlap off.)
 # The N emulated ranks share ONE process, hence one set of hardware queues (ROCm default: 4); a real rank has its process's queues
 # to itself.  With 2 N streams on 4 queues a rank's two MSM streams often land on the same queue and serialise (per-rank busy time
 # bimodal: 12.0 / 13.3 ms at N = 8); 8 queues restore what a rank sees on a GPU of its own (profiles/r03_m_*).
@@ -24,7 +23,9 @@ ap.add_argument("--log-constraints", type=int, default=20)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--curve", default="bls12_381")
 ap.add_argument("--layout", default="vector")
+ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="pm_ctx_set_option on every rank's context, e.g. --opt msm_overlap=0 --opt tables=wide")
 a = ap.parse_args()
+opts = {kv.split("=", 1)[0]: (kv.split("=", 1)[1] if not kv.split("=", 1)[1].lstrip("-").isdigit() else int(kv.split("=", 1)[1])) for kv in a.opt}
 N, curve = a.ranks, a.curve
 r = FIELDS[curve]["r"]
 lc = PC.synthetic_r1cs_native(curve, (1 << a.log_constraints) - 100)
@@ -46,10 +47,12 @@ def pinned_copy(arr):
     return out
 
 
-comms = api.Comm.local_group(N)
+comms = api.Comm.local_group(N, serialize=True)
 pms = [Polymath(curve, "merlin", device=0) for _ in range(N)]
 for k in range(N):
     pms[k].ctx.set_comm(comms[k])
+    for name, value in opts.items():
+        pms[k].ctx.set_option(name, value)
 t0 = time.time()
 pks = [pms[k].setup(lc, x, z, shard_rank=k, shard_count=N, layout=a.layout) for k in range(N)]
 setup_s = time.time() - t0
@@ -82,6 +85,6 @@ assert all(p == proofs[0] for p in proofs)
 print(json.dumps({"ranks": N, "layout": a.layout, "curve": curve, "log_constraints": a.log_constraints, "steps": a.steps,
                   "emulated_ms_per_rank": dt / a.steps / N * 1e3,
                   "busy_ms_per_rank": [round(b, 3) for b in busy], "busy_ms_max_rank": max(busy), "wall_ms_per_proof_all_ranks_serialised": dt / a.steps * 1e3,
-                  "msm_overlap": os.environ.get("PM_MSM_OVERLAP", "1") != "0", "setup_s_all_ranks": setup_s, "stage_ms_rank0": {k: round(v, 3) for k, v in timings[0].items()},
+                  "options": {name: pms[0].ctx.get_option(name) for name in api.OPTIONS}, "setup_s_all_ranks": setup_s, "stage_ms_rank0": {k: round(v, 3) for k, v in timings[0].items()},
                   "stage_ms_last_rank": {k: round(v, 3) for k, v in timings[N - 1].items()},
                   "note": "exchanges are local device-to-device copies: xGMI latency / bandwidth not included", "proof": proofs[0].hex()}))
