@@ -21,7 +21,8 @@ layer falls back RCCL -> host-staged torch.distributed until one configuration c
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the MSM bucket accumulation,
 HIP-event timed on the library's stream), `cpu_baseline` (the CPU restatement oracle/cpp proving the SAME
 2^20-100-gate circuit on this box's host cores, once; "CPU restatement -- not arkworks") and
-`msm_micro` (the metric's second half: standalone resident G1 MSM pairs/s at 2^20 ... 2^26 pairs).
+`msm_micro` (the metric's second half: standalone resident G1 MSM pairs/s at 2^20 ... 2^26 pairs), `ntt_micro` (standalone
+resident transforms at 2^21, 2^22, 2^24) and `stages` (per stage ms, algorithmic GB/s / 8 TB/s, lane-mads/s / peak).
 """
 import argparse
 import json
@@ -100,7 +101,7 @@ def live_traffic(args, timeout_s=None):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pm_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic",
+               os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--msm-micro", "", "--ntt-micro", "", "--no-live-traffic",
                "--log-constraints", str(args.log_constraints), "--curve", args.curve, "--transcript", args.transcript, "--opt", "msm_overlap=0"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
@@ -161,6 +162,82 @@ def msm_micro(ctx, curve, logs, reps=3):
     return out
 
 
+NTT_MADS_PER_BUTTERFLY = 162      # one carry-free product on 9 limbs of 29 bits (81 + 81 multiplier operations)
+
+
+def ntt_micro(ctx, curve, logs, reps=5):
+    """SURVEY.md §8d per-stage report for the transforms (prover.rs:239-243, 315-328): standalone resident NTT (pm_ntt_device,
+    canonical inputs already in HBM), forward direction, at the domain sizes of the BASELINE configurations.  Algorithmic bytes =
+    64 B / element / transform (one read + one write of 32 B); the kernels are bound by the 64-bit multiplier, so the achieved
+    lane-mads/s against the measured v_mad_u64_u32 peak is reported beside the HBM fraction."""
+    import torch
+    from polymath_amd.polymath import FIELDS
+    top = FIELDS[curve]["r"] >> 192
+    out = []
+    for lg in logs:
+        n = 1 << lg
+        g = torch.Generator(device="cuda").manual_seed(lg)
+        x = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device="cuda", generator=g) * 4 + torch.randint(0, 4, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+        x[:, 3] = torch.randint(0, top, (n,), dtype=torch.int64, device="cuda", generator=g)
+        torch.cuda.synchronize()
+        best_wall, best_gpu = None, None
+        for rep in range(reps + 1):
+            t0 = time.perf_counter()
+            ctx.ntt_device(curve, x.data_ptr(), lg, False)
+            dt = time.perf_counter() - t0
+            gpu_ms = ctx.timings()["ntt"]
+            if rep and (best_wall is None or dt < best_wall):
+                best_wall, best_gpu = dt, gpu_ms
+        mads = NTT_MADS_PER_BUTTERFLY * (n // 2) * lg
+        sec = best_gpu * 1e-3
+        out.append({"log_n": lg, "ms": best_gpu, "ms_wall_incl_launch_and_sync": best_wall * 1e3,
+                    "algorithmic_GBps": 64.0 * n / sec / 1e9, "hbm_frac_algorithmic": 64.0 * n / sec / 1e9 / HBM_PEAK_GBS,
+                    "lane_mads_per_sec": mads / sec, "valu_frac": mads / sec / VALU_MAD_PEAK})
+        del x
+        torch.cuda.empty_cache()
+    return out
+
+
+def stage_report(curve, r1cs, pk, tm1, tm3, plans):
+    """"Report, per stage: achieved GB/s / 8 TB/s and achieved MAD/s / measured peak".  Stage times are the
+    HIP-event slots of ONE proof with msm_overlap = 0 (every stage alone on the chip), algorithmic bytes as §8d defines them;
+    where §8d gives no figure the definition is in the entry's `bytes_are`."""
+    n, m0, mw, nr = pk.n, r1cs.m0, r1cs.mw, r1cs.nr
+    nnz = sum(int(a.rowptr[-1]) for a in r1cs.csrs)
+    pairs = sum(p[0] for p in plans)
+    entries = sum(p[0] * p[1] for p in plans)
+    buckets = sum((1 << (p[2] - 1)) * (1 if p[3] else p[1]) for p in plans)       # one shared set with tables, one per window without
+    log_n = n.bit_length() - 1
+
+    def entry(ms, nbytes, bytes_are, **extra):
+        e = {"ms": ms, "algorithmic_bytes": nbytes, "bytes_are": bytes_are}
+        if ms and ms > 0:
+            e["algorithmic_GBps"] = nbytes / (ms * 1e-3) / 1e9
+            e["hbm_frac_algorithmic"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
+        e.update(extra)
+        return e
+    ntt_mads = 4 * NTT_MADS_PER_BUTTERFLY * (n // 2) * log_n
+    acc_ms = tm1["msm_accumulate"] + tm3["msm_accumulate"]
+    acc_mads = float(MADS_PER_MIXED_ADD[curve]) * entries
+    return {
+        "source": "HIP-event stage slots of one proof with msm_overlap = 0, outside the timed region",
+        "witness_map": entry(tm1["witness_map"], 36 * nnz + 32 * (m0 + mw) + 64 * n, "36 nnz(A,B,C) + 32 (m0 + mw) + 64 n (SURVEY.md §8d)"),
+        "ntt": entry(tm1["ntt"], 4 * 64 * n, "64 B / element / transform x the 4 size-n transforms this prover runs (u, w, and the forward / inverse pair of "
+                     "the negacyclic square; the reference's 3 size-n + 2 size-2n of prover.rs:94-96,319-325 would be 7 n elements)",
+                     lane_mads_per_sec=ntt_mads / (tm1["ntt"] * 1e-3) if tm1["ntt"] else None,
+                     valu_frac=ntt_mads / (tm1["ntt"] * 1e-3) / VALU_MAD_PEAK if tm1["ntt"] else None),
+        "pointwise_phase1": entry(tm1["poly"], 64 * 5 * n, "64 B / element over twist, square, untwist + h, and the two scalar vectors (5 n elements)"),
+        "division_scan": entry(tm3["poly"], 64 * (10 * n + 23), "64 B / element of the numerator / quotient index space (10 n + 23; SURVEY.md §8d)"),
+        "msm_sort": entry(tm1["msm_sort"] + tm3["msm_sort"], 32 * pairs + 4 * entries,
+                          "32 B scalar read per pair + 4 B sorted table index written per (pair, window) entry: the least a bucket sort moves"),
+        "msm_accumulate": entry(acc_ms, MSM_BYTES_PER_PAIR[curve] * pairs, "%d B / pair (SURVEY.md §8d)" % MSM_BYTES_PER_PAIR[curve],
+                                lane_mads_per_sec=acc_mads / (acc_ms * 1e-3) if acc_ms else None,
+                                valu_frac=acc_mads / (acc_ms * 1e-3) / VALU_MAD_PEAK if acc_ms else None),
+        "msm_reduce": entry(tm1["msm_reduce"] + tm3["msm_reduce"], 4 * 48 * buckets if curve == "bls12_381" else 4 * 32 * buckets,
+                            "one XYZZ partial per bucket read (%d buckets): chains of dependent point additions, latency-bound" % buckets),
+    }
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +249,7 @@ def parse_args():
     ap.add_argument("--cpu-baseline-log", type=int, default=0, help="0 = the headline workload itself when this box has >= 32 host threads, else 2^16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-micro", default="20,22,24,26", help="log2 lengths of the standalone resident MSM legs ('' = none)")
+    ap.add_argument("--ntt-micro", default="21,22,24", help="log2 sizes of the standalone resident NTT legs ('' = none)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure `roofline.traffic`")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="pm_ctx_set_option on the proving context before the key is generated, e.g. --opt msm_overlap=0 --opt tables=wide")
@@ -186,8 +264,12 @@ def main():
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not os.environ.get("BENCH_CHILD"):
         world_env = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
-        # the deadline of one attempt: import + synthesis + key setup + K proofs, generous; scaled with the circuit
-        deadline = int(os.environ.get("BENCH_ATTEMPT_DEADLINE_S", str(900 * (1 << max(0, args.log_constraints - 20)) + 60 * args.steps)))
+        # what ONE healthy attempt may need at most: import + synthesis + key setup + K proofs, generous, scaled with the circuit.
+        # The job as a whole lives on one clock (launch.Budget: BENCH_TOTAL_BUDGET_S, default 1 500 s, inside the driver's 1 800 s).
+        scale = 1 << max(0, args.log_constraints - 20)
+        deadline = int(os.environ.get("BENCH_ATTEMPT_DEADLINE_S", str(600 * scale + 3 * (args.steps + args.warmup) * scale + 120)))
+        if args.log_constraints > 20 and "BENCH_TOTAL_BUDGET_S" not in os.environ:
+            os.environ["BENCH_TOTAL_BUDGET_S"] = str(1500 * scale)       # larger circuits are run by hand, not by the driver
         if under_launcher and (world_env > 1 or os.environ.get("BENCH_FORCE_VECTOR")):
             if world_env != args.gpus and world_env > 1:
                 raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world_env))
@@ -224,7 +306,8 @@ def worker(args):
     def stage(name, limit_s):
         if wd:
             wd.stage_begin(name, limit_s)
-    stage("import torch + rendezvous", 600 + (600 if int(os.environ.get("BENCH_ATTEMPT", "0")) > 0 else 0))
+    attempt_limit = float(os.environ.get("BENCH_ATTEMPT_LIMIT_S", "1e9"))   # the supervisor kills the attempt then anyway
+    stage("import torch + rendezvous", min(600.0, attempt_limit))
     import datetime
     import numpy as np
     import torch
@@ -248,7 +331,7 @@ def worker(args):
             # supervisors notice the previous attempt's failure at different times -- the rank that failed at once, its peers when
             # their collective deadline passed -- so the rendezvous waits much longer than any collective does.
             store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0,
-                                  timeout=datetime.timedelta(seconds=600), wait_for_workers=True)
+                                  timeout=datetime.timedelta(seconds=max(30.0, min(300.0, attempt_limit / 3))), wait_for_workers=True)
             dist.init_process_group(backend, store=store, rank=rank, world_size=world, timeout=pg_timeout, **kw)
         else:
             dist.init_process_group(backend, timeout=pg_timeout, **kw)
@@ -392,6 +475,7 @@ def worker(args):
     pm.ctx.set_option("msm_overlap", overlap_was)
     assert proof_serial == proof_b
     acc_serial_ms = pm.phase_timings[0]["msm_accumulate"] + pm.phase_timings[2]["msm_accumulate"]
+    tm1_serial, tm3_serial = dict(pm.phase_timings[0]), dict(pm.phase_timings[2])
     if os.environ.get("BENCH_PHASES"):             # dev hook: stage timings of all three phases (stderr)
         log(rank, "phase-by-phase proof %.2f ms; phases:" % ms_python_glue)
         for i, tm in enumerate(pm.phase_timings):
@@ -464,6 +548,7 @@ def worker(args):
                      "frac": (mads_rank / acc_s / VALU_MAD_PEAK) if acc_s > 0 else None,
                      "note": "the real bound of this kernel: mads are 76 % of its instruction stream (3 542 of 4 682 per mixed add); "
                              "SQ counters (profiles/r02_pmc_valu_k_accumulate.json): 0.95 of the VALU issue slots, clock 1.98 GHz under this load"},
+            "stages": stage_report(curve, r1cs, pk, tm1_serial, tm3_serial, plans),
             "proof_bytes": proof_b.hex(),
             # Polymath::verify (verifier.rs:19-62) on the timed proof, by the library's own CPU verifier (pm_host_verify)
             "proof_verified": bool(pm.verify(pm.make_vk(pk, x_trap, z_trap), inst[1:], proof_b)),
@@ -490,8 +575,12 @@ def worker(args):
                     gp = pm.prove_native(pk_s, lc_s.inst_limbs, lc_s.wit_limbs, r_a)
                     out["cpu_baseline"] = cpu_baseline(curve, cb_log, lc_s, pk_s, r_a, gp, args.transcript)
                     pk_s.free()
-            if args.msm_micro:
+            if args.msm_micro or args.ntt_micro:
                 pk.free()                                        # give the HBM back: the 2^26 leg holds 100 GB of window tables
+            if args.ntt_micro:
+                log(rank, "standalone resident NTT legs: 2^{%s} points ..." % args.ntt_micro)
+                out["ntt_micro"] = ntt_micro(pm.ctx, curve, [int(v) for v in args.ntt_micro.split(",")])
+            if args.msm_micro:
                 log(rank, "standalone resident MSM legs: 2^{%s} pairs ..." % args.msm_micro)
                 out["msm_micro"] = msm_micro(pm.ctx, curve, [int(v) for v in args.msm_micro.split(",")])
         stage("final agreement", 120)

@@ -120,9 +120,7 @@ typedef enum pm_option {
                                    * workspaces are left out of the HBM granted to window tables.  Default 1 (PM_INFLIGHT_CONTEXTS). */
     PM_OPT_MSM_TASK_LEN = 6,      /* entries of one bucket-accumulation task; 0 = twice the mean bucket load.  Default 0 (PM_MSM_SEG). */
     PM_OPT_TABLE_WINDOW_BITS = 7, /* (key) widest window of the table sets; 0 = the cost model of tables_plan.  Default 0 (PM_TABLE_C). */
-    PM_OPT_MSM_CHUNKS = 8,        /* the quotient MSM [d]_1 (prover.rs:229) is sorted in this many pair chunks, chunk k + 1's sort
-                                   * hidden under chunk k's accumulation, ONE bucket set; 1 = one sort.  Default 2 (PM_MSM_CHUNKS). */
-    PM_NUM_OPTIONS = 9
+    PM_NUM_OPTIONS = 8
 } pm_option;
 typedef enum pm_tables_mode {
     PM_TABLES_OFF = 0,      /* no window tables, no wide mode: every MSM on the per-window pipeline */
@@ -130,7 +128,8 @@ typedef enum pm_tables_mode {
     PM_TABLES_WIDE = 2,     /* the wide mode for every MSM (test / tuning) */
     PM_TABLES_NO_WIDE = 3   /* tables where they fit, the per-window pipeline for the others */
 } pm_tables_mode;
-/* PM_ERR_INVALID_ARG for an unknown option or a value outside its range; PM_ERR_STATE while a proof is in flight. */
+/* PM_ERR_INVALID_ARG for an unknown option or a value outside its range.  A change takes effect at the next phase (next MSM,
+ * next key) the context starts; call it from the thread that drives the context. */
 int pm_ctx_set_option(pm_ctx *ctx, int option, long long value);
 int pm_ctx_get_option(const pm_ctx *ctx, int option, long long *value);
 

@@ -59,7 +59,7 @@ EXPORTS = [
 ]
 # pm_option / pm_tables_mode (include/polymath_hip.h)
 OPTIONS = {"msm_overlap": 0, "ntt_overlap": 1, "tables": 2, "msm_max_piece_log": 3, "max_seg_log": 4, "inflight_contexts": 5,
-           "msm_task_len": 6, "table_window_bits": 7, "msm_chunks": 8}
+           "msm_task_len": 6, "table_window_bits": 7}
 TABLES_MODES = {"off": 0, "auto": 1, "wide": 2, "no_wide": 3}
 SHARD_PAIRS, SHARD_VECTOR = 0, 1
 LAYOUTS = {"pairs": SHARD_PAIRS, "vector": SHARD_VECTOR, 0: 0, 1: 1}

@@ -85,7 +85,6 @@ static const OptionSpec OPTION_SPECS[PM_NUM_OPTIONS] = {
     /* PM_OPT_INFLIGHT_CONTEXTS */ {"PM_INFLIGHT_CONTEXTS", 1, 1, 64},
     /* PM_OPT_MSM_TASK_LEN      */ {"PM_MSM_SEG", 0, 0, 1 << 20},
     /* PM_OPT_TABLE_WINDOW_BITS */ {"PM_TABLE_C", 0, 0, 24},
-    /* PM_OPT_MSM_CHUNKS        */ {"PM_MSM_CHUNKS", 2, 1, 8},
 };
 static void options_defaults(pm_options *o) {
     for (int k = 0; k < PM_NUM_OPTIONS; ++k) {
@@ -106,7 +105,6 @@ static void options_defaults(pm_options *o) {
 extern "C" int pm_ctx_set_option(pm_ctx *ctx, int option, long long value) {
     if (!ctx || option < 0 || option >= PM_NUM_OPTIONS) return PM_ERR_INVALID_ARG;
     if (value < OPTION_SPECS[option].lo || value > OPTION_SPECS[option].hi) return PM_ERR_INVALID_ARG;
-    if (ctx->pk && ctx->phase >= 1 && ctx->phase < 3) return PM_ERR_STATE;     // between phase 1 and phase 3 of a proof
     ctx->opt.v[option] = value;
     if (ctx->aux) ctx->aux->opt.v[option] = value;
     return PM_OK;
@@ -158,14 +156,7 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     timing_flush(ctx);
     MsmWorkspace &m = ctx->msm;
-    for (MsmSet &q : m.set)
-        for (DevBuf *b : {&q.sorted, &q.counts, &q.bucket_off, &q.task_off, &q.order, &q.partials, &q.task_cnt}) b->release();
-    if (m.sort_stream) (void)hipStreamDestroy(m.sort_stream);
-    if (m.ev_begin) (void)hipEventDestroy(m.ev_begin);
-    for (int k = 0; k < MSM_SETS; ++k) {
-        if (m.ev_sorted[k]) (void)hipEventDestroy(m.ev_sorted[k]);
-        if (m.ev_acc[k]) (void)hipEventDestroy(m.ev_acc[k]);
-    }
+    for (DevBuf *b : {&m.set.sorted, &m.set.counts, &m.set.bucket_off, &m.set.task_off, &m.set.order, &m.set.partials, &m.set.task_cnt}) b->release();
     for (DevBuf *b : {&m.digits, &m.cursor, &m.wsum,
                       &m.region, &m.sub, &m.digits2, &m.len_bins, &m.block_cnt, &m.hot, &ctx->scratch, &ctx->flags, &ctx->xw, &ctx->ue, &ctx->we, &ctx->u, &ctx->w,
                       &ctx->wit_u, &ctx->u2, &ctx->sc_a, &ctx->sc_c, &ctx->quotient, &ctx->ztail, &ctx->ra, &ctx->sh_a, &ctx->sh_b, &ctx->sh_c, &ctx->halo,
@@ -728,76 +719,21 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
     Fr y = pow_u64<P>(x, sigma), yinv = inverse<P>(y);                            // generator.rs:73
     Fr y_alpha = pow_u64<P>(yinv, 3), y_to_minus_alpha = pow_u64<P>(y, 3), y_gamma = pow_u64<P>(yinv, 5);
     Fr zh = sub<P>(xn, one);                                                       // :106
-    // Lagrange coefficients at x (:113): L_i = zh/n * w^i / (x - w^i), host batch inversion -- in parallel chunks (every chunk
-    // starts from its own w^lo and inverts its own running product; the values are field elements, so the chunking cannot
-    // change them).  At n = 2^25 these loops are ~3 x 10^8 host multiplications: minutes on one thread.
-    std::vector<Fr> L(n);
+    // uj_wj_lcs scalars (generator.rs:112-136) on the device: Lagrange coefficients at x by chunked batch inversion, the sparse pass
+    // over the CSR matrices already uploaded above (setup.hip: lcs_scalars).  Rounds 1-3 ran both on <= 32 host threads.
+    DevBuf d_lagrange, d_work, d_lcs_buf;
+    struct Release { DevBuf &a, &b, &c; ~Release() { a.release(); b.release(); c.release(); } } release_lcs{d_lagrange, d_work, d_lcs_buf};
     {
+        if (hipMalloc(&d_lcs_buf.p, (Lz ? Lz : 1) * sizeof(Fr)) != hipSuccess) { ctx->err = "out of device memory for the lcs scalars"; return guard(PM_ERR_HIP); }
+        d_lcs_buf.bytes = (Lz ? Lz : 1) * sizeof(Fr);
         const Fr kscale = mul<P>(zh, inverse<P>(from_u64<P>(n)));
-        parallel_chunks(n, [&](uint64_t lo, uint64_t hi, unsigned) {
-            std::vector<Fr> den(hi - lo), pre(hi - lo);
-            Fr wi = pow_u64<P>(omega, lo), run = one;
-            for (uint64_t i = lo; i < hi; ++i) {
-                den[i - lo] = sub<P>(x, wi);
-                L[i] = wi;
-                pre[i - lo] = run;
-                run = mul<P>(run, den[i - lo]);
-                wi = mul<P>(wi, omega);
-            }
-            Fr inv = inverse<P>(run);
-            for (uint64_t i = hi; i-- > lo;) {
-                Fr di = mul<P>(inv, pre[i - lo]);
-                inv = mul<P>(inv, den[i - lo]);
-                L[i] = mul<P>(mul<P>(L[i], di), kscale);
-            }
-        });
+        st = lcs_scalars<C>(ctx, pk, x, omega, kscale, y_gamma, y_to_minus_alpha, d_lagrange, d_work, d_lcs_buf.as<Fr>());
+        if (st) return guard(st);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "lcs scalars: stream failed"; return guard(PM_ERR_HIP); }
+        d_lagrange.release();
+        d_work.release();
     }
-    // the sparse lcs pass: every thread owns a range of COLUMNS (no two threads add into one accumulator) and walks all rows
-    std::vector<Fr> ucol(mcols, Fr::zero()), wcol(Lz, Fr::zero());
-    parallel_chunks(mcols, [&](uint64_t clo, uint64_t chi, unsigned) {
-        for (uint64_t r = 0; r < nr; ++r) {
-            const uint64_t a0 = host[0].rowptr[r], a1 = host[0].rowptr[r + 1], b0 = host[1].rowptr[r], b1 = host[1].rowptr[r + 1],
-                           c0 = host[2].rowptr[r], c1 = host[2].rowptr[r + 1];
-            bool mine = false;
-            for (uint64_t k = a0; k < a1 && !mine; ++k) mine = host[0].col[k] >= clo && host[0].col[k] < chi;
-            for (uint64_t k = b0; k < b1 && !mine; ++k) mine = host[1].col[k] >= clo && host[1].col[k] < chi;
-            for (uint64_t k = c0; k < c1 && !mine; ++k) mine = host[2].col[k] >= clo && host[2].col[k] < chi;
-            if (!mine) continue;
-            const Fr L1 = L[2 * m0 + r], L2 = L[2 * m0 + nr + r], sp = add<P>(L1, L2), sm = sub<P>(L1, L2), L1x4 = dbl<P>(dbl<P>(L1));
-            for (uint64_t k = a0; k < a1; ++k) {
-                const uint32_t cc = host[0].col[k];
-                if (cc < clo || cc >= chi) continue;
-                Fr v; memcpy(v.l, &host[0].val[4 * k], 32);
-                ucol[cc] = add<P>(ucol[cc], mul<P>(v, sp));
-            }
-            for (uint64_t k = b0; k < b1; ++k) {
-                const uint32_t cc = host[1].col[k];
-                if (cc < clo || cc >= chi) continue;
-                Fr v; memcpy(v.l, &host[1].val[4 * k], 32);
-                ucol[cc] = add<P>(ucol[cc], mul<P>(v, sm));
-            }
-            for (uint64_t k = c0; k < c1; ++k) {
-                const uint32_t cc = host[2].col[k];
-                if (cc < clo || cc >= chi) continue;
-                Fr v; memcpy(v.l, &host[2].val[4 * k], 32);
-                wcol[cc] = add<P>(wcol[cc], mul<P>(v, L1x4));
-            }
-        }
-    });
-    parallel_chunks(nr, [&](uint64_t lo, uint64_t hi, unsigned) {
-        for (uint64_t r = lo; r < hi; ++r) wcol[mcols + m0 + r] = add<P>(L[2 * m0 + r], L[2 * m0 + nr + r]);
-    });
-    for (uint64_t i = 0; i < m0; ++i) {
-        wcol[i] = add<P>(wcol[i], dbl<P>(dbl<P>(L[i])));
-        wcol[mcols + i] = add<P>(L[i], L[i + m0]);
-    }
-    std::vector<Fr> lcs(Lz);
-    parallel_chunks(Lz, [&](uint64_t lo, uint64_t hi, unsigned) {
-        for (uint64_t j = lo; j < hi; ++j) {
-            Fr u = j < mcols ? ucol[j] : Fr::zero();
-            lcs[j] = mul<P>(add<P>(mul<P>(u, y_gamma), wcol[j]), y_to_minus_alpha);  // :134
-        }
-    });
+    const Fr *d_lcs = d_lcs_buf.as<Fr>();
     // per-vector scale of the x-power vectors (generator.rs:82-109)
     Fr scale[PM_NUM_BASE_VECS];
     scale[PM_X_POWERS] = one;
@@ -811,13 +747,14 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
         Fr *d_sc = ctx->scratch.as<Fr>();
         for (uint64_t s = 0; s < count; s += CH) {
             uint64_t cnt = std::min(CH, count - s);
+            const Fr *src = d_sc;
             if (v == PM_UJ_WJ_LCS_BY_Y_ALPHA) {
-                PM_HIP(ctx, hipMemcpyAsync(d_sc, &lcs[start + s], cnt * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+                src = d_lcs + start + s;
             } else {
                 Fr first = mul<P>(scale[v], pow_u64<P>(x, start + s));
                 PM_TRY(powers_fill<C>(ctx, d_sc, cnt, first, x));
             }
-            PM_TRY(fixed_base_batch<C>(ctx, d_sc, cnt, dst + s));
+            PM_TRY(fixed_base_batch<C>(ctx, src, cnt, dst + s));
             PM_TRY(bases_convert<C>(ctx, dst + s, cnt, true));
             PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }

@@ -82,18 +82,13 @@ enum TimingSlot {
     T_NUM_SLOTS = 8
 };
 
-// What one bucket pipeline hands from its sort to its accumulation and from there to the reduction.  The table pipeline can sort an
-// MSM's pairs in CHUNKS (PM_OPT_MSM_CHUNKS; msm.hip: msm_piece_tables): chunk k + 1 is sorted on `sort_stream` while chunk k
-// accumulates, and chunk k + 1's tasks continue from chunk k's partials -- three slots in rotation.  Slot 0 serves every other path.
+// What one bucket pipeline hands from its sort to its accumulation and from there to the reduction.
 struct MsmSet {
     DevBuf sorted, counts, bucket_off, task_off, order, partials, task_cnt;
 };
-constexpr int MSM_SETS = 3;
 struct MsmWorkspace {
-    MsmSet set[MSM_SETS];
+    MsmSet set;
     DevBuf digits, cursor, wsum, region, sub, digits2, len_bins, block_cnt, hot;
-    hipStream_t sort_stream = nullptr;
-    hipEvent_t ev_begin = nullptr, ev_sorted[MSM_SETS] = {nullptr, nullptr, nullptr}, ev_acc[MSM_SETS] = {nullptr, nullptr, nullptr};
 };
 
 // Window tables of a resident base vector (setup.hip: tables_build): point (w, i) = 2^(c w) P_i lives at
@@ -337,7 +332,7 @@ int msm_resident_end(pm_ctx *ctx, uint64_t *out_xy, int *out_inf);
 // msm_reduce.hip: the bucket reduction of the table-mode MSM (one set of NB >= 4096 buckets whose task partials sit in ctx->msm),
 // three launches on ctx->stream; *out = the sum sum_b (b + 1) B_b, internal form, inside the workspace.
 template <class C>
-int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets = 1, const MsmSet *S = nullptr /* default: slot 0 */);
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets = 1);
 
 // One bucket pipeline covers at most this many pairs (sorted-entry positions are u32: windows x pairs < 2^32); longer
 // MSMs run in pieces summed on the host.  2^27 in production; PM_OPT_MSM_MAX_PIECE_LOG (developer / test knob) lowers it
@@ -372,6 +367,13 @@ int fixed_base_batch(pm_ctx *ctx, const Fp<typename C::FrP> *d_scalars, size_t l
 template <class C>
 int bases_convert(pm_ctx *ctx, Affine<C> *d_points, size_t len, bool to_internal);
 
+// setup.hip: the uj_wj_lcs scalars of generator.rs:112-136 on the device (Lagrange coefficients at x + the sparse pass over the
+// key's CSR matrices); `lagrange` and `work` are scratch the caller releases
+template <class C>
+int lcs_scalars(pm_ctx *ctx, const pm_pk *pk, const Fp<typename C::FrP> &x, const Fp<typename C::FrP> &omega, const Fp<typename C::FrP> &kscale,
+                const Fp<typename C::FrP> &y_gamma, const Fp<typename C::FrP> &y_to_minus_alpha, DevBuf &lagrange, DevBuf &work,
+                Fp<typename C::FrP> *d_lcs);
+
 template <class C>
 int powers_fill(pm_ctx *ctx, Fp<typename C::FrP> *d_out, size_t count, const Fp<typename C::FrP> &scale,
                 const Fp<typename C::FrP> &x);
@@ -404,6 +406,15 @@ inline pm_ctx *ctx_aux(pm_ctx *ctx) {
     if (!ctx->aux && pm_ctx_create(ctx->device, &ctx->aux) != PM_OK) ctx->aux = nullptr;
     if (ctx->aux) ctx->aux->opt = ctx->opt;
     return ctx->aux;
+}
+
+// The context's pinned host staging: [0, 4096) the asynchronous MSM's result slots (msm.hip) and phase 3's remainder, then
+// PINNED_STAGE_BYTES for small device-to-host records that must land without stalling the host (prove_sharded.hip: phase 1's
+// flags and halo coefficients -- a pageable destination makes hipMemcpyAsync wait for the stream).  nullptr on failure.
+constexpr size_t PINNED_SLOTS_BYTES = 4096, PINNED_STAGE_BYTES = 32768;
+inline void *ctx_pinned(pm_ctx *ctx) {
+    if (!ctx->h_pinned && hipHostMalloc(&ctx->h_pinned, PINNED_SLOTS_BYTES + PINNED_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pinned = nullptr;
+    return ctx->h_pinned;
 }
 
 inline void timing_reset(pm_ctx *ctx) {

@@ -144,10 +144,8 @@ __global__ __launch_bounds__(1024) void k_hist(const uint32_t *digits, uint32_t 
 // (+ totals at index G).  A lane owns SCAN_PER contiguous counters (64 B), a workgroup SCAN_TILE.
 constexpr unsigned SCAN_PER = 16, SCAN_TILE = 256 * SCAN_PER;
 
-// prev_task_off != nullptr (a later chunk of a chunked MSM, msm_piece_tables): a bucket that had a task in the PREVIOUS chunk gets at
-// least one task here even without entries, so that its partial sum is carried forward from chunk to chunk (k_accumulate: `prev`).
 __global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *counts, uint32_t *bucket_off, uint32_t *task_off,
-                                                    uint32_t *tile_tot, size_t G, unsigned seg, const uint32_t *prev_task_off) {
+                                                    uint32_t *tile_tot, size_t G, unsigned seg) {
     __shared__ uint32_t s_a[256], s_b[256];
     const unsigned tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)tid * SCAN_PER;
@@ -157,7 +155,6 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t *counts, uint
     for (unsigned k = 0; k < SCAN_PER; ++k) {
         c[k] = base + k < G ? counts[base + k] : 0u;
         nt[k] = (c[k] + seg - 1) / seg;
-        if (prev_task_off && base + k < G && nt[k] == 0 && prev_task_off[base + k + 1] != prev_task_off[base + k]) nt[k] = 1;
         sa += c[k];
         sb += nt[k];
     }
@@ -273,8 +270,7 @@ __global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, cons
         t0 = task_off[g];
         n = task_off[g + 1] - t0;
         if (n) {
-            uint32_t L = counts[g] - (n - 1) * seg;                 // 1 .. seg (0: a chunked MSM's carried-forward task without entries)
-            if (L == 0) L = 1;
+            const uint32_t L = counts[g] - (n - 1) * seg;           // 1 .. seg
             bin = (seg - L) >> lshift;
             if (n > 1) rank_full = atomicAdd(&h[0], n - 1);
             rank_last = atomicAdd(&h[bin], 1u);
@@ -305,15 +301,11 @@ __global__ __launch_bounds__(1024) void k_task_bins(const uint32_t *counts, cons
 // dense affine array of the per-window pipeline).  The accumulator lives in reduced-radix registers (fq28.cuh): 10 carry-free
 // Montgomery products and 7 lazy add/sub per mixed add.  `bases` are in INTERNAL Montgomery form.
 // The exceptional case acc == +-point (doubling / cancellation) is resolved on the dense path.
-// prev_* (a later chunk of a chunked MSM): the first task of bucket g starts from the bucket's partial sum of the previous chunk
-// instead of zero -- ONE record: the previous chunk's fold (fold_hot_buckets with fold_min = 1) has summed the tasks of every bucket
-// that was longer than the task length there.
 template <class C, bool TABLE>
 __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, const uint32_t *counts,
                                                     const uint32_t *bucket_off, const uint32_t *task_off,
                                                     const uint32_t *order, const void *points, XYZZ<C> *partials, size_t G,
-                                                    unsigned seg, const XYZZ<C> *prev_partials, const uint32_t *prev_task_off,
-                                                    const uint32_t *prev_task_cnt) {
+                                                    unsigned seg) {
     typedef typename C::FqRR RR;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = task_off[G];
@@ -332,10 +324,6 @@ __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, cons
     if (start + seg < end) end = start + seg;
     XYZZ28<C> acc;
     acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
-    if (prev_partials && k == 0) {
-        const uint32_t q0 = prev_task_off[g], qn = prev_task_cnt[g];
-        if (qn) acc = xyzz28_load<C>(prev_partials[q0]);
-    }
     for (uint32_t e = start; e < end; ++e) {
         const uint32_t v = sorted[e];
         const bool neg = (v & 1u) != 0;
@@ -384,7 +372,7 @@ __device__ __forceinline__ void lds_tree_sum(XYZZ28<C> *sh) {
 constexpr uint32_t FOLD_MIN = 8, FOLD_BLOCK_MIN = 1024;
 
 __global__ void k_task_counts(const uint32_t *task_off, size_t G, uint32_t *task_cnt, uint32_t *hot_a, uint32_t *hot_b,
-                              uint32_t *hot_counts /*[2], zeroed*/, uint32_t cap, uint32_t fold_min) {
+                              uint32_t *hot_counts /*[2], zeroed*/, uint32_t cap) {
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     const uint32_t n = task_off[g + 1] - task_off[g];
@@ -392,7 +380,7 @@ __global__ void k_task_counts(const uint32_t *task_off, size_t G, uint32_t *task
     if (n > FOLD_BLOCK_MIN) {
         const uint32_t i = atomicAdd(&hot_counts[0], 1u);
         if (i < cap) hot_a[i] = (uint32_t)g;   // an unlisted bucket keeps its sequential sum
-    } else if (n > fold_min) {
+    } else if (n > FOLD_MIN) {
         const uint32_t i = atomicAdd(&hot_counts[1], 1u);
         if (i < cap) hot_b[i] = (uint32_t)g;
     }
@@ -989,19 +977,17 @@ static void host_finish(const XYZZ<C> *S /*[nwin], internal form*/, unsigned nwi
 
 // effective task counts for the reduction + parallel fold of hot buckets (k_task_counts / k_task_fold);
 // enqueued after k_accumulate, before the bucket reduction
-// fold_min = FOLD_MIN before a reduction (its lanes add up to FOLD_MIN partials of a bucket themselves); 1 between the chunks of a
-// chunked MSM: EVERY bucket with more than one task is folded, the next chunk continues from one record per bucket.
 template <class C>
-static int fold_hot_buckets(pm_ctx *ctx, MsmSet &S, size_t G, size_t max_tasks, uint32_t fold_min = FOLD_MIN) {
+static int fold_hot_buckets(pm_ctx *ctx, MsmSet &S, size_t G, size_t max_tasks) {
     MsmWorkspace &ws = ctx->msm;
-    size_t cap = max_tasks > G ? max_tasks - G + 1 : 1;          // a listed bucket has > fold_min tasks: at most (tasks - buckets) / fold_min
-    cap = cap / fold_min + 1;
+    size_t cap = max_tasks > G ? max_tasks - G + 1 : 1;          // a listed bucket has > FOLD_MIN tasks
+    cap = cap / FOLD_MIN + 1;
     PM_HIP(ctx, S.task_cnt.reserve(G * 4));
     PM_HIP(ctx, ws.hot.reserve((2 * cap + 2) * 4));
     uint32_t *hot_counts = ws.hot.as<uint32_t>(), *hot_a = hot_counts + 2, *hot_b = hot_a + cap;
     PM_HIP(ctx, hipMemsetAsync(hot_counts, 0, 8, ctx->stream));
     hipLaunchKernelGGL(k_task_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx->stream, S.task_off.as<uint32_t>(), G,
-                       S.task_cnt.as<uint32_t>(), hot_a, hot_b, hot_counts, (uint32_t)cap, fold_min);
+                       S.task_cnt.as<uint32_t>(), hot_a, hot_b, hot_counts, (uint32_t)cap);
     PM_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL((k_task_fold<C, 256>), dim3(256), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream, S.partials.as<XYZZ<C>>(),
                        S.task_off.as<uint32_t>(), S.task_cnt.as<uint32_t>(), hot_a, hot_counts, (uint32_t)cap);
@@ -1012,8 +998,8 @@ static int fold_hot_buckets(pm_ctx *ctx, MsmSet &S, size_t G, size_t max_tasks, 
     return PM_OK;
 }
 
-// order[] for k_accumulate (see k_task_bins); enqueued on `st` (the stream of the sort) after the bucket scan.
-static int task_order(pm_ctx *ctx, hipStream_t st, MsmSet &S, const uint32_t *counts, size_t G, size_t seg, size_t max_tasks) {
+// order[] for k_accumulate (see k_task_bins); enqueued on the context's stream after the bucket scan.
+static int task_order(pm_ctx *ctx, MsmSet &S, const uint32_t *counts, size_t G, size_t seg, size_t max_tasks) {
     MsmWorkspace &ws = ctx->msm;
     unsigned lshift = 0;
     while (((seg - 1) >> lshift) + 1 > TASK_MAX_BINS) ++lshift;
@@ -1021,14 +1007,14 @@ static int task_order(pm_ctx *ctx, hipStream_t st, MsmSet &S, const uint32_t *co
     PM_HIP(ctx, S.order.reserve(max_tasks * 4));
     PM_HIP(ctx, ws.len_bins.reserve((3 * (size_t)nbins + 4) * 4));
     uint32_t *len_cnt = ws.len_bins.as<uint32_t>(), *len_off = len_cnt + nbins, *len_cursor = len_off + nbins + 1;
-    PM_HIP(ctx, hipMemsetAsync(len_cnt, 0, (size_t)nbins * 4, st));
+    PM_HIP(ctx, hipMemsetAsync(len_cnt, 0, (size_t)nbins * 4, ctx->stream));
     const unsigned blocks = (unsigned)((G + 1023) / 1024);      // one lane per bucket
-    hipLaunchKernelGGL(k_task_bins<false>, dim3(blocks), dim3(1024), nbins * 4, st, counts, S.task_off.as<uint32_t>(), G,
+    hipLaunchKernelGGL(k_task_bins<false>, dim3(blocks), dim3(1024), nbins * 4, ctx->stream, counts, S.task_off.as<uint32_t>(), G,
                        (unsigned)seg, lshift, nbins, len_cnt, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     PM_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, len_cnt, len_off, len_cursor, nbins);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, len_cnt, len_off, len_cursor, nbins);
     PM_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_task_bins<true>, dim3(blocks), dim3(1024), nbins * 4, st, counts, S.task_off.as<uint32_t>(), G,
+    hipLaunchKernelGGL(k_task_bins<true>, dim3(blocks), dim3(1024), nbins * 4, ctx->stream, counts, S.task_off.as<uint32_t>(), G,
                        (unsigned)seg, lshift, nbins, (uint32_t *)nullptr, len_off, len_cursor, S.order.as<uint32_t>());
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
@@ -1044,7 +1030,7 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
     StageTimer t_total(ctx, T_MSM_TOTAL);
     MsmPlan p = make_plan(len, (unsigned)FrP::BITS, (unsigned)ctx->opt.v[PM_OPT_MSM_TASK_LEN]);
     MsmWorkspace &ws = ctx->msm;
-    MsmSet &S = ws.set[0];
+    MsmSet &S = ws.set;
     const size_t G = (size_t)p.nwin * p.nbuckets;
     PM_HIP(ctx, ws.digits.reserve((size_t)p.nwin * len * 4));
     PM_HIP(ctx, S.sorted.reserve((size_t)p.nwin * len * 4));
@@ -1075,7 +1061,7 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
         PM_HIP(ctx, hipGetLastError());
         const unsigned ntiles = (unsigned)((G + SCAN_TILE - 1) / SCAN_TILE);
         hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, ctx->stream, counts, S.bucket_off.as<uint32_t>(),
-                           S.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), G, p.seg, (const uint32_t *)nullptr);
+                           S.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), G, p.seg);
         PM_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, ws.cursor.as<uint32_t>(), ntiles,
                            S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), G);
@@ -1086,14 +1072,14 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
         hipLaunchKernelGGL(k_scatter, dim3(p.nchunks, p.nwin), dim3(1024), lds, ctx->stream, ws.digits.as<uint32_t>(),
                            S.bucket_off.as<uint32_t>(), cursor, S.sorted.as<uint32_t>(), len, p.chunk, p.nbuckets);
         PM_HIP(ctx, hipGetLastError());
-        PM_TRY(task_order(ctx, ctx->stream, S, counts, G, p.seg, p.max_tasks));
+        PM_TRY(task_order(ctx, S, counts, G, p.seg, p.max_tasks));
     }
     {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
         size_t blocks = (p.max_tasks + 127) / 128;
         hipLaunchKernelGGL((k_accumulate<C, false>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, S.sorted.as<uint32_t>(),
                            counts, S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), S.order.as<uint32_t>(), (const void *)d_bases,
-                           S.partials.as<XYZZ<C>>(), G, p.seg, (const XYZZ<C> *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                           S.partials.as<XYZZ<C>>(), G, p.seg);
         PM_HIP(ctx, hipGetLastError());
     }
     std::vector<XYZZ<C>> hS(p.nwin);
@@ -1119,32 +1105,11 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
 // async_res != nullptr (table mode only): everything is ENQUEUED on ctx->stream, the reduced point (internal form) is copied to
 // *async_res -- pinned host memory -- and the call returns without waiting; the caller synchronises and finishes (msm_end).
 //
-// CHUNKS (PM_OPT_MSM_CHUNKS, round 4).  The sort is memory-bound, the accumulation ALU-bound, and an MSM that
-// runs alone -- the quotient commitment [d]_1 (prover.rs:229): 71 % of a proof's pairs -- pays for its sort in full before its
-// first point addition (3.2 ms of 41 at 2^20 gates).  With K chunks the pairs are sorted in K slices into the SAME bucket set:
-// chunk k + 1's sort runs on `sort_stream` under chunk k's accumulation, and chunk k + 1's first task of a bucket starts from the
-// bucket's partial sum of chunk k (k_accumulate: prev_*), so the reduction still sees one record per bucket -- no second bucket set
-// to reduce (what PM_MSM_SPLIT_D cost in round 3).  A bucket without entries in a chunk keeps a task there that only carries its
-// sum forward (k_scan_tiles: prev_task_off).  Price: one real addition per bucket and later chunk where the first entry used to be
-// a copy.  Three slots rotate: the accumulation of chunk k reads slots k and k - 1 while the sort of chunk k + 1 fills slot k + 1.
-constexpr size_t MSM_CHUNK_MIN_PAIRS = (size_t)1 << 20;    // shorter MSMs: one sort (their sort front end is launch-bound)
-
-static int chunk_streams(pm_ctx *ctx) {
-    MsmWorkspace &ws = ctx->msm;
-    if (ws.sort_stream) return PM_OK;
-    {
-        int lo_p = 0, hi_p = 0;     // (greatest numeric priority, least numeric priority) = (lowest, highest)
-        PM_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-        PM_HIP(ctx, hipStreamCreateWithPriority(&ws.sort_stream, hipStreamNonBlocking, hi_p));
-    }
-    PM_HIP(ctx, hipEventCreateWithFlags(&ws.ev_begin, hipEventDisableTiming));
-    for (int k = 0; k < MSM_SETS; ++k) {
-        PM_HIP(ctx, hipEventCreateWithFlags(&ws.ev_sorted[k], hipEventDisableTiming));
-        PM_HIP(ctx, hipEventCreateWithFlags(&ws.ev_acc[k], hipEventDisableTiming));
-    }
-    return PM_OK;
-}
-
+// (Round 4 measured the sort in CHUNKS of pairs -- chunk k + 1 sorted on a second stream under chunk k's accumulation, one bucket
+// set, the next chunk's tasks continuing from the previous partials -- and lost: k_accumulate holds 2 x 248 of a SIMD's 512 registers,
+// so no other wave can be resident beside it; the sort's 1024-lane workgroups wait for whole CUs to drain and the two kernels
+// time-slice instead of overlapping.  +1.8 ms per proof at two chunks, +5 at three: profiles/r04_chunked_sort_overlap_negative.txt;
+// the implementation is commit 5de5c70.)
 template <class C>
 static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename C::FrP> *d_scalars,
                             size_t len, Affine<C> *h_out, int *h_inf, const Affine<C> *plain = nullptr, XYZZ<C> *async_res = nullptr) {
@@ -1164,13 +1129,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
         if (tb.off[w] != win_off(nwin, w) || tb.width[w] != win_width(nwin, w)) return PM_ERR_INVALID_ARG;
     const bool two_level = NB1 >= 4096;                // msm_reduce.hip: k_reduce_level0 / level1 / final
     if (wide && !two_level) return PM_ERR_INVALID_ARG;  // wide plans have c >= 16 (setup.hip: wide_plan)
-    // chunks of pairs: [len k / K, len (k + 1) / K)
-    unsigned K = 1;
-    if (!wide && len >= MSM_CHUNK_MIN_PAIRS) K = (unsigned)ctx->opt.v[PM_OPT_MSM_CHUNKS];
-    if (K < 1) K = 1;
-    if (K > 1) PM_TRY(chunk_streams(ctx));
-    const size_t len_max = (len + K - 1) / K;              // the longest chunk
-    const size_t Emax = (size_t)nwin * len_max;            // entries of one chunk
+    const size_t Emax = (size_t)nwin * len;
     size_t seg = 2 * (Emax / NB + 1);
     if (seg < 64) seg = 64;
     if (ctx->opt.v[PM_OPT_MSM_TASK_LEN] > 0) seg = (size_t)ctx->opt.v[PM_OPT_MSM_TASK_LEN];
@@ -1180,9 +1139,8 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     PM_HIP(ctx, ws.digits.reserve(keys_bytes + Emax * 4));
     PM_HIP(ctx, ws.region.reserve((3 * (size_t)regions + 4) * 4));
     PM_HIP(ctx, ws.cursor.reserve(((NB + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
-    const int nslots = K == 1 ? 1 : (K == 2 ? 2 : MSM_SETS);
-    for (int q = 0; q < nslots; ++q) {
-        MsmSet &S = ws.set[q];
+    MsmSet &S = ws.set;
+    {
         PM_HIP(ctx, S.sorted.reserve(Emax * 4));
         PM_HIP(ctx, S.counts.reserve(2 * NB * 4));
         PM_HIP(ctx, S.bucket_off.reserve((NB + 1) * 4));
@@ -1202,7 +1160,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     if (regions > pbd) return PM_ERR_INVALID_ARG;                      // one scan lane per region
     const size_t plds = 2 * 1024 * 4 + (size_t)pbd * nwin * 8;
     {
-        const unsigned pblocks_max = (unsigned)((len_max + pbd - 1) / pbd);
+        const unsigned pblocks_max = (unsigned)((len + pbd - 1) / pbd);
         const BlockScanShape bsh_max = block_scan_shape(pblocks_max, regions);
         PM_HIP(ctx, ws.block_cnt.reserve(((size_t)pblocks_max + bsh_max.G) * regions * 4));
     }
@@ -1213,9 +1171,11 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
         PM_HIP(ctx, ws.digits2.reserve(keys_bytes + Emax * 4));
     }
 
-    // ---- the sort of pairs [lo, lo + cnt) into slot S, on stream `st`; prev: the previous chunk's slot (tasks carried forward)
-    auto sort_chunk = [&](hipStream_t st, size_t lo, size_t cnt, MsmSet &S, const MsmSet *prev) -> int {
-        StageTimer t(ctx, T_MSM_SORT, st);
+    // ---- the sort: (scalar, window) entries -> table indices grouped by bucket, task order
+    auto sort_all = [&]() -> int {
+        StageTimer t(ctx, T_MSM_SORT);
+        hipStream_t st = ctx->stream;
+        const size_t lo = 0, cnt = len;
         const size_t E = (size_t)nwin * cnt;
         const unsigned char *inf = tb.inf + tb.base_index + lo;
         const Fp<FrP> *sc = d_scalars + lo;
@@ -1256,8 +1216,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
         const unsigned ntiles = (unsigned)((NB + SCAN_TILE - 1) / SCAN_TILE);
         auto bucket_scan = [&]() -> int {
             hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, st, counts, S.bucket_off.as<uint32_t>(),
-                               S.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB, (unsigned)seg,
-                               prev ? prev->task_off.as<uint32_t>() : (const uint32_t *)nullptr);
+                               S.task_off.as<uint32_t>(), ws.cursor.as<uint32_t>(), NB, (unsigned)seg);
             PM_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, ws.cursor.as<uint32_t>(), ntiles,
                                S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), NB);
@@ -1302,58 +1261,22 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
                                (uint16_t *)nullptr, (uint32_t *)nullptr);
             PM_HIP(ctx, hipGetLastError());
         }
-        PM_TRY(task_order(ctx, st, S, counts, NB, seg, max_tasks));
+        PM_TRY(task_order(ctx, S, counts, NB, seg, max_tasks));
         return PM_OK;
     };
-    // ---- the accumulation of slot S on ctx->stream; prev: the previous chunk's slot, whose partials its first tasks continue
-    auto accumulate_chunk = [&](MsmSet &S, const MsmSet *prev) -> int {
+    PM_TRY(sort_all());
+    {
         StageTimer t(ctx, T_MSM_ACCUMULATE);
         const size_t blocks = (max_tasks + 127) / 128;
-        const XYZZ<C> *pp = prev ? prev->partials.as<XYZZ<C>>() : (const XYZZ<C> *)nullptr;
-        const uint32_t *po = prev ? prev->task_off.as<uint32_t>() : (const uint32_t *)nullptr;
-        const uint32_t *pc = prev ? prev->task_cnt.as<uint32_t>() : (const uint32_t *)nullptr;
         if (wide)
             hipLaunchKernelGGL((k_accumulate<C, false>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, S.sorted.as<uint32_t>(), S.counts.as<uint32_t>(),
                                S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), S.order.as<uint32_t>(), (const void *)plain,
-                               S.partials.as<XYZZ<C>>(), NB, (unsigned)seg, pp, po, pc);
+                               S.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
         else
             hipLaunchKernelGGL((k_accumulate<C, true>), dim3((unsigned)blocks), dim3(128), 0, ctx->stream, S.sorted.as<uint32_t>(), S.counts.as<uint32_t>(),
                                S.bucket_off.as<uint32_t>(), S.task_off.as<uint32_t>(), S.order.as<uint32_t>(), tb.table,
-                               S.partials.as<XYZZ<C>>(), NB, (unsigned)seg, pp, po, pc);
+                               S.partials.as<XYZZ<C>>(), NB, (unsigned)seg);
         PM_HIP(ctx, hipGetLastError());
-        return PM_OK;
-    };
-
-    MsmSet *last = &ws.set[0];
-    if (K == 1) {
-        PM_TRY(sort_chunk(ctx->stream, 0, len, ws.set[0], nullptr));
-        PM_TRY(accumulate_chunk(ws.set[0], nullptr));
-    } else {
-        // ctx->stream: sort 0 | acc 0 | fold 0 | acc 1 | fold 1 | ...      sort_stream:        sort 1 | sort 2 | ...
-        // sort k + 1 starts when acc k starts (after sort k and after acc k - 1, whose slot k - 2 = k + 1 (mod 3) it overwrites)
-        auto slot_of = [&](unsigned k) -> MsmSet & { return ws.set[k % (unsigned)nslots]; };
-        PM_TRY(sort_chunk(ctx->stream, 0, len / K, slot_of(0), nullptr));
-        PM_HIP(ctx, hipEventRecord(ws.ev_begin, ctx->stream));
-        PM_HIP(ctx, hipStreamWaitEvent(ws.sort_stream, ws.ev_begin, 0));
-        for (unsigned k = 0; k < K; ++k) {
-            if (k + 1 < K) {
-                const size_t lo = len * (k + 1) / K, hi = len * (k + 2) / K;
-                PM_TRY(sort_chunk(ws.sort_stream, lo, hi - lo, slot_of(k + 1), &slot_of(k)));
-                PM_HIP(ctx, hipEventRecord(ws.ev_sorted[(k + 1) % MSM_SETS], ws.sort_stream));
-            }
-            if (k > 0) PM_HIP(ctx, hipStreamWaitEvent(ctx->stream, ws.ev_sorted[k % MSM_SETS], 0));
-            PM_TRY(accumulate_chunk(slot_of(k), k ? &slot_of(k - 1) : nullptr));
-            if (k + 1 < K) {
-                // the next chunk's first tasks continue from ONE record per bucket: every bucket with several tasks is folded here
-                StageTimer t(ctx, T_MSM_REDUCE);
-                PM_TRY(fold_hot_buckets<C>(ctx, slot_of(k), NB, max_tasks, 1u));
-                // sort k + 2 overwrites slot k + 2 = k - 1 (mod 3), which acc k has just read as `prev`, and the sort temporaries
-                // are free once sort k + 1 is done (stream order): it may start when acc k + 1 does -- i.e. after this point
-                PM_HIP(ctx, hipEventRecord(ws.ev_acc[k % MSM_SETS], ctx->stream));
-                PM_HIP(ctx, hipStreamWaitEvent(ws.sort_stream, ws.ev_acc[k % MSM_SETS], 0));
-            }
-        }
-        last = &slot_of(K - 1);
     }
     if (wide) {
         // all windows' bucket sets reduced by ONE set of launches; then sum_w 2^(off_w) S_w by Horner from the top window: a chain
@@ -1361,9 +1284,9 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
         std::vector<XYZZ<C>> hS(nwin);
         {
             StageTimer t(ctx, T_MSM_REDUCE);
-            PM_TRY(fold_hot_buckets<C>(ctx, *last, NB, max_tasks));
+            PM_TRY(fold_hot_buckets<C>(ctx, S, NB, max_tasks));
             XYZZ<C> *dres = nullptr;
-            PM_TRY(reduce_two_level<C>(ctx, NB1, &dres, nwin, last));
+            PM_TRY(reduce_two_level<C>(ctx, NB1, &dres, nwin));
             PM_HIP(ctx, hipMemcpyAsync(hS.data(), dres, nwin * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
         }
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1379,15 +1302,15 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     XYZZ<C> hres;
     {
         StageTimer t(ctx, T_MSM_REDUCE);
-        PM_TRY(fold_hot_buckets<C>(ctx, *last, NB, max_tasks));
+        PM_TRY(fold_hot_buckets<C>(ctx, S, NB, max_tasks));
         XYZZ<C> *dres = nullptr;
         if (two_level) {
-            PM_TRY(reduce_two_level<C>(ctx, NB, &dres, 1, last));
+            PM_TRY(reduce_two_level<C>(ctx, NB, &dres));
         } else {
             XYZZ<C> *parts = ws.wsum.as<XYZZ<C>>();
             dres = parts + bpw;
             hipLaunchKernelGGL(k_bucket_reduce<C>, dim3(bpw), dim3(red_block), red_block * sizeof(XYZZ28<C>), ctx->stream,
-                               last->partials.as<XYZZ<C>>(), last->task_off.as<uint32_t>(), last->task_cnt.as<uint32_t>(), (unsigned)NB, red_lanes, bpw, parts);
+                               S.partials.as<XYZZ<C>>(), S.task_off.as<uint32_t>(), S.task_cnt.as<uint32_t>(), (unsigned)NB, red_lanes, bpw, parts);
             PM_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(k_sum_parts<C>, dim3(1), dim3(64), 0, ctx->stream, parts, bpw, dres);
             PM_HIP(ctx, hipGetLastError());
@@ -1445,9 +1368,7 @@ template <class C>
 int msm_begin(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C::FrP> *d_scalars, size_t len, const MsmTables *tables) {
     ctx->msm_async = 0;
     const bool tbl = tables && tables->c && !tables->wide;
-    if (!ctx->h_pinned) {
-        if (hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) { ctx->h_pinned = nullptr; ctx->err = "pinned result slot allocation failed"; return PM_ERR_HIP; }
-    }
+    if (!ctx_pinned(ctx)) { ctx->err = "pinned result slot allocation failed"; return PM_ERR_HIP; }
     Affine<C> *slot_pt = (Affine<C> *)((uint8_t *)ctx->h_pinned + 1024);
     int *slot_inf = (int *)((uint8_t *)ctx->h_pinned + 2048);
     if (len == 0 || !tbl || len > msm_max_piece(ctx)) {           // synchronous: result parked in the slot

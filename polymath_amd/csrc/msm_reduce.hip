@@ -226,9 +226,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // ctx->msm: three launches on ctx->stream, the nsets results (internal form) at (*out)[0 .. nsets) in the workspace.  nsets = 1:
 // the shared bucket set of the window-table MSM; nsets = windows: the wide-window MSM without tables.
 template <class C>
-int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets, const MsmSet *S) {
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets) {
     MsmWorkspace &ws = ctx->msm;
-    if (!S) S = &ws.set[0];
+    const MsmSet *S = &ws.set;
     if (nsets == 0 || (NB & (NB - 1)) != 0) return PM_ERR_INVALID_ARG;
     const size_t total = NB * nsets;
     unsigned K0 = 4;                                   // level-0 fan-in: <= 2^17 lanes = 2 waves per SIMD, one round of the chip
@@ -261,7 +261,7 @@ int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets, cons
     return PM_OK;
 }
 
-template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **, unsigned, const MsmSet *);
-template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **, unsigned, const MsmSet *);
+template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **, unsigned);
+template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **, unsigned);
 
 }  // namespace pm

@@ -824,8 +824,18 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     Fr *d_last = ctx->halo.as<Fr>() + N;
     hipLaunchKernelGGL(k_halo_pack<P>, dim3((N + 63) / 64), dim3(64), 0, st, (const Fr *)u, L, d_last);
     PM_HIP(ctx, hipGetLastError());
-    PM_HIP(ctx, hipMemcpyAsync(&r1->flags, flags, 4, hipMemcpyDeviceToHost, st));
-    PM_HIP(ctx, hipMemcpyAsync(my_halo, d_last, (size_t)N * sizeof(Fr), hipMemcpyDeviceToHost, st));   // both land before the MSM's final sync
+    // flags and halo go to PINNED staging (a pageable destination would make these two copies wait for the stream -- all transforms --
+    // before the MSM pipelines below could even be enqueued) and into the record after the MSMs' final synchronisation
+    uint8_t *stage = nullptr;
+    const size_t halo_bytes = (size_t)N * sizeof(Fr);
+    if (ctx_pinned(ctx) && 16 + halo_bytes <= PINNED_STAGE_BYTES) stage = (uint8_t *)ctx->h_pinned + PINNED_SLOTS_BYTES;
+    struct DrainOnExit {      // without pinned staging the copies target `mine`: no return path may free it while they are pending
+        hipStream_t st;
+        bool armed;
+        ~DrainOnExit() { if (armed) (void)hipStreamSynchronize(st); }
+    } drain{st, stage == nullptr};
+    PM_HIP(ctx, hipMemcpyAsync(stage ? (void *)stage : (void *)&r1->flags, flags, 4, hipMemcpyDeviceToHost, st));
+    PM_HIP(ctx, hipMemcpyAsync(stage ? (void *)(stage + 16) : (void *)my_halo, d_last, halo_bytes, hipMemcpyDeviceToHost, st));   // both land before the MSM's final sync
     // [a]_1 and [c]_1 are independent MSMs: both pipelines are ENQUEUED before either is waited for -- [a]_1 on the helper
     // context's stream and workspace, behind an event on this stream; [c]_1 here -- so the smaller one's latency-bound sort
     // front end and bucket reduction run under the larger one's accumulation.  One host thread, no collective in between
@@ -850,6 +860,11 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         PM_TRY(msm_resident<C>(ctx, pk, 1, sc_c, r1->c_xy, &c_inf_l));
     }
     hp.mark("msm_a+c");
+    if (stage) {              // the MSMs' final synchronisation is behind us: the staged words have landed
+        memcpy(&r1->flags, stage, 4);
+        memcpy(my_halo, stage + 16, halo_bytes);
+    }
+    drain.armed = false;
     r1->a_inf = (uint32_t)a_inf_l;
     r1->c_inf = (uint32_t)c_inf_l;
     r1->pad = 0;
@@ -984,8 +999,7 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
     const size_t T = pk->all_segs.size();
     PM_HIP(ctx, ctx->lvl[2].reserve(rec * N * sizeof(Fr)));
     Fr *d_hall = ctx->lvl[2].as<Fr>(), *d_rem = carry + S;
-    if (!ctx->h_pinned && hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
-        ctx->h_pinned = nullptr;
+    if (!ctx_pinned(ctx)) {
         ctx->err = "pinned result slot allocation failed";
         return PM_ERR_HIP;
     }
@@ -1010,8 +1024,8 @@ int prove_phase3_sharded(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_
             uint64_t inf;
         } mine3;
         int inf_l = 1;
-        // (Two half-length pipelines with a bucket set each lost 0.6 ms per rank at N = 8: profiles/r03_n_*; the chunked sort of
-        // PM_OPT_MSM_CHUNKS keeps ONE bucket set.)
+        // (Two half-length pipelines with a bucket set each lost 0.6 ms per rank at N = 8: profiles/r03_n_*; chunks of pairs sorted
+        // under the accumulation into ONE bucket set lost on one GPU: profiles/r04_chunked_sort_overlap_negative.txt.)
         PM_TRY(msm_resident<C>(ctx, pk, 2, qv, mine3.xy, &inf_l));
         hp.mark("expand+msm_d");
         if (!h_rem->is_zero()) return phase_end.ok(PM_ERR_REMAINDER_NONZERO);   // prover.rs:221 -- H_0 is the same value on every rank

@@ -186,6 +186,15 @@ def make_comm(rank, world, device, native=True, timeout_s=60):
             if all_ok(ok):
                 return comm, "rccl (native: ncclAllToAll / ncclAllGather inside the library)", {"kind": comm.kind, "ranks_seen": seen, "fallback_reason": None}
             reason = reason or "a peer could not use RCCL"
+            if comm is not None:
+                # falling back: do not leave the RCCL communicator (watchdog thread, 64 events, pinned / device staging, perhaps a
+                # half-finished collective on its stream) alive beside the transport that replaces it.  abort first: the destructor
+                # skips ncclCommDestroy on an aborted communicator, so a peer that never arrived cannot block the teardown.
+                try:
+                    comm.abort("falling back to host-staged exchanges: " + reason)
+                    comm.close()
+                except Exception:    # noqa: BLE001 -- a failing teardown must not cost the fallback
+                    pass
         else:
             reason = reason or "a peer could not load librccl"
     tc = TorchComm(rank, world)

@@ -10,6 +10,13 @@ exists to keep (they come from the GPU pool, not from taste):
     (ATTEMPTS) and the first configuration in which every rank finishes wins.  Rank 0 prints its JSON line only at the very
     end of a successful attempt, so a failed attempt leaves nothing on stdout.
 
+One clock for the whole job (round 4).  The driver gives a multi-GPU bench 1 800 s; a chain of four attempts
+with a deadline each could outlive that before the fallback that works is ever tried.  BENCH_TOTAL_BUDGET_S (default 1 500 s)
+is divided by `attempt_deadline`: an attempt that still has a host-staged attempt (gloo + callbacks: nothing depends on
+RCCL any more) AFTER it may use at most its own stage sum AND at most what is left minus FALLBACK_RESERVE_S (420 s) for that
+attempt; the first of two such attempts gets 60 % of that.  Worst case at the defaults: attempt 0 killed at 648 s, attempt 1 at
+1 080 s, the host-staged attempt starts with 420 s -- inside 1 500 s; every decision is printed to stderr.
+
 Two ways in:
   python bench.py --gpus N            -> supervise_all(): this process spawns the N ranks itself;
   torchrun ... bench.py --gpus N      -> supervise_one(): every torchrun worker supervises ONE child (its rank); retries are
@@ -31,6 +38,26 @@ ATTEMPTS = [
     ("gloo", "callbacks"),   # nothing depends on RCCL any more: exchanges staged through the host over gloo
     ("nccl", "callbacks"),   # (RCCL for torch only; tried last: two RCCL-dependent attempts have failed by now)
 ]
+
+
+TOTAL_BUDGET_S = 1500          # BENCH_TOTAL_BUDGET_S
+FALLBACK_RESERVE_S = 420       # BENCH_FALLBACK_RESERVE_S: kept for the first attempt that does not depend on RCCL at all
+EXIT_MARGIN_S = 10             # reporting, killing the children
+MIN_ATTEMPT_S = 45             # an attempt with less than this left is not started
+
+
+def attempt_deadline(attempts, k, remaining_s, stage_sum_s, reserve_s=FALLBACK_RESERVE_S):
+    """Seconds attempt k of `attempts` may run when `remaining_s` of the total budget are left (pure arithmetic: tests/test_launch.py).
+    0: do not start it."""
+    usable = remaining_s - EXIT_MARGIN_S
+    later_fallback = [j for j in range(k + 1, len(attempts)) if attempts[j] == ("gloo", "callbacks")]
+    if later_fallback:
+        usable -= reserve_s
+        rccl_before_fallback = later_fallback[0] - k          # attempts (this one included) ahead of the host-staged one
+        if rccl_before_fallback > 1:
+            usable *= 0.6                                      # the first of several gets the larger share, not everything
+    d = int(min(stage_sum_s, usable))
+    return d if d >= MIN_ATTEMPT_S else 0
 
 
 def attempts_from_env(env):
@@ -115,20 +142,90 @@ def _child_env(base, rank, local, world, port, attempt, backend, exchange, own_s
     return e
 
 
+class Budget:
+    """The job's one clock.  stage_sum_s: what a healthy attempt may need at most (bench.py: import, key setup, proofs)."""
+
+    def __init__(self, stage_sum_s, env=os.environ):
+        self.t0 = time.time()
+        self.total = float(env.get("BENCH_TOTAL_BUDGET_S", TOTAL_BUDGET_S))
+        self.reserve = float(env.get("BENCH_FALLBACK_RESERVE_S", FALLBACK_RESERVE_S))
+        self.stage_sum = float(stage_sum_s)
+
+    def remaining(self):
+        return self.total - (time.time() - self.t0)
+
+    def deadline(self, attempts, k, who=""):
+        rem = self.remaining()
+        d = attempt_deadline(attempts, k, rem, self.stage_sum, self.reserve)
+        _log("%sbudget: %.0f s of %.0f s left; attempt %d %s gets %d s (stage sum %.0f s, %.0f s reserved for a host-staged attempt)"
+             % (who, rem, self.total, k, attempts[k], d, self.stage_sum, self.reserve if ("gloo", "callbacks") in attempts[k + 1:] else 0.0))
+        return d
+
+
 def supervise_all(script, argv, world, deadline_s=900):
-    """`python bench.py --gpus N` without a launcher: spawn the N ranks, fall back through ATTEMPTS.  -> exit code."""
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks, fall back through ATTEMPTS.  -> exit code.
+    deadline_s: the stage sum of ONE healthy attempt; the job as a whole lives on Budget."""
     cmd = [sys.executable, script] + list(argv)
     why = "no attempt made"
-    for k, (backend, exchange) in enumerate(attempts_from_env(os.environ)):
+    attempts = attempts_from_env(os.environ)
+    budget = Budget(deadline_s)
+    for k, (backend, exchange) in enumerate(attempts):
+        d = budget.deadline(attempts, k)
+        if not d:
+            _log("attempt %d skipped: not enough of the budget left" % k)
+            continue
         port = free_port()
         _log("attempt %d: %d ranks, torch.distributed=%s, exchange=%s, port %d" % (k, world, backend, exchange, port))
-        envs = [_child_env(os.environ, r, r, world, port, k, backend, exchange, True) for r in range(world)]
-        ok, why = _run_attempt(cmd, envs, deadline_s)
+        envs = [_child_env(dict(os.environ, BENCH_ATTEMPT_LIMIT_S=str(d)), r, r, world, port, k, backend, exchange, True) for r in range(world)]
+        ok, why = _run_attempt(cmd, envs, d)
         if ok:
             return 0
         _log("attempt %d failed: %s" % (k, why))
     _log("all attempts failed (last: %s)" % why)
     return 1
+
+
+def _rendezvous_dir(env):
+    """Where the supervisors of ONE externally launched job (one node) meet between attempts: a directory named by the launcher's
+    run id and master port."""
+    import tempfile
+    tag = "%s_%s" % (env.get("TORCHELASTIC_RUN_ID", "norun"), env.get("MASTER_PORT", "29500"))
+    d = os.path.join(tempfile.gettempdir(), "pm_bench_" + "".join(c if c.isalnum() or c in "_-" else "_" for c in tag))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def agree_on_retry(env, rank, world, k, wait_s=90.0):
+    """Before attempt k > 0 under an external launcher: (a) every supervisor marks its arrival and waits (bounded) for the others --
+    the ranks notice a failed attempt at different times, and a retry's rendezvous should not burn on that skew; (b) rank 0
+    picks a FREE port for the retry's own TCP store and publishes it (the round-3 guess MASTER_PORT + 37 k could be taken or
+    above 65535).  Files in one directory: the job is one node.  -> port (the validated guess if the agreement times out)."""
+    d = _rendezvous_dir(env)
+    port0 = int(env.get("MASTER_PORT", "29500"))
+    guess = port0 + 37 * k
+    if guess > 65000:
+        guess = 20000 + (guess % 40000)
+    open(os.path.join(d, "attempt%d.rank%d" % (k, rank)), "w").close()
+    port_file = os.path.join(d, "attempt%d.port" % k)
+    if rank == 0:
+        port = free_port()
+        tmp = port_file + ".tmp"
+        with open(tmp, "w") as f:
+            f.write(str(port))
+        os.replace(tmp, port_file)
+    t_end = time.time() + wait_s
+    port = None
+    while time.time() < t_end:
+        if port is None and os.path.exists(port_file):
+            try:
+                port = int(open(port_file).read().strip())
+            except ValueError:
+                port = None
+        if port is not None and all(os.path.exists(os.path.join(d, "attempt%d.rank%d" % (k, r))) for r in range(world)):
+            return port
+        time.sleep(0.1)
+    _log("rank %d: retry %d not confirmed by every supervisor within %.0f s; going on with port %d" % (rank, k, wait_s, port or guess))
+    return port or guess
 
 
 def supervise_one(script, argv, deadline_s=900):
@@ -138,12 +235,20 @@ def supervise_one(script, argv, deadline_s=900):
     local = int(os.environ.get("LOCAL_RANK", rank))
     port0 = int(os.environ.get("MASTER_PORT", "29500"))
     why = "no attempt made"
-    for k, (backend, exchange) in enumerate(attempts_from_env(os.environ)):
+    attempts = attempts_from_env(os.environ)
+    budget = Budget(deadline_s)
+    who = "rank %d: " % rank
+    for k, (backend, exchange) in enumerate(attempts):
         # attempt 0 meets on the launcher's own store; a retry needs a store no earlier attempt has written to
-        port = port0 if k == 0 else port0 + 37 * k
+        port = port0 if k == 0 else agree_on_retry(os.environ, rank, world, k, wait_s=min(90.0, max(5.0, budget.remaining() / 10)))
+        d = budget.deadline(attempts, k, who if rank else "")
+        if not d:
+            _log("%sattempt %d skipped: not enough of the budget left" % (who, k))
+            continue
         if rank == 0:
             _log("attempt %d: %d ranks under the external launcher, torch.distributed=%s, exchange=%s, port %d" % (k, world, backend, exchange, port))
-        ok, why = _run_attempt(cmd, [_child_env(os.environ, rank, local, world, port, k, backend, exchange, k > 0)], deadline_s)
+        env = dict(os.environ, BENCH_ATTEMPT_LIMIT_S=str(d))
+        ok, why = _run_attempt(cmd, [_child_env(env, rank, local, world, port, k, backend, exchange, k > 0)], d)
         if ok:
             return 0
         _log("rank %d, attempt %d failed: %s" % (rank, k, why))

@@ -136,43 +136,6 @@ def test_config_bn254_2p20():
     assert all(p[3] for p in plans)                                  # all three MSMs on window tables
 
 
-# ------------------------------------------------------------------ chunked sort of the table pipeline (round 4)
-@pytest.mark.parametrize("curve", CURVE_LIST)
-def test_msm_chunked_sort_one_bucket_set_vs_oracle(gpu_ctx, oracle, api, curve):
-    """PM_OPT_MSM_CHUNKS (msm.hip: msm_piece_tables): the pairs of a table-mode MSM sorted in K slices into ONE bucket set, slice
-    k + 1's sort under slice k's accumulation, the first task of every bucket continuing from the previous slice's partial.
-    2^20 + 4321 pairs (ragged slices), K = 1, 2, 3, 5 and 8, against the CPU oracle's point:
-      * uniform scalars;
-      * scalars that are zero in the second half of the pairs -- later slices have NO entries, every bucket's sum is only
-        carried forward (k_scan_tiles: prev_task_off) -- and zero in the FIRST half (the first slice is empty);
-      * one scalar value for all pairs: every window's digit lands in one bucket (thousands of tasks per slice, folded to one
-        record between the slices: fold_hot_buckets with fold_min = 1) -- and two values alternating by halves."""
-    n = (1 << 20) + 4321
-    bases = api.Bases.multiples(gpu_ctx, curve, n)
-    bases.precompute()
-    hb = bases.download()
-    uni = rand_fr_limbs(curve, n, 9191)
-    tail_zero, head_zero = uni.copy(), uni.copy()
-    tail_zero[n // 2:] = 0
-    head_zero[:n // 2 + 17] = 0
-    one_value = np.repeat(uni[:1], n, axis=0)
-    two_values = one_value.copy()
-    two_values[n // 2:] = uni[1]
-    for name, sc in (("uniform", uni), ("tail zero", tail_zero), ("head zero", head_zero), ("one value", one_value), ("two values", two_values)):
-        ref, rinf = oracle.msm(curve, hb, sc, 16)
-        for K in (1, 2, 3, 5, 8):
-            gpu_ctx.set_option("msm_chunks", K)
-            out, inf = bases.msm(sc)
-            assert inf == rinf and np.array_equal(out, ref), (name, K)
-    # shorter than the chunking threshold: the option is ignored, same point
-    gpu_ctx.set_option("msm_chunks", 4)
-    m = 300000
-    out, inf = bases.msm(uni[:m])
-    ref, rinf = oracle.msm(curve, hb[:m], uni[:m], 16)
-    assert inf == rinf and np.array_equal(out, ref)
-    bases.free()
-
-
 # ---------------------------------------------------------------------------- piece-split MSM at small size
 @pytest.mark.parametrize("curve", CURVE_LIST)
 @pytest.mark.parametrize("tables", [False, True])
@@ -256,8 +219,8 @@ def test_three_contexts_prove_concurrently_on_one_resident_key(oracle):
     different r_a against the SAME resident key at the same time, six proofs each: every proof equals the one the CPU
     oracle computes for that r_a (2^16 - 100 gates: three-level sort, window tables, two transform passes).
     Each context runs in a DIFFERENT mode, chosen through pm_ctx_set_option (the library keeps no process-wide state, like the
-    reference's `Polymath<E, T>`, lib.rs:44-50): context 0 the defaults ([a]_1 / [c]_1 concurrently, the quotient MSM's sort in
-    two chunks), context 1 everything back to back in one piece, context 2 every MSM in 2^14-pair pieces summed on the host."""
+    reference's `Polymath<E, T>`, lib.rs:44-50): context 0 the defaults ([a]_1 / [c]_1 concurrently), context 1 the two MSMs back
+    to back with 96-entry accumulation tasks, context 2 every MSM in 2^14-pair pieces summed on the host."""
     import threading
     from polymath_amd import circuits as PC
     from polymath_amd.polymath import Polymath
@@ -270,13 +233,12 @@ def test_three_contexts_prove_concurrently_on_one_resident_key(oracle):
     ras = [[g.fr(c.r), g.fr(c.r)] for _ in range(K)]
     want = [_oracle_reference(oracle, curve, lc, x, z, ra)[0] for ra in ras]
     pms = [Polymath(curve, "merlin", device=0) for _ in range(K)]
-    pms[0].ctx.set_option("msm_chunks", 2)
     pms[1].ctx.set_option("msm_overlap", 0)
-    pms[1].ctx.set_option("msm_chunks", 1)
+    pms[1].ctx.set_option("msm_task_len", 96)
     pms[2].ctx.set_option("msm_max_piece_log", 14)
     assert [p.ctx.get_option("msm_overlap") for p in pms] == [1, 0, 1] and pms[2].ctx.get_option("msm_max_piece_log") == 14
     with pytest.raises(Exception):
-        pms[0].ctx.set_option("msm_chunks", 99)             # out of range: PM_ERR_INVALID_ARG
+        pms[0].ctx.set_option("msm_max_piece_log", 99)      # out of range: PM_ERR_INVALID_ARG
     pk = pms[0].setup(lc, x, z)
     views = [pk] + [pk.view(p.ctx) for p in pms[1:]]
     got, errs = [[None] * ROUNDS for _ in range(K)], [None] * K

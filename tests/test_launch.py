@@ -22,6 +22,77 @@ def test_attempt_list_and_pinning():
     assert e["BENCH_NO_RCCL"] == "1" and "TORCHELASTIC_USE_AGENT_STORE" not in e and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_budget_two_hung_rccl_attempts_still_leave_the_host_staged_attempt_400_s():
+    """one global budget (1 500 s, inside the driver's 1 800 s).  Worst case: the two RCCL attempts hang until
+    their deadlines -- the gloo + callbacks attempt must still get >= 400 s, and the chain must end inside the budget."""
+    from polymath_amd import launch
+    A = launch.ATTEMPTS
+    assert A[2] == ("gloo", "callbacks")
+    stage_sum = 600 + 3 * 25 + 120                       # bench.py's stage sum at --steps 20 --warmup 5
+    left = float(launch.TOTAL_BUDGET_S)
+    d0 = launch.attempt_deadline(A, 0, left, stage_sum)
+    left -= d0
+    d1 = launch.attempt_deadline(A, 1, left, stage_sum)
+    left -= d1
+    d2 = launch.attempt_deadline(A, 2, left, stage_sum)
+    assert d0 >= 300 and d1 >= 300, (d0, d1)              # a healthy 8-GPU attempt needs ~200 s
+    assert d2 >= 400, (d0, d1, d2)
+    assert d0 + d1 + d2 <= launch.TOTAL_BUDGET_S - launch.EXIT_MARGIN_S
+    left -= d2
+    assert launch.attempt_deadline(A, 3, left, stage_sum) == 0        # nothing worth starting is left: skipped, not overrun
+    # a pinned single configuration (tests, BENCH_DIST_BACKEND) may use the whole budget up to its stage sum
+    assert launch.attempt_deadline([("gloo", "callbacks")], 0, 1500.0, stage_sum) == stage_sum
+    # the arithmetic never hands out more than is left
+    for rem in (50, 100, 430, 500, 900, 1500, 3000):
+        for k in range(4):
+            assert launch.attempt_deadline(A, k, float(rem), stage_sum) <= max(0, rem - launch.EXIT_MARGIN_S)
+
+
+def test_supervisor_walks_the_chain_inside_its_budget_with_hanging_children(tmp_path):
+    """The same, live and small: children that hang in the RCCL attempts and succeed in the host-staged one; a 14 s budget with a
+    5 s reserve.  The supervisor kills the hung attempts on time, the third attempt runs and wins, the budget lines are printed."""
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\n"
+                     "if os.environ.get('BENCH_NO_RCCL') != '1':\n"
+                     "    time.sleep(600)\n"
+                     "print('{\"ok\": %s}' % os.environ['BENCH_ATTEMPT'] if os.environ['RANK'] == '0' else '', flush=True)\n")
+    code = ("import sys; sys.path.insert(0, %r); from polymath_amd import launch; launch.MIN_ATTEMPT_S = 2; launch.EXIT_MARGIN_S = 1; "
+            "raise SystemExit(launch.supervise_all(%r, [], 2, 100))" % (ROOT, str(child)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_DIST_BACKEND", "BENCH_NO_RCCL")}
+    env.update(BENCH_TOTAL_BUDGET_S="14", BENCH_FALLBACK_RESERVE_S="5")
+    t0 = time.time()
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    dt = time.time() - t0
+    assert run.returncode == 0, run.stderr
+    assert run.stdout.strip() == '{"ok": 2}', run.stdout
+    assert run.stderr.count("budget:") == 3 and "attempt 0 failed: deadline" in run.stderr and "attempt 1 failed: deadline" in run.stderr
+    assert dt < 14 + 25, dt                                # the two hung attempts end at ~4.8 s and ~8 s (+ up to 10 s of SIGTERM grace each)
+
+
+def test_retry_port_is_agreed_between_the_supervisors(tmp_path):
+    """Under an external launcher a retry meets on a port rank 0 found FREE and published (MASTER_PORT + 37 k was a
+    guess), and only once every supervisor has arrived at the retry."""
+    import threading
+    from polymath_amd import launch
+    env = {"TORCHELASTIC_RUN_ID": "t%d" % os.getpid(), "MASTER_PORT": "65530"}
+    got = [None] * 3
+
+    def sup(r, delay):
+        time.sleep(delay)
+        got[r] = launch.agree_on_retry(env, r, 3, 1, wait_s=20.0)
+    th = [threading.Thread(target=sup, args=(r, 0.3 * r)) for r in range(3)]
+    t0 = time.time()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(30)
+    assert got[0] == got[1] == got[2] and 1024 < got[0] < 65536
+    assert time.time() - t0 >= 0.55                        # nobody left before the slowest supervisor had arrived
+    # nobody publishes (rank 0 is gone): the bounded wait ends and the guess is validated into the port range
+    env2 = dict(env, TORCHELASTIC_RUN_ID="u%d" % os.getpid())
+    assert 1024 < launch.agree_on_retry(env2, 1, 2, 2, wait_s=0.5) < 65536
+
+
 def test_launcher_module_touches_neither_torch_nor_the_gpu():
     """The parent of the ranks must never initialise the GPU (a process that has may not start another program on this pool)."""
     code = "import sys; from polymath_amd import launch; assert 'torch' not in sys.modules and 'polymath_amd.api' not in sys.modules; print('clean')"

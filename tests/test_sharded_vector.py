@@ -532,6 +532,70 @@ class _Hip:
         for p in ps:
             self.lib.hipFree(p)
 
+    def stream(self):
+        st = self.ct.c_void_p()
+        self.lib.hipStreamCreateWithFlags.argtypes = [self.ct.POINTER(self.ct.c_void_p), self.ct.c_uint]
+        assert self.lib.hipStreamCreateWithFlags(self.ct.byref(st), 1) == 0          # hipStreamNonBlocking
+        return st
+
+    def sync(self, st):
+        self.lib.hipStreamSynchronize.argtypes = [self.ct.c_void_p]
+        assert self.lib.hipStreamSynchronize(st) == 0
+
+
+def _two_stream_exchanges(comms, order):
+    """Every rank issues the four all-to-alls of one proof's transforms (prover.rs:93-96: u and w are independent; then the
+    forward / inverse pair of the square) on TWO streams of its ONE communicator, in `order` = a permutation of
+    ("u", "w", "sq_fwd", "sq_inv") that all ranks share; "w" goes to the second stream.  -> nothing; asserts the delivered blocks."""
+    N = len(comms)
+    hip = _Hip()
+    words = 512                                                    # 4 KiB blocks
+    names = ("u", "w", "sq_fwd", "sq_inv")
+
+    def tag(kind, src, dst):
+        return (names.index(kind) << 40) | (src << 20) | dst
+
+    def body(r):
+        s_main, s_side = hip.stream(), hip.stream()
+        bufs = {}
+        for kind in names:
+            send = np.concatenate([np.full(words, tag(kind, r, p), dtype=np.int64) for p in range(N)])
+            bufs[kind] = (hip.upload(send), hip.upload(np.full(N * words, -1, dtype=np.int64)), send)
+        for kind in order:
+            d_send, d_recv, send = bufs[kind]
+            comms[r].all_to_all_device(d_send.value, d_recv.value, words * 8, (s_side if kind == "w" else s_main).value)
+        hip.sync(s_main)
+        hip.sync(s_side)
+        for kind in names:
+            d_send, d_recv, send = bufs[kind]
+            got = hip.download(d_recv, send).reshape(N, words)
+            assert all((got[p] == tag(kind, p, r)).all() for p in range(N)), (kind, r)
+            hip.free(d_send, d_recv)
+        return True
+    for c in comms:
+        c.set_timeout_ms(20000)                                     # a deadlock would end as PM_ERR_COMM after 20 s, not as a hang
+    assert _run_ranks(N, body, comms, timeout=120) == [True] * N
+
+
+@pytest.mark.gpu
+def test_exchanges_from_two_streams_of_one_communicator_in_both_orders():
+    """VERDICT r3 item 6 (PM_OPT_NTT_OVERLAP is the default since round 4): the four exchanges of a proof's transforms issued from
+    two streams of ONE communicator -- u first then w (the prover's order), and w first then u -- on 8 rank-threads of the
+    in-process group, and on the RCCL communicator with a world of one; every block arrives, nothing deadlocks (each case runs
+    under the communicators' fail-fast deadline)."""
+    from polymath_amd import api
+    for order in (("u", "w", "sq_fwd", "sq_inv"), ("w", "u", "sq_fwd", "sq_inv"), ("u", "sq_fwd", "w", "sq_inv")):
+        comms = api.Comm.local_group(8)
+        _two_stream_exchanges(comms, order)
+        assert not any(c.failed for c in comms)
+        for c in comms:
+            c.close()
+    for order in (("u", "w", "sq_fwd", "sq_inv"), ("w", "u", "sq_fwd", "sq_inv")):
+        comm = api.Comm.rccl(api.Comm.rccl_unique_id(), 0, 1, 0)
+        _two_stream_exchanges([comm], order)
+        assert not comm.failed
+        comm.close()
+
 @pytest.mark.gpu
 def test_rccl_comm_world_of_one():
     """The RCCL implementation of pm_comm (librccl dlopen'ed by the library, ncclCommInitRank / ncclAllToAll / ncclAllGather)
@@ -578,40 +642,62 @@ hip.hipStreamCreate.argtypes = [ct.POINTER(ct.c_void_p)]
 hip.hipMemcpyAsync.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p]
 hip.hipStreamSynchronize.argtypes = [ct.c_void_p]
 ctx = api.Context(0)
-comm = api.Comm.rccl(api.Comm.rccl_unique_id(), 0, 1, 0)
-assert comm.kind == "rccl" and not comm.failed
 st = ct.c_void_p()
 assert hip.hipStreamCreate(ct.byref(st)) == 0
-big = 1 << 30
-a, b, s, r = ct.c_void_p(), ct.c_void_p(), ct.c_void_p(), ct.c_void_p()
-for p, n in ((a, big), (b, big), (s, 4096), (r, 4096)):
+big, huge = 1 << 30, 16 << 30
+a, b, s, r, hs, hr = (ct.c_void_p() for _ in range(6))
+for p, n in ((a, big), (b, big), (s, 4096), (r, 4096), (hs, huge), (hr, huge)):
     assert hip.hipMalloc(ct.byref(p), n) == 0
-comm.all_to_all_device(s.value, r.value, 4096, st.value)            # healthy: completes
-assert hip.hipStreamSynchronize(st) == 0 and not comm.failed
-comm.set_timeout_ms(2)
-for _ in range(400):                                                 # ~0.5 s of copies queued AHEAD of the collective
+
+def wait_failed(comm, seconds=20):
+    deadline = time.time() + seconds
+    while not comm.failed and time.time() < deadline:
+        time.sleep(0.01)
+    return comm.failed
+
+# 1. healthy, with work queued AHEAD of the collective that takes several deadlines: the clock of a collective starts when the
+#    collective reaches the head of its stream, so it completes (the round-3 watchdog counted from the enqueue and aborted here)
+comm = api.Comm.rccl(api.Comm.rccl_unique_id(), 0, 1, 0)
+assert comm.kind == "rccl" and not comm.failed
+comm.set_timeout_ms(60)
+for _ in range(150):                                                 # ~0.2 s of copies ahead, 3 deadlines' worth
     assert hip.hipMemcpyAsync(b, a, big, 3, st) == 0
+comm.all_to_all_device(s.value, r.value, 4096, st.value)
+assert hip.hipStreamSynchronize(st) == 0
+time.sleep(0.1)
+assert not comm.failed, comm.last_error()
+print("HEALTHY behind queued work")
+# 2. the collective ITSELF misses its deadline: 16 GiB through a world-of-one all-to-all take ~15 ms, the deadline is 2 ms
+comm.set_timeout_ms(2)
 t0 = time.time()
-comm.all_to_all_device(s.value, r.value, 4096, st.value)            # cannot complete within 2 ms: the watchdog must abort the communicator
+comm.all_to_all_device(hs.value, hr.value, huge, st.value)
 hip.hipStreamSynchronize(st)
-deadline = time.time() + 20
-while not comm.failed and time.time() < deadline:
-    time.sleep(0.01)
-assert comm.failed, "the watchdog did not fire"
+assert wait_failed(comm), "the watchdog did not fire"
 print("FIRED after %.2f s: %s" % (time.time() - t0, comm.last_error()))
 try:
     comm.all_gather(np.arange(3, dtype=np.int64))
     print("STILL ALIVE")
 except api.PolymathError as e:
     print("STICKY", e.status)
+# 3. a stream that never gets to the collective is bounded too: 8 deadlines from the enqueue
+comm2 = api.Comm.rccl(api.Comm.rccl_unique_id(), 0, 1, 0)
+comm2.set_timeout_ms(10)
+for _ in range(600):                                                 # ~0.8 s of copies ahead of an 80 ms ceiling
+    assert hip.hipMemcpyAsync(b, a, big, 3, st) == 0
+comm2.all_to_all_device(s.value, r.value, 4096, st.value)
+assert wait_failed(comm2), "the ceiling did not fire"
+print("CEILING: %s" % comm2.last_error())
+hip.hipStreamSynchronize(st)
 """
 
 
 @pytest.mark.gpu
 def test_rccl_watchdog_aborts_a_collective_that_misses_its_deadline(tmp_path):
-    """The RCCL half of the fail-fast contract, on the one GPU of this box: a communicator (world of one) with a 2 ms deadline and
-    a collective queued behind half a second of copies on its stream -- the completion event cannot arrive in time, so the
-    watchdog thread must call ncclCommAbort and mark the communicator failed; later collectives return PM_ERR_COMM at once.
+    """The RCCL half of the fail-fast contract, on the one GPU of this box (world of one).  (1) A collective queued behind several
+    deadlines' worth of other work on its stream completes: its clock starts when it reaches the head of the stream (ADVICE r3:
+    it used to start at the enqueue).  (2) A collective that itself takes longer than the deadline -- 16 GiB against 2 ms -- makes
+    the watchdog thread call ncclCommAbort and mark the communicator failed; later collectives return PM_ERR_COMM at once.
+    (3) A stream that does not reach the collective within 8 deadlines fails it as well.
     (A real dead PEER cannot be staged on one GPU -- RCCL refuses two ranks on one device; this exercises the watchdog, the abort
     and the sticky failure on the real library.)  Runs in a child process: a misbehaving abort must not take pytest down."""
     import os, subprocess, sys
@@ -620,8 +706,10 @@ def test_rccl_watchdog_aborts_a_collective_that_misses_its_deadline(tmp_path):
     script.write_text(_WATCHDOG_SCRIPT)
     run = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-3000:])
+    assert "HEALTHY behind queued work" in run.stdout
     assert "FIRED" in run.stdout and "did not complete within 2 ms" in run.stdout and "STICKY 9" in run.stdout, run.stdout
-    assert "aborting the RCCL communicator" in run.stderr
+    assert "CEILING" in run.stdout and "was not reached by its stream within 80 ms" in run.stdout, run.stdout
+    assert run.stderr.count("aborting the RCCL communicator") == 2
 
 
 @pytest.mark.gpu
