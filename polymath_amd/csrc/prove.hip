@@ -521,20 +521,32 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
                            flags);
         PM_HIP(ctx, hipGetLastError());
     }
-    unsigned hflags = 0;
-    PM_HIP(ctx, hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
-    PM_HIP(ctx, hipStreamSynchronize(st));
-    if (hflags & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
-    if ((hflags & 2u) || !(hflags & 4u)) return PM_ERR_DEGREE_BOUND;   // prover.rs:107
+    // The status flags ride behind the MSMs (round 4): they land in pinned staging and are read after the MSM's own final
+    // synchronisation, so the host does not wait here and the sort's fifteen launches are enqueued while the transforms still run.
+    // An unsatisfied witness (prover.rs:107-108) is reported after the MSMs it no longer stops -- the rare path pays, not the proof.
+    if (!ctx_pinned(ctx)) { ctx->err = "pinned staging allocation failed"; return PM_ERR_HIP; }
+    volatile unsigned *hflags_p = (volatile unsigned *)((uint8_t *)ctx->h_pinned + PINNED_SLOTS_BYTES);
+    *hflags_p = 0;
+    PM_HIP(ctx, hipMemcpyAsync((void *)hflags_p, flags, 4, hipMemcpyDeviceToHost, st));
     if (a_early) {
         const int st_c = msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
         helper.join();
         for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];
+        if (st_c == PM_OK || st_a == PM_OK) PM_HIP(ctx, hipStreamSynchronize(st));
+        const unsigned hf = *hflags_p;
+        if (hf & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
+        if ((hf & 2u) || !(hf & 4u)) return PM_ERR_DEGREE_BOUND;       // prover.rs:107
         if (st_a != PM_OK) { ctx->err = ctx->aux->err; return st_a; }
         PM_TRY(st_c);
     } else {
-        PM_TRY(msm_shard<C>(ctx, pk, 0, sc_a, a_xy, a_inf));
-        PM_TRY(msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf));
+        const int s_a = msm_shard<C>(ctx, pk, 0, sc_a, a_xy, a_inf);
+        const int s_c = s_a == PM_OK ? msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf) : (int)PM_OK;
+        PM_HIP(ctx, hipStreamSynchronize(st));
+        const unsigned hf = *hflags_p;
+        if (hf & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
+        if ((hf & 2u) || !(hf & 4u)) return PM_ERR_DEGREE_BOUND;       // prover.rs:107
+        PM_TRY(s_a);
+        PM_TRY(s_c);
     }
     t_phase.stop();
     timing_flush(ctx);
@@ -638,11 +650,15 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
             PM_HIP(ctx, hipGetLastError());
         }
     }
-    unsigned hflags = 0;
-    PM_HIP(ctx, hipMemcpyAsync(&hflags, flags, 4, hipMemcpyDeviceToHost, st));
+    // rem == 0 (prover.rs:221) is read after the MSM's final synchronisation: no host wait between the division and the sort
+    if (!ctx_pinned(ctx)) { ctx->err = "pinned staging allocation failed"; return PM_ERR_HIP; }
+    volatile unsigned *hflags_p = (volatile unsigned *)((uint8_t *)ctx->h_pinned + PINNED_SLOTS_BYTES);
+    *hflags_p = 0;
+    PM_HIP(ctx, hipMemcpyAsync((void *)hflags_p, flags, 4, hipMemcpyDeviceToHost, st));
+    const int st_d = msm_shard<C>(ctx, pk, 2, q, d_xy, d_inf);   // [d]_1 = M8, prover.rs:229
     PM_HIP(ctx, hipStreamSynchronize(st));
-    if (hflags & 8u) return PM_ERR_REMAINDER_NONZERO;  // prover.rs:221
-    PM_TRY(msm_shard<C>(ctx, pk, 2, q, d_xy, d_inf));   // [d]_1 = M8, prover.rs:229
+    if (*hflags_p & 8u) return PM_ERR_REMAINDER_NONZERO;  // prover.rs:221
+    PM_TRY(st_d);
     t_phase.stop();
     timing_flush(ctx);
     ctx->phase = 3;
