@@ -374,7 +374,7 @@ MsmTables wide_plan(size_t piece) {
 // they are accumulated with atomics -- exactly: every product (a canonical residue) is split into eight 32-bit words and each word
 // is added to its own 64-bit counter (2^32 terms of 32 bits fit), the counters are carried and reduced once per column
 // (k_lcs_finish).  Integer sums commute, so the result does not depend on the order the rows arrive in: bit-identical to the host
-// pass it replaces (tests: the bases against the pyref fixtures and oracle/cpp).
+// pass it replaces (the parity tests compare the bases with the committed fixtures and with the CPU restatement).
 template <class P>
 __global__ void k_lagrange(Fp<P> *L, Fp<P> *pre, size_t n, Fp<P> x, Fp<P> omega, Fp<P> kscale, unsigned CH) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -50,16 +50,16 @@ __global__ __launch_bounds__(256, 2) void k(uint32_t *out, int iters) {
 template <int MODE, int G>
 static void run(const char *name, int cus, int w, uint32_t *out, int iters) {
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k<MODE, G><<<cus * w, 256>>>(out, 16);
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
-        hipEventRecord(e0);
+        (void)hipEventRecord(e0);
         k<MODE, G><<<cus * w, 256>>>(out, iters);
-        hipEventRecord(e1);
-        hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
     const double cyc = best * 1e-3 * 2.4e9 / ((double)iters * w);   // nominal cycles per loop body per wave slot
@@ -72,7 +72,7 @@ int main() {
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { printf("no device\n"); return 1; }
     const int cus = prop.multiProcessorCount, iters = 20000;
     uint32_t *out;
-    hipMalloc(&out, (size_t)cus * 2 * 256 * 4);
+    (void)hipMalloc(&out, (size_t)cus * 2 * 256 * 4);
     for (int w : {1, 2}) {
         run<1, 4>("16 mfma", cus, w, out, iters);
         run<2, 4>("16 x 4 mad", cus, w, out, iters);
