@@ -304,20 +304,23 @@ template <class C>
 PM_HD bool xyzz28_madd_limbs(XYZZ28<C> &acc, const F28<typename C::FqRR> &x2, F28<typename C::FqRR> y2, bool negate) {
     typedef typename C::FqRR RR;
     typedef F28<RR> F;
-    if (negate) y2 = f28_weak_norm<RR>(f28_sub_k4<RR>(f28_zero<RR>(), y2));  // 4p - y: W, < 4p
+    // 4p - y as a MULTIPLICAND needs no carry propagation: limbs < 2^29 (e = 1) against a tight ZZZ stay inside the column bound
+    // (e_a + e_b <= 4), value < 4p.  (Round 4: the 42-instruction weak normalisation moved to the rare first-point branch.)
+    if (negate) y2 = f28_sub_k4<RR>(f28_zero<RR>(), y2);
     if (f28_all_zero<RR>(acc.ZZ)) {
         acc.X = x2;
-        acc.Y = y2;
+        acc.Y = f28_weak_norm<RR>(y2);                     // the accumulator's Y is W: tight limbs (K16 must dominate them)
         acc.ZZ = f28_one<RR>();
         acc.ZZZ = f28_one<RR>();
         return true;
     }
     const F U2 = f28_mul<RR>(x2, acc.ZZ);                  // T
-    const F S2 = f28_mul<RR>(y2, acc.ZZZ);                 // y2 W(<4p) x T -> T
+    const F S2 = f28_mul<RR>(y2, acc.ZZZ);                 // y2 (limbs < 2^29, < 4p) x T -> T
     const F P = f28_sub_k16<RR>(U2, acc.X);                // L e<=2, < 18p
     const F R = f28_sub_k16<RR>(S2, acc.Y);                // L e<=2, < 18p
     const F PP = f28_sqr<RR>(P);                           // e 2+2, 18p*18p < 2^8.4 p^2 -> T
-    if (f28_is_zero_mod_p<RR>(PP)) return false;           // P == 0 (mod p): exceptional
+    // P == 0 (mod p) <=> PP in {0, p}: the low limb decides in all but 2^-27 of the cases, the 42-instruction compare is behind it
+    if ((PP.l[0] == 0u || PP.l[0] == RR::MOD[0]) && f28_is_zero_mod_p<RR>(PP)) return false;   // exceptional
     const F PPP = f28_mul<RR>(P, PP);                      // T
     const F Q = f28_mul<RR>(acc.X, PP);                    // W(<14p) x T -> T
     const F RR2 = f28_sqr<RR>(R);                          // T
