@@ -187,9 +187,10 @@ def supervise_all(script, argv, world, deadline_s=900):
 
 def _rendezvous_dir(env):
     """Where the supervisors of ONE externally launched job (one node) meet between attempts: a directory named by the launcher's
-    run id and master port."""
+    run id, master port and process id (the workers of one launcher share their parent; back-to-back jobs that reuse a port and a
+    run id -- the driver's N = 2, 4, 8 series -- must not meet each other's files)."""
     import tempfile
-    tag = "%s_%s" % (env.get("TORCHELASTIC_RUN_ID", "norun"), env.get("MASTER_PORT", "29500"))
+    tag = "%s_%s_%s" % (env.get("TORCHELASTIC_RUN_ID", "norun"), env.get("MASTER_PORT", "29500"), env.get("PM_LAUNCHER_PID", os.getppid()))
     d = os.path.join(tempfile.gettempdir(), "pm_bench_" + "".join(c if c.isalnum() or c in "_-" else "_" for c in tag))
     os.makedirs(d, exist_ok=True)
     return d

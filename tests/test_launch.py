@@ -74,7 +74,8 @@ def test_retry_port_is_agreed_between_the_supervisors(tmp_path):
     guess), and only once every supervisor has arrived at the retry."""
     import threading
     from polymath_amd import launch
-    env = {"TORCHELASTIC_RUN_ID": "t%d" % os.getpid(), "MASTER_PORT": "65530"}
+    env = {"TORCHELASTIC_RUN_ID": "t%d" % os.getpid(), "MASTER_PORT": "65530", "PM_LAUNCHER_PID": "1"}
+    assert launch._rendezvous_dir(env) != launch._rendezvous_dir(dict(env, PM_LAUNCHER_PID="2"))      # another launcher, another directory
     got = [None] * 3
 
     def sup(r, delay):
