@@ -1,8 +1,8 @@
 // C ABI of libpolymath_hip.so (include/polymath_hip.h): context / key management and dispatch
 // on the curve.  All compute is in the .hip kernels; the host code here only moves buffers,
-// removes row-duplicate R1CS entries the reference cannot see (m_at, common.rs:100-105), and
-// prepares the O(nnz) setup scalars.
+// and removes row-duplicate R1CS entries the reference cannot see (m_at, common.rs:100-105) when a matrix has any.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -535,19 +535,48 @@ static uint64_t pk_resident_points(const pm_pk *pk) {
 }
 
 template <class C>
-static int pk_upload_matrices(pm_ctx *ctx, pm_pk *pk, const pm_csr *a, const pm_csr *b, const pm_csr *c, HostCsr host[3]) {
+static int pk_upload_matrices(pm_ctx *ctx, pm_pk *pk, const pm_csr *a, const pm_csr *b, const pm_csr *c) {
     const pm_csr *m[3] = {a, b, c};
+    const uint64_t nr = pk->nr, ncols = pk->m0 + pk->mw;
     for (int i = 0; i < 3; ++i) {
-        PM_TRY(dedupe_csr(m[i], pk->nr, pk->m0 + pk->mw, host[i]));
-        pk->nnz[i] = host[i].col.size();
-        PM_HIP(ctx, hipMalloc((void **)&pk->d_rowptr[i], host[i].rowptr.size() * 8));
-        PM_HIP(ctx, hipMemcpy(pk->d_rowptr[i], host[i].rowptr.data(), host[i].rowptr.size() * 8, hipMemcpyHostToDevice));
-        size_t nz = host[i].col.size() ? host[i].col.size() : 1;
+        if (!m[i] || m[i]->nrows != nr || !m[i]->rowptr) return PM_ERR_INVALID_ARG;
+        // One parallel pass over the rows: column range, and whether ANY row repeats a column (m_at, common.rs:100-105, only ever
+        // sees the first entry).  Without repeats -- every circuit ark-relations' `to_matrices` produces after its own
+        // linear-combination merging, and the synthetic ones -- the caller's arrays go to the device as they are: no host copy
+        // (round 4: the copying first-entry pass was 1.05 s of host time at 2^24 gates).
+        std::atomic<int> bad{0}, repeats{0};
+        const pm_csr *mi = m[i];
+        parallel_chunks(nr, [&](uint64_t lo, uint64_t hi, unsigned) {
+            for (uint64_t r = lo; r < hi; ++r) {
+                const uint64_t k0 = mi->rowptr[r], k1 = mi->rowptr[r + 1];
+                if (k1 < k0) { bad = 1; return; }
+                for (uint64_t k = k0; k < k1; ++k) {
+                    if (mi->col[k] >= ncols) { bad = 1; return; }
+                    for (uint64_t q = k0; q < k; ++q)
+                        if (mi->col[q] == mi->col[k]) { repeats = 1; break; }
+                }
+            }
+        });
+        if (bad) return PM_ERR_INVALID_ARG;
+        HostCsr h;
+        const uint64_t *rowptr = mi->rowptr, *val = mi->val;
+        const uint32_t *col = mi->col;
+        uint64_t nnz = nr ? mi->rowptr[nr] - mi->rowptr[0] : 0;
+        if (repeats || (nr && mi->rowptr[0] != 0)) {
+            PM_TRY(dedupe_csr(mi, nr, ncols, h));
+            rowptr = h.rowptr.data(); col = h.col.data(); val = h.val.data();
+            nnz = h.col.size();
+        }
+        const uint64_t zero_row = 0;
+        pk->nnz[i] = nnz;
+        PM_HIP(ctx, hipMalloc((void **)&pk->d_rowptr[i], (nr + 1) * 8));
+        PM_HIP(ctx, hipMemcpy(pk->d_rowptr[i], nr ? rowptr : &zero_row, (nr + 1) * 8, hipMemcpyHostToDevice));
+        const size_t nz = nnz ? nnz : 1;
         PM_HIP(ctx, hipMalloc((void **)&pk->d_col[i], nz * 4));
         PM_HIP(ctx, hipMalloc((void **)&pk->d_val[i], nz * 32));
-        if (host[i].col.size()) {
-            PM_HIP(ctx, hipMemcpy(pk->d_col[i], host[i].col.data(), host[i].col.size() * 4, hipMemcpyHostToDevice));
-            PM_HIP(ctx, hipMemcpy(pk->d_val[i], host[i].val.data(), host[i].val.size() * 8, hipMemcpyHostToDevice));
+        if (nnz) {
+            PM_HIP(ctx, hipMemcpy(pk->d_col[i], col, nnz * 4, hipMemcpyHostToDevice));
+            PM_HIP(ctx, hipMemcpy(pk->d_val[i], val, nnz * 32, hipMemcpyHostToDevice));
         }
     }
     return PM_OK;
@@ -658,8 +687,7 @@ static int pk_load_impl(pm_ctx *ctx, uint64_t n, uint64_t m0, uint64_t mw, uint6
     for (int v = 0; v < PM_NUM_BASE_VECS; ++v)
         if (bases[v].len < pk->base_len[v] || bases[v].stride < sizeof(Affine<C>) || !bases[v].points)
             return guard(PM_ERR_LEN_MISMATCH);
-    HostCsr host[3];
-    st = pk_upload_matrices<C>(ctx, pk, a, b, c, host);
+    st = pk_upload_matrices<C>(ctx, pk, a, b, c);
     if (st) return guard(st);
     std::vector<Affine<C>> tmp;
     st = pk_fill_bases<C>(ctx, pk, [&](int v, uint64_t start, uint64_t count, Affine<C> *dst) -> int {
@@ -704,12 +732,14 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
     typedef Fp<P> Fr;
     pm_pk *pk = new pm_pk();
     auto guard = [&](int st) { if (st != PM_OK) pk_release(pk); return st; };
+    HostProfile hp("setup", shard_rank);            // PM_PROFILE_HOST=1: where the host thread's time goes (stderr)
     int st = pk_init_layout<C>(ctx, pk, m0, mw, nr, shard_rank, shard_count, layout);
     if (st) return guard(st);
-    HostCsr host[3];
-    st = pk_upload_matrices<C>(ctx, pk, a, b, c, host);
+    hp.mark("layout");
+    st = pk_upload_matrices<C>(ctx, pk, a, b, c);
     if (st) return guard(st);
-    const uint64_t n = pk->n, sigma = pk->sigma, mcols = m0 + mw, Lz = 2 * m0 + mw + nr;
+    hp.mark("matrices: first-entry pass + upload");
+    const uint64_t n = pk->n, sigma = pk->sigma, Lz = 2 * m0 + mw + nr;
     Fr x, z, omega;
     memcpy(x.l, x_trap, 32);
     memcpy(z.l, z_trap, 32);
@@ -733,6 +763,7 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
         d_lagrange.release();
         d_work.release();
     }
+    hp.mark("lcs scalars (device, synchronised)");
     const Fr *d_lcs = d_lcs_buf.as<Fr>();
     // per-vector scale of the x-power vectors (generator.rs:82-109)
     Fr scale[PM_NUM_BASE_VECS];
@@ -761,6 +792,7 @@ static int pk_generate_impl(pm_ctx *ctx, uint64_t m0, uint64_t mw, uint64_t nr, 
         return PM_OK;
     });
     if (st) return guard(st);
+    hp.mark("bases + tables (device, synchronised)");
     *out = pk;
     return PM_OK;
 }
