@@ -134,6 +134,9 @@ def _child_env(base, rank, local, world, port, attempt, backend, exchange, own_s
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: without it RCCL's ipc handles fail on this driver
     if exchange == "callbacks":
         e["BENCH_NO_RCCL"] = "1"
+        # the fallback of the fallback is the plainest configuration: one stream per rank for the exchanges as well (the
+        # two-stream transforms are the default since round 4 and have not met a fabric yet); a context's defaults come from here
+        e.setdefault("PM_NTT_OVERLAP", "0")
     else:
         e.pop("BENCH_NO_RCCL", None)
     if own_store:                                        # rank 0's child hosts the TCP store itself

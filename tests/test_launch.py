@@ -20,6 +20,8 @@ def test_attempt_list_and_pinning():
     e = launch._child_env({"TORCHELASTIC_USE_AGENT_STORE": "True", "X": "1"}, 3, 3, 8, 1234, 2, "gloo", "callbacks", True)
     assert (e["RANK"], e["WORLD_SIZE"], e["MASTER_PORT"], e["BENCH_ATTEMPT"], e["BENCH_CHILD"]) == ("3", "8", "1234", "2", "1")
     assert e["BENCH_NO_RCCL"] == "1" and "TORCHELASTIC_USE_AGENT_STORE" not in e and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert e["PM_NTT_OVERLAP"] == "0"                          # host-staged attempts also drop the two-stream transforms
+    assert "PM_NTT_OVERLAP" not in launch._child_env({}, 0, 0, 8, 1234, 0, "nccl", "rccl", True)
 
 
 def test_budget_two_hung_rccl_attempts_still_leave_the_host_staged_attempt_400_s():
