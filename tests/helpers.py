@@ -58,20 +58,4 @@ def pm_csrs(curve, r1cs):
     return out
 
 
-import contextlib
-
-
-@contextlib.contextmanager
-def ctx_options(ctx, **opts):
-    """pm_ctx_set_option for the body, the previous values back afterwards (the GPU context is shared by the session)."""
-    old = {k: ctx.get_option(k) for k in opts}
-    try:
-        for k, v in opts.items():
-            ctx.set_option(k, v)
-        yield ctx
-    finally:
-        for k, v in old.items():
-            ctx.set_option(k, v)
-
-
 TABLES_OPT = {"1": "auto", "0": "off", "wide": "wide"}     # the parametrisations' historical names (PM_TABLES values)
