@@ -26,6 +26,19 @@ def test_header_symbols_exported():
     assert sorted(api.EXPORTS) == syms
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/polymath_hip.h must compile as C99 (what cgo / bindgen / a JNI stub would feed it to)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "polymath_hip.h"\nint main(void) { pm_ctx *c = 0; (void)c; return PM_NUM_OPTIONS > 0 && PM_OK == 0 ? 0 : 1; }\n')
+    run = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o",
+                          str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+
+
 def test_integration_md_binds_every_symbol():
     """INTEGRATION.md's `extern "C"` block (what a Rust maintainer would paste) names exactly the header's entry points, and the
     counts quoted in its prose are the real one."""
