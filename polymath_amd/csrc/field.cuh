@@ -170,6 +170,16 @@ PM_HD Fp<P> mul_cios(const Fp<P> &a, const Fp<P> &b) {
     return r;
 }
 
+// acc += x * y, pinned: LLVM's reassociation orders a sum by dependency depth and would add the carry (the deepest operand) LAST,
+// as a separate 64-bit addition.  llvm.annotation is opaque to the IR optimiser and vanishes at instruction selection (an empty
+// inline asm does the same job but makes the hazard recogniser put an s_nop behind every one of them): the chain keeps the order
+// written here and each step is one v_mad_u64_u32 whose addend is the previous step.
+#if defined(__clang__)
+#define PM_PIN64(v) ((v) = __builtin_annotation((v), "pm_chain"))
+#else
+#define PM_PIN64(v) ((void)0)
+#endif
+
 // The same product a b 2^(-32 N) mod p, same canonical result, computed on W-bit limbs (Radix28<P>::RR: W = 28, or 29 for the
 // 254/255-bit scalar fields = 9 limbs): a 64-bit accumulator of v_mad_u64_u32 absorbs a whole column of W x W-bit products
 // (2 L 2^(2W) < 2^64), so there is no carry chain inside the loop (fq28.cuh uses the idea with its own radix; here the radix
@@ -190,47 +200,37 @@ PM_HD Fp<P> mul_r28(const Fp<P> &a, const Fp<P> &b) {
         A[i] = (uint32_t)(ta >> s) & MASK;
         B[i] = (uint32_t)(tb >> s) & MASK;
     }
-    uint64_t acc[L];
-#pragma unroll
-    for (int j = 0; j < L; ++j) acc[j] = 0;
-#pragma unroll
-    for (int i = 0; i < L - 1; ++i) {   // full steps: divide by 2^W each
-        const uint32_t bi = B[i];
-#pragma unroll
-        for (int j = 0; j < L; ++j) acc[j] += (uint64_t)A[j] * bi;
-        const uint32_t m = ((uint32_t)acc[0] * RR::INV) & MASK;
-#pragma unroll
-        for (int j = 0; j < L; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
-        const uint64_t carry = acc[0] >> W;
-#pragma unroll
-        for (int j = 0; j < L - 1; ++j) acc[j] = acc[j + 1];
-        acc[L - 1] = 0;
-        acc[0] += carry;
-    }
-    {   // partial step: clear the low TAIL bits only
-        const uint32_t bi = B[L - 1];
-#pragma unroll
-        for (int j = 0; j < L; ++j) acc[j] += (uint64_t)A[j] * bi;
-        uint32_t m = ((uint32_t)acc[0] * RR::INV) & ((1u << TAIL) - 1u);
-#if defined(__HIP_DEVICE_COMPILE__)
-        // TAIL = 24 (9 limbs of 29 bits) makes m a known-24-bit value: hipcc (ROCm 7.2) then forms a 24-bit multiply with the top
-        // limb of p, drops the mask as redundant for it, and fuses the product into v_mad_u64_u32 -- which does not truncate its
-        // operands (seen in the ISA: the unmasked -acc[0] times MOD[8]; 4 081 of 4 096 random products wrong on the device, none
-        // on the host).  Keeping the masked value opaque makes the compiler multiply the register it was given.
-        asm volatile("" : "+v"(m));
-#endif
-#pragma unroll
-        for (int j = 0; j < L; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
-    }
-    // carry-normalise (the top limb keeps its overflow), shift right by TAIL: value < 2p
+    // product scanning: one accumulator walks the columns, the carry of a column is the addend of the next column's first
+    // v_mad_u64_u32 (fq28.cuh has the reasoning and PM_PIN64).  Columns 0 .. L-2 clear W bits each, column L-1 only TAIL bits;
+    // columns L-1 .. 2L-2 are the result before the TAIL-bit shift (the top one keeps its overflow).
+    uint32_t m[L];
     uint64_t t[L];
-    uint64_t c = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < L; ++j) {
-        c += acc[j];
-        t[j] = j + 1 < L ? (c & MASK) : c;
-        c >>= W;
+    for (int k = 0; k < 2 * L - 1; ++k) {
+#pragma unroll
+        for (int i = (k < L ? 0 : k - L + 1); i <= (k < L ? k : L - 1); ++i) { acc += (uint64_t)A[i] * B[k - i]; PM_PIN64(acc); }
+#pragma unroll
+        for (int i = (k < L ? 0 : k - L + 1); i <= (k < L ? k - 1 : L - 1); ++i) { acc += (uint64_t)m[i] * RR::MOD[k - i]; PM_PIN64(acc); }
+        if (k < L - 1) {
+            m[k] = ((uint32_t)acc * RR::INV) & MASK;
+            acc += (uint64_t)m[k] * RR::MOD[0]; PM_PIN64(acc);
+        } else if (k == L - 1) {   // partial step: clear the low TAIL bits only
+            uint32_t mt = ((uint32_t)acc * RR::INV) & ((1u << TAIL) - 1u);
+#if defined(__HIP_DEVICE_COMPILE__)
+            // TAIL = 24 (9 limbs of 29 bits) makes mt a known-24-bit value: hipcc (ROCm 7.2) then forms a 24-bit multiply with the
+            // top limb of p, drops the mask as redundant for it, and fuses the product into v_mad_u64_u32 -- which does not truncate
+            // its operands (seen in the ISA: the unmasked -acc times MOD[8]; 4 081 of 4 096 random products wrong on the device, none
+            // on the host).  Keeping the masked value opaque makes the compiler multiply the register it was given.
+            asm volatile("" : "+v"(mt));
+#endif
+            m[k] = mt;
+            acc += (uint64_t)mt * RR::MOD[0]; PM_PIN64(acc);
+        }
+        if (k >= L - 1) t[k - (L - 1)] = k < 2 * L - 2 ? (acc & MASK) : acc;
+        acc >>= W;
     }
+    // shift right by TAIL: value < 2p
     uint32_t r28[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) {

@@ -6,8 +6,8 @@
 // (288 mads + 299 64-bit adds + 640 register moves).  Here an element is N limbs of W = 28 bits held in
 // u32 registers; the 64-bit accumulator of v_mad_u64_u32 then absorbs 2N products without overflow, so a
 // product is N*N mads for a*b plus N*N for the interleaved Montgomery reduction and NO carry chain:
-// ~490 instructions for BLS12-381 (N = 14).  Additions and subtractions are limb-wise v_add_u32 with
-// lazy carries (14 instructions instead of ~200).
+// 463 instructions for BLS12-381 (N = 14; 392 mads, 14 + 27 digit / limb masks, 14 v_mul_lo, 27 carry shifts).
+// Additions and subtractions are limb-wise v_add_u32 with lazy carries (14 instructions instead of ~200).
 //
 // Bounds discipline (R = 2^(W N) is >= 2^8 larger than p, so magnitudes up to ~45p are harmless):
 //   T ("tight")  limbs < 2^28,            value < 2p      -- every mul/sqr output
@@ -62,71 +62,61 @@ PM_HD bool f28_is_zero_mod_p(const F28<RR> &a) {
     return o == 0 || q == 0;
 }
 
-// Montgomery product, interleaved (CIOS) over 28-bit digits.  Output T.
+// ---- Montgomery products by product scanning (column by column): ONE 64-bit accumulator walks the 2N columns of a b + m p; the
+// carry out of a column (acc >> W) is the addend of the next column's first v_mad_u64_u32, so a product needs no 64-bit addition
+// at all.  (Rounds 1-4 ran the operand-scanning form -- N accumulators, one row of a b_i + m_i p per step -- which pays one
+// v_lshl_add_u64 per row and one per output limb: 26 of its 489 instructions, 234 of the mixed addition's 4 711; same digits m_k,
+// same column sums, same bounds, bit-identical outputs.  Same-box A/B: profiles/r04_product_scanning_ab.txt.)
+// (PM_PIN64, field.cuh, keeps every chain in the order written here.)
 template <class RR>
 PM_HD F28<RR> f28_mul(const F28<RR> &a, const F28<RR> &b) {
     constexpr int N = RR::N;
-    uint64_t acc[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) acc[j] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint32_t bi = b.l[i];
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)a.l[j] * bi;
-        const uint32_t m = ((uint32_t)acc[0] * RR::INV) & RR::MASK;
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
-        const uint64_t carry = acc[0] >> RR::W;
-#pragma unroll
-        for (int j = 0; j < N - 1; ++j) acc[j] = acc[j + 1];
-        acc[N - 1] = 0;
-        acc[0] += carry;
-    }
+    uint32_t m[N];
     F28<RR> r;
-    uint64_t c = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        c += acc[j];
-        r.l[j] = (uint32_t)c & RR::MASK;
-        c >>= RR::W;
+    for (int k = 0; k < 2 * N - 1; ++k) {
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); ++i) { acc += (uint64_t)a.l[i] * b.l[k - i]; PM_PIN64(acc); }
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k - 1 : N - 1); ++i) { acc += (uint64_t)m[i] * RR::MOD[k - i]; PM_PIN64(acc); }
+        if (k < N) {
+            m[k] = ((uint32_t)acc * RR::INV) & RR::MASK;
+            { acc += (uint64_t)m[k] * RR::MOD[0]; PM_PIN64(acc); }
+        } else {
+            r.l[k - N] = (uint32_t)acc & RR::MASK;
+        }
+        acc >>= RR::W;
     }
-    // value < 2p < 2^(W N): the final carry is zero
+    r.l[N - 1] = (uint32_t)acc;   // value < 2p < 2^(W N): the last column is the top limb itself
     return r;
 }
 
-// a*b + c*d with ONE interleaved Montgomery reduction (3 N^2 mads instead of 4 N^2).  Column bound:
+// a*b + c*d with ONE Montgomery reduction (3 N^2 mads instead of 4 N^2).  Column bound:
 // N 2^(56+ea+eb) + N 2^(56+ec+ed) + N 2^56 < 2^64; value bound (ab + cd) < 2^(W N) p.  Output T.
 template <class RR>
 PM_HD F28<RR> f28_mul2_add(const F28<RR> &a, const F28<RR> &b, const F28<RR> &c, const F28<RR> &d) {
     constexpr int N = RR::N;
-    uint64_t acc[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) acc[j] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint32_t bi = b.l[i], di = d.l[i];
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)a.l[j] * bi;
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)c.l[j] * di;
-        const uint32_t m = ((uint32_t)acc[0] * RR::INV) & RR::MASK;
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
-        const uint64_t carry = acc[0] >> RR::W;
-#pragma unroll
-        for (int j = 0; j < N - 1; ++j) acc[j] = acc[j + 1];
-        acc[N - 1] = 0;
-        acc[0] += carry;
-    }
+    uint32_t m[N];
     F28<RR> r;
-    uint64_t cc = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        cc += acc[j];
-        r.l[j] = (uint32_t)cc & RR::MASK;
-        cc >>= RR::W;
+    for (int k = 0; k < 2 * N - 1; ++k) {
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); ++i) { acc += (uint64_t)a.l[i] * b.l[k - i]; PM_PIN64(acc); }
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k : N - 1); ++i) { acc += (uint64_t)c.l[i] * d.l[k - i]; PM_PIN64(acc); }
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k - 1 : N - 1); ++i) { acc += (uint64_t)m[i] * RR::MOD[k - i]; PM_PIN64(acc); }
+        if (k < N) {
+            m[k] = ((uint32_t)acc * RR::INV) & RR::MASK;
+            { acc += (uint64_t)m[k] * RR::MOD[0]; PM_PIN64(acc); }
+        } else {
+            r.l[k - N] = (uint32_t)acc & RR::MASK;
+        }
+        acc >>= RR::W;
     }
+    r.l[N - 1] = (uint32_t)acc;
     return r;
 }
 
@@ -139,35 +129,26 @@ PM_HD F28<RR> f28_sqr(const F28<RR> &a) {
     uint32_t a2[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) a2[j] = a.l[j] << 1;
-    uint64_t acc[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) acc[j] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        // After i shifts acc[j] holds ORIGINAL column i + j.  Row i adds the diagonal a_i^2 (original
-        // column 2i -> local i) and the doubled cross terms 2 a_i a_j, j > i (original i + j -> local j).
-        // A term (k, l), k <= l, enters at iteration k <= (k + l) / 2, so original column i is complete
-        // when iteration i reads acc[0] for the Montgomery digit.
-        acc[i] += (uint64_t)a.l[i] * a.l[i];
-#pragma unroll
-        for (int j = i + 1; j < N; ++j) acc[j] += (uint64_t)a2[i] * a.l[j];
-        const uint32_t m = ((uint32_t)acc[0] * RR::INV) & RR::MASK;
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] += (uint64_t)m * RR::MOD[j];
-        const uint64_t carry = acc[0] >> RR::W;
-#pragma unroll
-        for (int j = 0; j < N - 1; ++j) acc[j] = acc[j + 1];
-        acc[N - 1] = 0;
-        acc[0] += carry;
-    }
+    uint32_t m[N];
     F28<RR> r;
-    uint64_t c = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        c += acc[j];
-        r.l[j] = (uint32_t)c & RR::MASK;
-        c >>= RR::W;
+    for (int k = 0; k < 2 * N - 1; ++k) {
+        // column k of a^2: 2 a_i a_(k-i) for i < k - i, plus a_(k/2)^2 on the even columns
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); 2 * i < k; ++i) { acc += (uint64_t)a2[i] * a.l[k - i]; PM_PIN64(acc); }
+        if ((k & 1) == 0) { acc += (uint64_t)a.l[k / 2] * a.l[k / 2]; PM_PIN64(acc); }
+#pragma unroll
+        for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k - 1 : N - 1); ++i) { acc += (uint64_t)m[i] * RR::MOD[k - i]; PM_PIN64(acc); }
+        if (k < N) {
+            m[k] = ((uint32_t)acc * RR::INV) & RR::MASK;
+            { acc += (uint64_t)m[k] * RR::MOD[0]; PM_PIN64(acc); }
+        } else {
+            r.l[k - N] = (uint32_t)acc & RR::MASK;
+        }
+        acc >>= RR::W;
     }
+    r.l[N - 1] = (uint32_t)acc;
     return r;
 }
 
