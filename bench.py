@@ -546,8 +546,8 @@ def worker(args):
             "valu": {"kernel": "k_accumulate", "unit": "lane-mads/s (v_mad_u64_u32)", "mads_per_mixed_add": MADS_PER_MIXED_ADD[curve],
                      "mixed_adds_per_pair": [p[1] for p in plans], "achieved": mads_rank / acc_s if acc_s > 0 else None, "peak": VALU_MAD_PEAK,
                      "frac": (mads_rank / acc_s / VALU_MAD_PEAK) if acc_s > 0 else None,
-                     "note": "the real bound of this kernel: mads are 75 % of its instruction stream (3 542 of 4 711 per mixed add, point load included); "
-                             "SQ counters (profiles/r02_pmc_valu_k_accumulate.json): 0.95 of the VALU issue slots, clock 1.98 GHz under this load"},
+                     "note": "the real bound of this kernel: mads are 79 % of its instruction stream (3 542 of 4 468 per mixed add, point load included); "
+                             "SQ counters (profiles/r04_pmc_sort_summary.txt): 0.94 of the VALU issue slots at the 2.0-2.1 GHz the package power limit leaves (profiles/r04_power_probe.txt)"},
             "stages": stage_report(curve, r1cs, pk, tm1_serial, tm3_serial, plans),
             "proof_bytes": proof_b.hex(),
             # Polymath::verify (verifier.rs:19-62) on the timed proof, by the library's own CPU verifier (pm_host_verify)
