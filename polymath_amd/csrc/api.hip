@@ -135,6 +135,7 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     ctx->h_pinned = nullptr;
     ctx->msm_async = 0;
     ctx->keep_timings = false;
+    ctx->lazy_timings = false;
     timing_reset(ctx);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -176,6 +177,11 @@ extern "C" const char *pm_last_error(const pm_ctx *ctx) { return ctx ? ctx->err.
 
 extern "C" int pm_last_timings(const pm_ctx *ctx, double *ms_out, int n_slots) {
     if (!ctx || !ms_out) return PM_ERR_INVALID_ARG;
+    if (!ctx->pending_timers.empty()) {   // pm_host_prove leaves its stage timers unread (internal.h: lazy_timings)
+        pm_ctx *c = const_cast<pm_ctx *>(ctx);
+        if (hipSetDevice(c->device) != hipSuccess) return PM_ERR_HIP;
+        timing_flush_now(c);
+    }
     for (int i = 0; i < n_slots; ++i) ms_out[i] = i < T_NUM_SLOTS ? ctx->timing_ms[i] : 0.0;
     return PM_OK;
 }

@@ -25,6 +25,7 @@ int host_prove_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *instance_host,
     int status = PM_OK;
     pm::timing_reset(ctx);
     ctx->keep_timings = true;      // pm_last_timings then covers the whole proof
+    ctx->lazy_timings = true;      // ... and reads the stage timers when asked, not between the phases
     try {
         pmhost::Polymath<C, T> pm(view);
         typename pmhost::Polymath<C, T>::Combine cb = nullptr;
@@ -55,6 +56,8 @@ int host_prove_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *instance_host,
         status = PM_ERR_STATE;
     }
     ctx->keep_timings = false;
+    ctx->lazy_timings = false;
+    if (ctx->aux) ctx->aux->lazy_timings = false;
     key.h = nullptr;   // borrowed: the destructor must not free the caller's key
     return status;
 }

@@ -265,6 +265,7 @@ struct pm_ctx {
     uint64_t x1_host[4];      // ... and the x1 they were taken at
     uint64_t ra_host[8];      // r_a of the proof in flight (phase 3's numerator constants need it on the host)
     bool keep_timings;   // pm_host_prove: the stage slots accumulate over the three phases of one proof
+    bool lazy_timings;   // ... and are read by pm_last_timings instead of at the end of every phase (timing_flush)
     pm::DevBuf xw, ue, we, u, w, wit_u, u2, sc_a, sc_c, quotient, ztail, lvl[6], ra;
     // PM_SHARD_VECTOR prover (prove_sharded.hip): transform temporaries, halo coefficients, roots of the cross-rank butterfly
     pm::DevBuf sh_a, sh_b, sh_c, halo, shard_roots;
@@ -419,6 +420,10 @@ inline void *ctx_pinned(pm_ctx *ctx) {
 
 inline void timing_reset(pm_ctx *ctx) {
     for (int i = 0; i < T_NUM_SLOTS; ++i) ctx->timing_ms[i] = 0;
+    // timers nobody asked for (lazy mode, below): their events go back to the pool unread -- the work they bracket finished with the
+    // call that recorded them
+    for (auto &t : ctx->pending_timers) { ctx->event_pool.push_back(t.a); ctx->event_pool.push_back(t.b); }
+    ctx->pending_timers.clear();
 }
 
 // hipEvent stage timers (replace start_timer!/end_timer!, prover.rs:32-61).  Events are only
@@ -449,7 +454,9 @@ struct StageTimer {
     ~StageTimer() { stop(); }
 };
 
-inline void timing_flush(pm_ctx *ctx) {
+// Reading ~18 event pairs costs ~40 us of host time per phase, with the GPU idle between the phases of a proof: pm_host_prove sets
+// lazy_timings, the phases then leave their timers pending and pm_last_timings reads them when (if) somebody asks.
+inline void timing_flush_now(pm_ctx *ctx) {
     for (auto &t : ctx->pending_timers) {
         float ms = 0;
         if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess)
@@ -458,6 +465,19 @@ inline void timing_flush(pm_ctx *ctx) {
         ctx->event_pool.push_back(t.b);
     }
     ctx->pending_timers.clear();
+}
+inline void timing_flush(pm_ctx *ctx) {
+    if (!ctx->lazy_timings) timing_flush_now(ctx);
+}
+// the helper context of the second MSM pipeline: reset / hand its stage times (or, lazily, its pending timers) to the owner
+inline void timing_reset_aux(pm_ctx *ctx, pm_ctx *aux) {
+    for (int i = 0; i < T_NUM_SLOTS; ++i) aux->timing_ms[i] = 0;   // its pending timers stay: the sharded prover's w transform ran on it
+    aux->lazy_timings = ctx->lazy_timings;
+}
+inline void timing_absorb_aux(pm_ctx *ctx, pm_ctx *aux) {
+    for (int s = 0; s < T_NUM_SLOTS; ++s) { ctx->timing_ms[s] += aux->timing_ms[s]; aux->timing_ms[s] = 0; }
+    for (auto &t : aux->pending_timers) ctx->pending_timers.push_back(t);
+    aux->pending_timers.clear();
 }
 
 // Declared BEFORE a call's StageTimers: whatever path the call returns by (error statuses included), the stage timers

@@ -465,7 +465,7 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
         hipLaunchKernelGGL(k_sc_a<P>, dim3(nblk(n)), dim3(256), 0, st, u, ra, sc_a, n);
         PM_HIP(ctx, hipGetLastError());
         PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
-        timing_reset(aux);
+        timing_reset_aux(ctx, aux);
         {
             helper.pending = ctx->worker.submit([&, aux] {
                 if (hipSetDevice(aux->device) != hipSuccess || hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0) != hipSuccess) {
@@ -531,7 +531,7 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     if (a_early) {
         const int st_c = msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
         helper.join();
-        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL}) ctx->timing_ms[s] += ctx->aux->timing_ms[s];
+        timing_absorb_aux(ctx, ctx->aux);
         if (st_c == PM_OK || st_a == PM_OK) PM_HIP(ctx, hipStreamSynchronize(st));
         const unsigned hf = *hflags_p;
         if (hf & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108

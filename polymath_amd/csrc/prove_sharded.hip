@@ -843,7 +843,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
     int a_inf_l = 1, c_inf_l = 1;
     const bool overlap = ctx->opt.v[PM_OPT_MSM_OVERLAP] != 0;
     if (pm_ctx *aux = overlap ? ctx_aux(ctx) : nullptr) {
-        timing_reset(aux);
+        timing_reset_aux(ctx, aux);
         PM_HIP(ctx, hipEventRecord(ctx->ev_sc_a, st));
         PM_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_sc_a, 0));
         int st_a = msm_resident_begin<C>(aux, pk, 0, u);
@@ -851,7 +851,7 @@ int prove_phase1_sharded(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const 
         const int en_c = st_a == PM_OK && st_c == PM_OK ? msm_resident_end<C>(ctx, r1->c_xy, &c_inf_l) : (int)PM_OK;
         if (st_a == PM_OK) st_a = msm_resident_end<C>(aux, r1->a_xy, &a_inf_l);      // always drained: its scalars live in this context
         timing_flush(aux);
-        for (int s : {T_MSM_SORT, T_MSM_ACCUMULATE, T_MSM_REDUCE, T_MSM_TOTAL, T_NTT}) ctx->timing_ms[s] += aux->timing_ms[s];
+        timing_absorb_aux(ctx, aux);
         if (st_a != PM_OK) { ctx->err = aux->err; return st_a; }
         PM_TRY(st_c);
         PM_TRY(en_c);

@@ -135,7 +135,7 @@ static int run(const char *name, int iters) {
 }
 
 // The dense product the kernels use (field.cuh: mul_r28, 28-bit limbs, radix 2^(32 N)) against the textbook
-// 32-bit CIOS (mul_cios) on random and extreme operands: identical canonical words.
+// 32-bit CIOS (mul_cios) on random and extreme operands: identical canonical words; so is mul(), which host code takes on 64-bit limbs.
 template <class P>
 static int dense_mul_check(const char *name, int iters) {
     int bad = 0;
@@ -152,6 +152,7 @@ static int dense_mul_check(const char *name, int iters) {
         if (it == 2) a = Fp<P>::one();
         if (it == 3) { for (int i = 0; i < P::N; ++i) a.l[i] = P::MOD[i]; a.l[0] -= 1; b = Fp<P>::one(); }
         if (!mul_r28<P>(a, b).eq(mul_cios<P>(a, b))) bad++;
+        if (!mul<P>(a, b).eq(mul_cios<P>(a, b))) bad++;   // host code's product (64-bit limbs where the compiler has __int128)
     }
     printf("%s dense mul vs CIOS: %d mismatches of %d\n", name, bad, iters);
     return bad;
