@@ -167,6 +167,7 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
     for (auto &b : ctx->fb_table) b.release();
     for (auto &t : ctx->tw) { t.fwd.release(); t.inv.release(); t.fwd_int.release(); t.inv_int.release(); }
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (auto &t : ctx->pending_timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }   // pm_host_prove leaves them unread (lazy_timings)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ctx->ev_sc_a);
     (void)hipStreamDestroy(ctx->stream);
