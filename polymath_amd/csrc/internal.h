@@ -476,7 +476,12 @@ inline void timing_reset_aux(pm_ctx *ctx, pm_ctx *aux) {
 }
 inline void timing_absorb_aux(pm_ctx *ctx, pm_ctx *aux) {
     for (int s = 0; s < T_NUM_SLOTS; ++s) { ctx->timing_ms[s] += aux->timing_ms[s]; aux->timing_ms[s] = 0; }
-    for (auto &t : aux->pending_timers) ctx->pending_timers.push_back(t);
+    // lazy mode: the helper's unread timers (and their events) become the owner's; the helper's pool gets as many events back from the
+    // owner's, or it would create new ones every proof while the owner's pool grows.  Called by the owner's thread, the helper idle.
+    for (auto &t : aux->pending_timers) {
+        ctx->pending_timers.push_back(t);
+        for (int k = 0; k < 2 && !ctx->event_pool.empty(); ++k) { aux->event_pool.push_back(ctx->event_pool.back()); ctx->event_pool.pop_back(); }
+    }
     aux->pending_timers.clear();
 }
 
