@@ -96,7 +96,9 @@ int pm_ctx_create(int device, pm_ctx **out);
 void pm_ctx_destroy(pm_ctx *ctx);
 const char *pm_last_error(const pm_ctx *ctx);
 /* Wall-clock GPU milliseconds of the most recent call's kernels, by stage (hipEvent timers;
- * replaces the reference's start_timer!/end_timer! tracing, prover.rs:32-61). */
+ * replaces the reference's start_timer!/end_timer! tracing, prover.rs:32-61).  After pm_host_prove[_sharded] the
+ * slots cover the whole proof and the events are read HERE (a few dozen event queries, ~0.1 ms of host time), not
+ * between the proof's phases: call it from the thread that proved, before the context's next call. */
 int pm_last_timings(const pm_ctx *ctx, double *ms_out, int n_slots);
 
 /* ---- options -----------------------------------------------------------------------------
