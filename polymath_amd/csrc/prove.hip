@@ -599,7 +599,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     NumParams np{n, sigma, 8 * sigma + 2 * n - 1};
     const NumConsts<P> nc = make_num_consts<P>(x2, rah, a_at, c_at);
     // levels of the chunked recurrence
-    const unsigned L = 32;
+    const unsigned L = 16;   // coefficients per lane and level: 16 puts 20 K waves on the chip (32: 10 K, half of its wave slots idle): 0.98 -> 0.90 ms
     uint64_t cnt[8];
     cnt[0] = np.len;
     int levels = 0;
