@@ -151,3 +151,79 @@ def r1cs_is_satisfied(c, q, inst, wit):
         if az * bz % r != cz:
             return False
     return True
+
+
+def first_entry_dot(r, row, zz):
+    """(M z)_row as the SAP matrices see it: m_at (common.rs:100-105) returns the FIRST entry of a column, so
+    later entries of the same column inside a row do not count."""
+    seen, s = set(), 0
+    for v, j in row:
+        if j in seen:
+            continue
+        seen.add(j)
+        s += v * zz[j]
+    return s % r
+
+
+def random_r1cs(c, seed, m0, nr, max_entries=4, unused_every=5):
+    """A seeded random R1CS of ARBITRARY shape for differential testing of the witness map
+    (common.rs:77-97, 131-207; prover.rs:75-96, 156-166) -- everything the harness circuits never do:
+    m0 - 1 free public inputs (m0 = 1: none), 0..max_entries entries per row in each of A, B, C, entries on
+    column 0 and on instance columns, zero / one / minus-one coefficients, duplicate columns inside a row
+    (only the first counts: m_at), empty rows, witness columns no row uses (points at infinity in
+    uj_wj_lcs), a fresh witness per gate with a random non-zero coefficient somewhere inside its C row.
+    Satisfied under m_at's first-entry semantics.  Draw order: instance values, seed witnesses, then per
+    gate: the A row, the B row, the C row."""
+    r = c.r
+    g = SplitMix64(seed)
+    inst = [1] + [g.fr(r) for _ in range(m0 - 1)]
+    z = inst + [g.fr(r) for _ in range(1 + g.below(3))]          # One, instance, then the witnesses as they are allocated
+
+    def coef():
+        k = g.below(8)
+        return 0 if k == 0 else 1 if k == 1 else r - 1 if k == 2 else g.below(1 << 16) if k == 3 else g.fr(r)
+
+    def column():
+        k = g.below(8)
+        if k == 0:
+            return 0
+        if k <= 2 and m0 > 1:
+            return 1 + g.below(m0 - 1)
+        return m0 + g.below(len(z) - m0)
+
+    def row(k):
+        out = []
+        for _ in range(k):
+            if out and g.below(5) == 0:
+                out.append((coef(), out[g.below(len(out))][1]))      # a repeated column: ignored by m_at
+            else:
+                out.append((coef(), column()))
+        return out
+
+    A, B, Cm = [], [], []
+    for i in range(nr):
+        ra, rb = row(g.below(max_entries + 1)), row(g.below(max_entries + 1))
+        prod = first_entry_dot(r, ra, z) * first_entry_dot(r, rb, z) % r
+        rc = row(g.below(max_entries))
+        rest = first_entry_dot(r, rc, z)
+        if prod == rest and g.below(2) == 0:
+            pass                                                     # already satisfied (e.g. an empty A row): no fresh witness
+        else:
+            k = 0
+            while k == 0:
+                k = coef()
+            t = (prod - rest) * pow(k, -1, r) % r
+            col = len(z)
+            z.append(t)
+            rc.insert(g.below(len(rc) + 1), (k, col))
+            if g.below(6) == 0:
+                rc.append((coef(), col))                             # the fresh column once more, later in the row
+        A.append(ra)
+        B.append(rb)
+        Cm.append(rc)
+        if unused_every and g.below(unused_every) == 0:
+            z.append(g.fr(r))                                        # a witness no row refers to
+    wit = z[m0:]
+    q = R1CS(m0, len(wit), A, B, Cm)
+    assert all(first_entry_dot(r, a, z) * first_entry_dot(r, b, z) % r == first_entry_dot(r, cc, z) for a, b, cc in zip(A, B, Cm))
+    return q, inst, wit

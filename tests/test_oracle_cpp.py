@@ -120,3 +120,38 @@ def test_unsatisfied_and_state_errors(oracle):
     pk2 = CO.OraclePk(curve, q, 5, 7, 1)
     rc, _ = pk2.phase2(CO.fr_to_mont_limbs(curve, [3]))
     assert rc == 8                                    # phase 2 before phase 1
+
+
+@pytest.mark.parametrize("curve,seed,m0,nr", [("bls12_381", 11, 1, 1), ("bls12_381", 12, 4, 4), ("bls12_381", 13, 9, 5),
+                                              ("bn254", 14, 2, 7), ("bn254", 15, 17, 2)])
+def test_random_r1cs_shapes_sparse_equals_dense_literal(oracle, curve, seed, m0, nr):
+    """CI.random_r1cs (any m0, multi-entry rows on column 0 / instance columns, duplicate columns, zero coefficients, empty
+    rows, unused witnesses; nr = 1): the sparse closed form of oracle/cpp against the arm-by-arm dense
+    transcription of common.rs:138-207 in oracle/pyref -- bases, proof, all 8 intermediate vectors, challenges."""
+    from oracle.pyref import circuits as CI, protocol as PR
+    CO, c = oracle, CURVES[curve]
+    q, inst, wit = CI.random_r1cs(c, seed, m0, nr)
+    g = CI.SplitMix64(seed * 7919)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    dense = PR.generate_proving_key(c, q, x, z)
+    pk = CO.OraclePk(curve, q, x, z, 2)
+    assert (pk.n, pk.sigma) == (dense.n, dense.sigma)
+    for i, nm in enumerate(BASE_NAMES):
+        assert CO.g1_from_mont_limbs(curve, pk.export_bases(i)) == getattr(dense, nm), nm
+    TR = T.make_transcripts(c)["blake3"]
+    tr_d, tr_s = {}, {}
+    want = PR.create_proof_with_assignment(c, dense, inst, wit, r_a, TR, tr_d)
+    got = DR.prove(pk, pk.n, pk.sigma, dense.omega, inst, wit, r_a, TR, tr_s)
+    assert got == want and (tr_s["x1"], tr_s["x2"]) == (tr_d["x1"], tr_d["x2"])
+    for which, key in [(0, "u_evals"), (1, "w_evals"), (2, "u"), (3, "w"), (4, "h"), (5, "wit_u"), (6, "z_tail"), (7, "quotient")]:
+        have = CO.fr_from_mont_limbs(curve, pk.tap(which, 1 << 16))
+        assert have[:len(tr_d[key])] == tr_d[key] and not any(have[len(tr_d[key]):]), key
+    # one witness value off by one: the remainder assert of prover.rs:108, if any row reads that column at all
+    bad = list(wit)
+    bad[0] = (bad[0] + 1) % c.r
+    zz = inst + bad
+    if not all(CI.first_entry_dot(c.r, a, zz) * CI.first_entry_dot(c.r, b, zz) % c.r == CI.first_entry_dot(c.r, cc, zz)
+               for a, b, cc in zip(q.a, q.b, q.c)):
+        with pytest.raises(DR.ProverError) as e:
+            DR.prove(pk, pk.n, pk.sigma, dense.omega, inst, bad, r_a, TR)
+        assert (e.value.phase, e.value.rc) == (1, 4)

@@ -66,7 +66,7 @@ def test_pairing_bilinear_bn254():
 
 
 def test_bn254_golden_proofs_pass_the_pairing_verifier():
-    """Every committed BN254 fixture proof (tests/golden/proofs_bn254.json, 3 circuits x 3 transcripts) is accepted by
+    """Every committed BN254 fixture proof (tests/golden/proofs_bn254.json, 5 circuits x 3 transcripts; m0 = 1, 2 and 12) is accepted by
     verify_proof (verifier.rs:19-62) over the BN254 pairing; tampering and a wrong public input are rejected."""
     import json, os
     c, E = BN254, PA.ENGINES["bn254"]
@@ -80,7 +80,10 @@ def test_bn254_golden_proofs_pass_the_pairing_verifier():
             proof = dict(a_g1=PT(ref["a_g1"]), c_g1=PT(ref["c_g1"]), a_at_x1=I(ref["a_at_x1"]), d_g1=PT(ref["d_g1"]))
             assert PR.verify_proof(c, vk, proof, inst[1:], TR[tname], E.pairing_check), (fx["name"], tname)
         assert not PR.verify_proof(c, vk, dict(proof, a_at_x1=(proof["a_at_x1"] + 1) % c.r), inst[1:], TR[tname], E.pairing_check)
-        assert not PR.verify_proof(c, vk, proof, [(v + 1) % c.r for v in inst[1:]], TR[tname], E.pairing_check)
+        if len(inst) > 1:                # m0 = 1 has no public input to get wrong
+            assert not PR.verify_proof(c, vk, proof, [(v + 1) % c.r for v in inst[1:]], TR[tname], E.pairing_check)
+        else:                            # ... but one too many is refused
+            assert not PR.verify_proof(c, vk, proof, [5], TR[tname], E.pairing_check)
 
 
 def test_dummy_prove_verify_all_transcripts():

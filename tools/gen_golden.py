@@ -85,6 +85,11 @@ def proof_fixtures():
     q, inst, wit = CI.dummy_circuit(c, 3, 5)
     q.a[0] = [(1, 2), (7, 2)]
     cases.append(("dup_column", q, inst, wit))
+    # m0 != 2: no public input at all; two; eleven (2 m0 > 16: the witness-only part of u is no longer a
+    # short direct sum).  Rows with several entries that touch column 0 and the instance columns, duplicate columns, zero
+    # coefficients, unused witnesses (CI.random_r1cs); 2 (m0 + nr) = 2^k exactly, 2^k + 2, 2^k exactly.
+    for name, seed, m0, nr in [("m0_1", 0x101, 1, 3), ("m0_3", 0x103, 3, 6), ("m0_12", 0x10C, 12, 4)]:
+        cases.append((name, ) + CI.random_r1cs(c, seed, m0, nr))
     out = []
     for name, q, inst, wit in cases:
         x, z = g.fr(c.r), g.fr(c.r)
@@ -120,7 +125,9 @@ def proof_fixtures_bn254():
     g = CI.SplitMix64(0xB254)
     cases = [("dummy", ) + CI.dummy_circuit(c, g.fr(c.r), g.fr(c.r)),
              ("synthetic6", ) + CI.synthetic_r1cs(c, 6),
-             ("bench_shape", ) + CI.bench_circuit(c, g.fr(c.r), g.fr(c.r), 7, 6)]
+             ("bench_shape", ) + CI.bench_circuit(c, g.fr(c.r), g.fr(c.r), 7, 6),
+             ("m0_12", ) + CI.random_r1cs(c, 0x20C, 12, 3),      # 2 (m0 + nr) = 2^k - 2
+             ("m0_1", ) + CI.random_r1cs(c, 0x201, 1, 5)]
     out = []
     for name, q, inst, wit in cases:
         x, z = g.fr(c.r), g.fr(c.r)
