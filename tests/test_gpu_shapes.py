@@ -163,3 +163,43 @@ def test_golden_m0_shapes_on_rank_threads(api, fname):
                     assert vals[:len(want)] == want and not any(vals[len(want):]), (fx["name"], key)
             for pk in pks:
                 pk.free()
+
+
+@pytest.mark.parametrize("seed", range(40, 52))
+def test_differential_fuzz_of_r1cs_shapes_on_rank_threads(oracle, api, seed):
+    """12 more random shapes as ONE proof over N = 2, 4 or 8 rank-threads (cyclic witness map with multi-entry rows on instance
+    columns, the distributed head rows for every m0, both branches of the witness-only part of u), sub-segments of 8 or 64
+    indices, the three transcripts in turn: the CPU oracle's bytes; an unsatisfied row gives status 4 on EVERY rank."""
+    from polymath_amd.polymath import PolymathProverError
+    curve, m0, nr, tables = fuzz_shape(seed)
+    c = CURVES[curve]
+    N = (2, 4, 8)[seed % 3]
+    tname = ("merlin", "keccak256", "blake3")[(seed // 3) % 3]
+    q, inst, wit = CI.random_r1cs(c, 0xF022 + seed, m0, nr)
+    lc = _limb_circuit(curve, q, inst, wit)
+    g = CI.SplitMix64(9000 + seed)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    want, opk = _oracle_reference(oracle, curve, lc, x, z, r_a, transcript=tname)
+    assert opk.n % (N * N) == 0
+    pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, transcript=tname,
+                                              options={"max_seg_log": 3 if seed % 2 else 6, "ntt_overlap": seed % 2, "tables": tables})
+    assert all(p == want for p in proofs)
+    zz = list(inst) + list(wit)
+    used = sorted({j for rows in (q.a, q.b, q.c) for row in rows for v, j in row if j >= m0 and v})
+    if used:
+        col = used[seed % len(used)]
+        zz[col] = (zz[col] + 1) % c.r
+        if not all(CI.first_entry_dot(c.r, a, zz) * CI.first_entry_dot(c.r, b, zz) % c.r == CI.first_entry_dot(c.r, cc, zz)
+                   for a, b, cc in zip(q.a, q.b, q.c)):
+            bad = pms[0].field.fr_limbs(zz[m0:])
+
+            def prove_bad(r):
+                try:
+                    pms[r].prove_native(pks[r], lc.inst_limbs, bad, r_a)
+                except PolymathProverError as e:
+                    return e.status
+                return 0
+            assert _run_ranks(N, prove_bad, comms) == [4] * N
+            assert all(p == want for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms))
+    for pk in pks:
+        pk.free()

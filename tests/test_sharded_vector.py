@@ -263,8 +263,9 @@ def test_vector_sharded_without_window_tables(oracle, monkeypatch, tables):
 
 
 @pytest.mark.gpu
-def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
-    """Tiny sub-segments (PM_OPT_MAX_SEG_LOG = 6: hundreds of segments per rank, several per block), a circuit with 12 public
+def test_vector_sharded_many_segments_public_inputs_and_errors(oracle, monkeypatch):
+    """(Compared with the CPU ORACLE's bytes since round 5 -- the single-GPU proof of the same library is checked against them too.)
+    Tiny sub-segments (PM_OPT_MAX_SEG_LOG = 6: hundreds of segments per rank, several per block), a circuit with 12 public
     inputs (2 m0 > 16: the witness-only part of u takes its own distributed transform), all three transcripts; an
     unsatisfied witness makes EVERY rank return PM_ERR_REMAINDER_NONZERO (no rank is left waiting in a collective)."""
     from polymath_amd import circuits as PC
@@ -289,6 +290,10 @@ def test_vector_sharded_many_segments_public_inputs_and_errors(monkeypatch):
         ref_pm = Polymath(curve, tname, device=0)
         ref_pk = ref_pm.setup(lc, x, z)
         ref = ref_pm.prove_native(ref_pk, lc.inst_limbs, lc.wit_limbs, r_a)
+        oracle_proof, _ = _oracle_reference(oracle, curve, lc, x, z, r_a, transcript=tname)
+        assert ref == oracle_proof, tname                   # m0 = 12 on one GPU: the fifth transform (prove.hip) against oracle/cpp
+        assert ref_pm.verify(ref_pm.make_vk(ref_pk, x, z), lc.instance[1:], ref)
+        ref = oracle_proof
         # the two-stream transforms on (keccak256) and off on this shape too
         pms, pks, comms, proofs = _sharded_proofs(curve, lc, x, z, r_a, N, transcript=tname,
                                                   options={"max_seg_log": 6, "ntt_overlap": 1 if tname == "keccak256" else 0})
