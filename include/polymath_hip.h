@@ -98,8 +98,10 @@ const char *pm_last_error(const pm_ctx *ctx);
 /* Wall-clock GPU milliseconds of the most recent call's kernels, by stage (hipEvent timers;
  * replaces the reference's start_timer!/end_timer! tracing, prover.rs:32-61).  After pm_host_prove[_sharded] the
  * slots cover the whole proof and the events are read HERE (a few dozen event queries, ~0.1 ms of host time), not
- * between the proof's phases: call it from the thread that proved, before the context's next call. */
-int pm_last_timings(const pm_ctx *ctx, double *ms_out, int n_slots);
+ * between the proof's phases: call it from the thread that proved, before the context's next call.  It MUTATES the
+ * context (pending events are read and recycled, the device is made current): not thread-safe against any other call on
+ * the same context -- hence no const. */
+int pm_last_timings(pm_ctx *ctx, double *ms_out, int n_slots);
 
 /* ---- options -----------------------------------------------------------------------------
  * What a host may choose, per context.  The reference keeps no global state (src/lib.rs:44-50: `Polymath<E, T>` is a

@@ -176,12 +176,11 @@ extern "C" void pm_ctx_destroy(pm_ctx *ctx) {
 
 extern "C" const char *pm_last_error(const pm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-extern "C" int pm_last_timings(const pm_ctx *ctx, double *ms_out, int n_slots) {
+extern "C" int pm_last_timings(pm_ctx *ctx, double *ms_out, int n_slots) {
     if (!ctx || !ms_out) return PM_ERR_INVALID_ARG;
     if (!ctx->pending_timers.empty()) {   // pm_host_prove leaves its stage timers unread (internal.h: lazy_timings)
-        pm_ctx *c = const_cast<pm_ctx *>(ctx);
-        if (hipSetDevice(c->device) != hipSuccess) return PM_ERR_HIP;
-        timing_flush_now(c);
+        if (hipSetDevice(ctx->device) != hipSuccess) return PM_ERR_HIP;
+        timing_flush_now(ctx);
     }
     for (int i = 0; i < n_slots; ++i) ms_out[i] = i < T_NUM_SLOTS ? ctx->timing_ms[i] : 0.0;
     return PM_OK;

@@ -534,7 +534,11 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
         const int st_c = msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf);
         helper.join();
         timing_absorb_aux(ctx, ctx->aux);
-        if (st_c == PM_OK || st_a == PM_OK) PM_HIP(ctx, hipStreamSynchronize(st));
+        // always synchronise before the staged flags are read: with both MSMs failed the copy may still be in flight
+        // and the host-written 0 would read as a degree-bound violation instead of the MSMs' own status
+        const hipError_t e_sync = hipStreamSynchronize(st);
+        if (st_a != PM_OK && st_c != PM_OK) { ctx->err = ctx->aux->err; return st_a; }
+        PM_HIP(ctx, e_sync);
         const unsigned hf = *hflags_p;
         if (hf & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
         if ((hf & 2u) || !(hf & 4u)) return PM_ERR_DEGREE_BOUND;       // prover.rs:107
@@ -543,11 +547,12 @@ int prove_phase1_impl(pm_ctx *ctx, const pm_pk *pk, const uint64_t *x, const uin
     } else {
         const int s_a = msm_shard<C>(ctx, pk, 0, sc_a, a_xy, a_inf);
         const int s_c = s_a == PM_OK ? msm_shard<C>(ctx, pk, 1, sc_c, c_xy, c_inf) : (int)PM_OK;
-        PM_HIP(ctx, hipStreamSynchronize(st));
+        const hipError_t e_sync = hipStreamSynchronize(st);
+        PM_TRY(s_a);                                                  // an MSM's own failure first: the flags may not have landed
+        PM_HIP(ctx, e_sync);
         const unsigned hf = *hflags_p;
         if (hf & 1u) return PM_ERR_REMAINDER_NONZERO;                 // prover.rs:108
         if ((hf & 2u) || !(hf & 4u)) return PM_ERR_DEGREE_BOUND;       // prover.rs:107
-        PM_TRY(s_a);
         PM_TRY(s_c);
     }
     t_phase.stop();
@@ -603,7 +608,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     uint64_t cnt[8];
     cnt[0] = np.len;
     int levels = 0;
-    while (cnt[levels] > 64 && levels < 5) {   // the top level is one lane: keep it to <= 64 values
+    while (cnt[levels] > 64 && levels < 6) {   // the top level is one lane: keep it to <= 64 values (16^6 covers every domain of both curves; lvl[6], cnt[8], xp[8] have room)
         cnt[levels + 1] = (cnt[levels] + L - 1) / L;
         ++levels;
     }

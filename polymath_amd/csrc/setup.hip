@@ -388,7 +388,7 @@ __global__ void k_lagrange(Fp<P> *L, Fp<P> *pre, size_t n, Fp<P> x, Fp<P> omega,
         run = mul<P>(run, sub<P>(x, wi));
         wi = mul<P>(wi, omega);
     }
-    Fp<P> inv = inverse<P>(run);             // x is outside the domain (checked by the caller): no denominator is zero
+    Fp<P> inv = inverse<P>(run);             // x^n != 1 (api.hip: pk_generate_impl returns PM_ERR_INVALID_ARG otherwise): no denominator is zero
     for (size_t i = hi; i-- > lo;) {
         const Fp<P> w = L[i];
         const Fp<P> di = mul<P>(inv, pre[i]);

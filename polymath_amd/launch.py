@@ -134,11 +134,14 @@ def _child_env(base, rank, local, world, port, attempt, backend, exchange, own_s
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: without it RCCL's ipc handles fail on this driver
     if exchange == "callbacks":
         e["BENCH_NO_RCCL"] = "1"
-        # the fallback of the fallback is the plainest configuration: one stream per rank for the exchanges as well (the
-        # two-stream transforms are the default since round 4 and have not met a fabric yet); a context's defaults come from here
-        e.setdefault("PM_NTT_OVERLAP", "0")
     else:
         e.pop("BENCH_NO_RCCL", None)
+    # Only the FIRST attempt runs the two-stream transforms (the default since round 4: w's exchange from a second stream of the
+    # same RCCL communicator -- a configuration that has not met a fabric yet).  Every later attempt, the second RCCL attempt
+    # included, is the plainest configuration: one stream per rank, the exchange order round 3 validated.  A
+    # context's defaults come from here (pm_ctx_create reads PM_NTT_OVERLAP once).
+    if attempt > 0:
+        e.setdefault("PM_NTT_OVERLAP", "0")
     if own_store:                                        # rank 0's child hosts the TCP store itself
         for k in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
             e.pop(k, None)
@@ -193,7 +196,10 @@ def _rendezvous_dir(env):
     run id, master port and process id (the workers of one launcher share their parent; back-to-back jobs that reuse a port and a
     run id -- the driver's N = 2, 4, 8 series -- must not meet each other's files)."""
     import tempfile
-    tag = "%s_%s_%s" % (env.get("TORCHELASTIC_RUN_ID", "norun"), env.get("MASTER_PORT", "29500"), env.get("PM_LAUNCHER_PID", os.getppid()))
+    # ... and a second incarnation under the same launcher (torchrun --max-restarts: same parent, run id and port) must not meet
+    # the first one's markers either: the restart count is part of the name (ADVICE r4)
+    tag = "%s_%s_%s_%s" % (env.get("TORCHELASTIC_RUN_ID", "norun"), env.get("MASTER_PORT", "29500"), env.get("PM_LAUNCHER_PID", os.getppid()),
+                           env.get("TORCHELASTIC_RESTART_COUNT", "0"))
     d = os.path.join(tempfile.gettempdir(), "pm_bench_" + "".join(c if c.isalnum() or c in "_-" else "_" for c in tag))
     os.makedirs(d, exist_ok=True)
     return d
@@ -209,8 +215,15 @@ def agree_on_retry(env, rank, world, k, wait_s=90.0):
     guess = port0 + 37 * k
     if guess > 65000:
         guess = 20000 + (guess % 40000)
-    open(os.path.join(d, "attempt%d.rank%d" % (k, rank)), "w").close()
     port_file = os.path.join(d, "attempt%d.port" % k)
+    if rank == 0:
+        try:                                    # nothing older than this arrival may be taken for the agreement
+            os.unlink(port_file)
+        except OSError:
+            pass
+    mine = os.path.join(d, "attempt%d.rank%d" % (k, rank))
+    open(mine, "w").close()
+    t_arrival = os.stat(mine).st_mtime_ns
     if rank == 0:
         port = free_port()
         tmp = port_file + ".tmp"
@@ -222,14 +235,32 @@ def agree_on_retry(env, rank, world, k, wait_s=90.0):
     while time.time() < t_end:
         if port is None and os.path.exists(port_file):
             try:
-                port = int(open(port_file).read().strip())
-            except ValueError:
+                # a port file left by an earlier incarnation is older than every arrival of this one; rank 0 publishes after its
+                # own arrival, which is not before this rank's by more than the skew the 2 s allow for
+                if rank == 0 or os.stat(port_file).st_mtime_ns >= t_arrival - 2_000_000_000:
+                    port = int(open(port_file).read().strip())
+            except (ValueError, OSError):
                 port = None
         if port is not None and all(os.path.exists(os.path.join(d, "attempt%d.rank%d" % (k, r))) for r in range(world)):
             return port
         time.sleep(0.1)
     _log("rank %d: retry %d not confirmed by every supervisor within %.0f s; going on with port %d" % (rank, k, wait_s, port or guess))
     return port or guess
+
+
+def _leave_rendezvous(env, rank):
+    """A supervisor's exit: its own markers go, rank 0's port files go, and whoever leaves last removes the directory."""
+    d = _rendezvous_dir(env)
+    try:
+        for f in os.listdir(d):
+            if f.endswith(".rank%d" % rank) or (rank == 0 and ".port" in f):
+                try:
+                    os.unlink(os.path.join(d, f))
+                except OSError:
+                    pass
+        os.rmdir(d)                # fails while another rank's markers are still there: the last one out succeeds
+    except OSError:
+        pass
 
 
 def supervise_one(script, argv, deadline_s=900):
@@ -242,21 +273,24 @@ def supervise_one(script, argv, deadline_s=900):
     attempts = attempts_from_env(os.environ)
     budget = Budget(deadline_s)
     who = "rank %d: " % rank
-    for k, (backend, exchange) in enumerate(attempts):
-        # attempt 0 meets on the launcher's own store; a retry needs a store no earlier attempt has written to
-        port = port0 if k == 0 else agree_on_retry(os.environ, rank, world, k, wait_s=min(90.0, max(5.0, budget.remaining() / 10)))
-        d = budget.deadline(attempts, k, who if rank else "")
-        if not d:
-            _log("%sattempt %d skipped: not enough of the budget left" % (who, k))
-            continue
-        if rank == 0:
-            _log("attempt %d: %d ranks under the external launcher, torch.distributed=%s, exchange=%s, port %d" % (k, world, backend, exchange, port))
-        env = dict(os.environ, BENCH_ATTEMPT_LIMIT_S=str(d))
-        ok, why = _run_attempt(cmd, [_child_env(env, rank, local, world, port, k, backend, exchange, k > 0)], d)
-        if ok:
-            return 0
-        _log("rank %d, attempt %d failed: %s" % (rank, k, why))
-    return 1
+    try:
+        for k, (backend, exchange) in enumerate(attempts):
+            # attempt 0 meets on the launcher's own store; a retry needs a store no earlier attempt has written to
+            port = port0 if k == 0 else agree_on_retry(os.environ, rank, world, k, wait_s=min(90.0, max(5.0, budget.remaining() / 10)))
+            d = budget.deadline(attempts, k, who if rank else "")
+            if not d:
+                _log("%sattempt %d skipped: not enough of the budget left" % (who, k))
+                continue
+            if rank == 0:
+                _log("attempt %d: %d ranks under the external launcher, torch.distributed=%s, exchange=%s, port %d" % (k, world, backend, exchange, port))
+            env = dict(os.environ, BENCH_ATTEMPT_LIMIT_S=str(d))
+            ok, why = _run_attempt(cmd, [_child_env(env, rank, local, world, port, k, backend, exchange, k > 0)], d)
+            if ok:
+                return 0
+            _log("rank %d, attempt %d failed: %s" % (rank, k, why))
+        return 1
+    finally:
+        _leave_rendezvous(os.environ, rank)
 
 
 class Watchdog:

@@ -91,6 +91,22 @@ def test_retry_port_is_agreed_between_the_supervisors(tmp_path):
         t.join(30)
     assert got[0] == got[1] == got[2] and 1024 < got[0] < 65536
     assert time.time() - t0 >= 0.55                        # nobody left before the slowest supervisor had arrived
+    # a second incarnation under the same launcher (torchrun --max-restarts: same parent, run id and port) meets in its own
+    # directory; and inside ONE directory a port file that is older than a supervisor's arrival is not taken for the agreement
+    assert launch._rendezvous_dir(env) != launch._rendezvous_dir(dict(env, TORCHELASTIC_RESTART_COUNT="1"))
+    env3 = dict(env, TORCHELASTIC_RUN_ID="s%d" % os.getpid())
+    d3 = launch._rendezvous_dir(env3)
+    stale = os.path.join(d3, "attempt1.port")
+    open(stale, "w").write("4711")
+    old_t = time.time() - 600
+    os.utime(stale, (old_t, old_t))
+    open(os.path.join(d3, "attempt1.rank0"), "w").close()                # rank 0 "arrived" long ago as well, and published nothing new
+    assert launch.agree_on_retry(env3, 1, 2, 1, wait_s=0.6) != 4711      # falls back to the validated guess instead of the stale port
+    launch._leave_rendezvous(env3, 1)
+    launch._leave_rendezvous(env3, 0)
+    assert not os.path.exists(d3)                                        # the last supervisor out removes the directory
+    for r in range(3):
+        launch._leave_rendezvous(env, r)
     # nobody publishes (rank 0 is gone): the bounded wait ends and the guess is validated into the port range
     env2 = dict(env, TORCHELASTIC_RUN_ID="u%d" % os.getpid())
     assert 1024 < launch.agree_on_retry(env2, 1, 2, 2, wait_s=0.5) < 65536
