@@ -18,6 +18,7 @@ HEADERS = ["field.cuh", "ec.cuh", "fq28.cuh", "constants.cuh", "internal.h", os.
            os.path.join("..", "..", "include", "polymath_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
+FLAGS += os.environ.get("PM_BUILD_FLAGS", "").split()     # same-box A/B builds of compile-time variants (tools/README.md)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 

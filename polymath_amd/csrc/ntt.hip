@@ -149,11 +149,14 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const Fp<P> *a, Fp<P> *dst, co
 // and the 2^6 p the product tolerates; they are brought back to the canonical range once, on the way out (conditional subtractions
 // of 32p ... p; in the last pass of an inverse transform the n^-1 product does it).  Elements enter and leave in the dense
 // canonical form: the results are bit-identical.
-// 512 threads (L28_THREADS) and one 72 KiB tile per workgroup: two workgroups share a CU's 160 KiB (tools/lds_occupancy.hip) = 4 waves
-// per SIMD, and one workgroup's barriers and loads hide under the other's butterflies.
-constexpr unsigned L28_THREADS = 512;
-constexpr unsigned L28_BPL = 1024 / L28_THREADS;   // butterflies per lane and stage of a full 2^11-element tile
-constexpr unsigned L28_EPL = 2048 / L28_THREADS;   // elements per lane of a full tile
+// 512 threads and one 72 KiB tile per workgroup: two workgroups share a CU's 160 KiB (tools/lds_occupancy.hip) = 4 waves
+// per SIMD, and one workgroup's barriers and loads hide under the other's butterflies (round 5: 256 threads on 36 KiB tiles, four
+// workgroups per CU, wherever a pass has at most 8 stages -- see TH below).
+// Round 5: the workgroup size is a template parameter TH; a full tile is 4 TH elements (TH = 512: 2^11 elements, 72 KiB, two
+// workgroups per CU; TH = 256: 2^10 elements, 36 KiB, four per CU -- the same 4 waves per SIMD, but a barrier holds 4 waves
+// instead of 8 and a wave's stall costs its SIMD less).
+constexpr unsigned L28_BPL = 2;   // butterflies per lane and stage of a full tile
+constexpr unsigned L28_EPL = 4;   // elements per lane of a full tile
 
 template <class RR>
 __device__ __forceinline__ F28<RR> l28_load(const uint32_t *t, unsigned tile, unsigned e) {
@@ -168,10 +171,12 @@ __device__ __forceinline__ void l28_store(uint32_t *t, unsigned tile, unsigned e
     for (int l = 0; l < RR::N; ++l) t[l * tile + e] = v.l[l];
 }
 // tight limbs, value < 64 p  ->  canonical (< p): conditional subtraction of 32p, 16p, ..., p (limbs of p << j by constant shifts)
-template <class RR>
+// JMAX: the largest multiple 2^JMAX p the value can reach (round 5: the chain used to start at 32p everywhere; after a product the
+// value is < 2p and one step does, after <= 7 stages it is < 30p and the 32p step never fires)
+template <class RR, int JMAX = 5>
 __device__ __forceinline__ F28<RR> l28_canonical(F28<RR> x) {
 #pragma unroll
-    for (int j = 5; j >= 0; --j) {
+    for (int j = JMAX; j >= 0; --j) {
         uint32_t t[RR::N];
         uint32_t borrow = 0;
 #pragma unroll
@@ -206,7 +211,7 @@ __device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d
 // limbs are < 2^(W+1)), so a limb entering a product is below 2^W + 2^(W+1) and the column sums stay in 64 bits
 // (W = 29, N = 9: 9 * 1.5 * 2^30 * 2^29 + 9 * 2^58 < 2^63 against a tight twiddle; the n^-1 product of l28_emit sees at most
 // 2.5 * 2^30: < 2^63.8).  The stage that ends the pass leaves its carries to l28_emit.
-template <class P, class RR, bool FIRST>
+template <class P, class RR, bool FIRST, unsigned TH>
 __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols,
                                            size_t lo0, bool pair_stages) {
     const unsigned cols = 1u << log_cols, cm = cols - 1, rows = 1u << ns, nbf = (rows >> 1) * cols, tid = threadIdx.x;
@@ -218,7 +223,7 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
     auto two_stages = [&](unsigned st, auto norm_tag) {
         constexpr bool NORM = decltype(norm_tag)::value;
         const unsigned half = 1u << st, sA = s0 + st + 1, sB = sA + 1, ngroups = (rows >> 2) * cols;
-        for (unsigned e = tid; e < ngroups; e += L28_THREADS) {
+        for (unsigned e = tid; e < ngroups; e += TH) {
             const unsigned c = e & cm, k = e >> log_cols;
             const unsigned r0 = ((k >> st) << (st + 2)) | (k & (half - 1)), r1 = r0 + half, r2 = r1 + half, r3 = r2 + half;
             const unsigned low = r0 & (half - 1);
@@ -312,19 +317,19 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
                     l28_store<RR>(t, tile, e1, hi);
                 }
             };
-            if (nbf == L28_BPL * L28_THREADS) {   // full tile: the twiddle loads of this lane's butterflies are issued before the arithmetic
+            if (nbf == L28_BPL * TH) {   // full tile: the twiddle loads of this lane's butterflies are issued before the arithmetic
                 Tw28<RR> w[L28_BPL];
                 unsigned e0v[L28_BPL], e1v[L28_BPL];
 #pragma unroll
                 for (unsigned q = 0; q < L28_BPL; ++q) {
                     size_t j;
-                    slots(tid + q * L28_THREADS, e0v[q], e1v[q], j);
+                    slots(tid + q * TH, e0v[q], e1v[q], j);
                     w[q] = tw[j << (log_n - s)];
                 }
 #pragma unroll
                 for (unsigned q = 0; q < L28_BPL; ++q) bfly(e0v[q], e1v[q], w[q]);
             } else {
-                for (unsigned e = tid; e < nbf; e += L28_THREADS) {
+                for (unsigned e = tid; e < nbf; e += TH) {
                     unsigned e0, e1;
                     size_t j;
                     slots(e, e0, e1, j);
@@ -341,18 +346,24 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
 }
 
 template <class P, class RR>
-__device__ __forceinline__ void l28_emit(const F28<RR> &v, Fp<P> *dst, const F28<RR> &scale28, int do_scale) {
-    // v: limbs < 2^32 (the last stages' carries are still pending).  The product takes it as it is and returns < 2p, so the
-    // subtraction chain ends at once; otherwise the carries are propagated here, once per element and pass.
-    const F28<RR> c = do_scale ? f28_mul<RR>(v, scale28) : f28_weak_norm<RR>(v);
+__device__ __forceinline__ void l28_emit(const F28<RR> &v, Fp<P> *dst, const F28<RR> &scale28, int do_scale, bool short_pass) {
+    // v: limbs < 2^32 (the last stages' carries are still pending), value < (1 + 4 ns) p.  The product takes it as it is and
+    // returns < 2p: one conditional subtraction; otherwise the carries are propagated here, once per element and pass, and the
+    // chain starts at 16p after a pass of <= 7 stages (short_pass: < 30p), at 32p after 8 or 9 (< 38p).  All three branches are
+    // uniform over the workgroup.
     Fp<P> out;
-    l28_pack_canonical<RR>(l28_canonical<RR>(c), out.l);
+    if (do_scale)
+        l28_pack_canonical<RR>(l28_canonical<RR, 0>(f28_mul<RR>(v, scale28)), out.l);
+    else if (short_pass)
+        l28_pack_canonical<RR>(l28_canonical<RR, 4>(f28_weak_norm<RR>(v)), out.l);
+    else
+        l28_pack_canonical<RR>(l28_canonical<RR, 5>(f28_weak_norm<RR>(v)), out.l);
     *dst = out;
 }
 
 // general pass: stages [s0, s0 + ns), tile of 2^ns rows x 2^log_cols contiguous columns, src -> dst at the same positions
-template <class P, class RR>
-__global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_pass28(const Fp<P> *a, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns,
+template <class P, class RR, unsigned TH>
+__global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_pass28(const Fp<P> *a, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns,
                                                              unsigned log_cols, Fp<P> scale_int, int do_scale, int pair_stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
@@ -361,25 +372,25 @@ __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     const size_t hi = g / lo_groups, lo0 = (g % lo_groups) << log_cols, base = (hi << (s0 + ns)) + lo0;
     // every load of the tile is in flight before the first one is unpacked (a 2^11-element tile is 8 per lane = 64 VGPRs):
     // with one load per loop trip the workgroup paid eight HBM round trips in sequence, a quarter of its time
-    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * L28_THREADS) {
+    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * TH) {
         Fp<P> v[L28_EPL];
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
-            const unsigned e = e8 + q * L28_THREADS, r = e >> log_cols, c = e & (cols - 1);
+            const unsigned e = e8 + q * TH, r = e >> log_cols, c = e & (cols - 1);
             if (e < tile) v[q] = a[base + ((size_t)r << s0) + c];
         }
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
-            const unsigned e = e8 + q * L28_THREADS;
+            const unsigned e = e8 + q * TH;
             if (e < tile) l28_store<RR>(t, tile, e, f28_unpack<RR>(v[q].l));
         }
     }
     __syncthreads();
-    l28_stages<P, RR, false>(t, tile, tw, log_n, s0, ns, log_cols, lo0, pair_stages != 0);
+    l28_stages<P, RR, false, TH>(t, tile, tw, log_n, s0, ns, log_cols, lo0, pair_stages != 0);
     const F28<RR> sc = f28_unpack<RR>(scale_int.l);
-    for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
+    for (unsigned e = threadIdx.x; e < tile; e += TH) {
         const unsigned r = e >> log_cols, c = e & (cols - 1);
-        l28_emit<P, RR>(l28_load<RR>(t, tile, e), &dst[base + ((size_t)r << s0) + c], sc, do_scale);
+        l28_emit<P, RR>(l28_load<RR>(t, tile, e), &dst[base + ((size_t)r << s0) + c], sc, do_scale, ns <= 7);
     }
 }
 
@@ -389,33 +400,33 @@ __global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // (8g .. 8g + 7): its loads are then 256-byte-contiguous segments like every other pass's, and it writes, for each of
 // its hi, 2^ns contiguous outputs.  Reads and writes touch different positions, so the pass goes src -> dst.
 // (src -> dst.)  The tile is swizzled (column (c + r) & (cols - 1)) so that the column-major store phase is bank-conflict free.
-template <class P, class RR>
-__global__ __launch_bounds__(L28_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned ns,
+template <class P, class RR, unsigned TH>
+__global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_first_pass28(const Fp<P> *src, Fp<P> *dst, const Tw28<RR> *tw, unsigned log_n, unsigned ns,
                                                                    unsigned log_cols, int pair_stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
     const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols, H = log_n - ns, cm = cols - 1;
     const size_t g = blockIdx.x;
-    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * L28_THREADS) {      // loads batched as in k_ntt_pass28
+    for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * TH) {      // loads batched as in k_ntt_pass28
         Fp<P> v[L28_EPL];
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
-            const unsigned e = e8 + q * L28_THREADS, rb = e >> log_cols, c = e & cm;
+            const unsigned e = e8 + q * TH, rb = e >> log_cols, c = e & cm;
             if (e < tile) v[q] = src[((size_t)rb << H) + (g << log_cols) + c];
         }
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
-            const unsigned e = e8 + q * L28_THREADS, rb = e >> log_cols, c = e & cm, r = __brev(rb) >> (32 - ns);
+            const unsigned e = e8 + q * TH, rb = e >> log_cols, c = e & cm, r = __brev(rb) >> (32 - ns);
             if (e < tile) l28_store<RR>(t, tile, r * cols + ((c + r) & cm), f28_unpack<RR>(v[q].l));
         }
     }
     __syncthreads();
-    l28_stages<P, RR, true>(t, tile, tw, log_n, 0, ns, log_cols, 0, pair_stages != 0);
+    l28_stages<P, RR, true, TH>(t, tile, tw, log_n, 0, ns, log_cols, 0, pair_stages != 0);
     const F28<RR> none = f28_zero<RR>();
-    for (unsigned e = threadIdx.x; e < tile; e += L28_THREADS) {
+    for (unsigned e = threadIdx.x; e < tile; e += TH) {
         const unsigned c = e >> ns, r = e & (rows - 1);
         const size_t hi = __brevll((unsigned long long)((g << log_cols) + c)) >> (64 - H);
-        l28_emit<P, RR>(l28_load<RR>(t, tile, r * cols + ((c + r) & cm)), &dst[(hi << ns) + r], none, 0);
+        l28_emit<P, RR>(l28_load<RR>(t, tile, r * cols + ((c + r) & cm)), &dst[(hi << ns) + r], none, 0, ns <= 7);
     }
 }
 
@@ -515,35 +526,53 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         Fr *tmp = ctx->ntt_tmp.as<Fr>();
         typedef typename C::FrNttRR RR;
         const Tw28<RR> *tw28 = twb.as<Tw28<RR>>();
-        const size_t lds28 = ((size_t)1 << 11) * RR::N * 4;
+        // workgroup shape (round 5): TH = 256 lanes on 2^10-element tiles where every pass still reads segments of >= 8 elements
+        // (256 B), TH = 512 on 2^11-element tiles otherwise (9-stage passes, domains above 2^24)
+        const unsigned p8 = (log_n + 7) / 8, p9 = (log_n + 8) / 9, npass = p9 < p8 ? p9 : p8;
+        const unsigned ns_max = log_n / npass + (log_n % npass ? 1 : 0);
+        // same-box A/B (profiles/r05_ntt_workgroup_shape_ab.txt): 2^21 forward 0.289 -> 0.276 ms, 2^22 inverse 0.562 -> 0.533 ms; 9-stage
+        // passes would read 64-byte segments on the small tile and stay on the large one
+#ifndef PM_NTT_TH_SMALL_MAX_NS
+#define PM_NTT_TH_SMALL_MAX_NS 8
+#endif
+        const bool small = ns_max <= PM_NTT_TH_SMALL_MAX_NS;
+        const unsigned tile_log28 = small ? 10 : 11;
         // the raised dynamic-LDS limit is a per-DEVICE function attribute: remembered per context (a context lives on one
         // device and runs one proof at a time), not in a process-wide flag -- a local group may span several devices and its
         // rank threads call this concurrently
         if (!ctx->ntt_lds_attr[C::ID]) {
-            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_pass28<P, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds28));
-            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_first_pass28<P, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds28));
+            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_pass28<P, RR, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << 11) * RR::N * 4)));
+            PM_HIP(ctx, hipFuncSetAttribute((const void *)k_ntt_first_pass28<P, RR, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)1 << 11) * RR::N * 4)));
             ctx->ntt_lds_attr[C::ID] = true;
         }
         Fr scale_int;
         for (int i = 0; i < P::N; ++i) scale_int.l[i] = RR::STD2INT[i];
         scale_int = mul<P>(ninv, scale_int);                      // n^-1 2^(W N) as a plain integer: the product with it scales AND reduces
-        // passes balanced over the stages, every tile 2^11 elements (21 = 7 + 7 + 7 with 16-column tiles, not 8 + 8 + 5 with a
+        // passes balanced over the stages, every tile 2^11 (2^10) elements (21 = 7 + 7 + 7 with 16-column tiles, not 8 + 8 + 5 with a
         // last pass whose workgroups hold 2^8 elements; 17 and 18 take two 9-stage passes instead of three)
-        const unsigned p8 = (log_n + 7) / 8, p9 = (log_n + 8) / 9, npass = p9 < p8 ? p9 : p8;
         const int pair_stages = 1;   // two stages per LDS round trip (profiles/r03_ntt_two_stage_ab.txt: -7 ... -13 % per transform)
         unsigned s0 = 0;
         for (unsigned k = 0; k < npass; ++k) {
             const unsigned ns = log_n / npass + (k < log_n % npass ? 1 : 0);
-            unsigned log_cols = 11 - ns;
+            unsigned log_cols = tile_log28 - ns;
             const bool last = s0 + ns == log_n;
             if (k == 0) {
-                hipLaunchKernelGGL((k_ntt_first_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
-                                   ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)d, tmp, tw28, log_n, ns, log_cols, pair_stages);
+                const dim3 grid((unsigned)(n >> (ns + log_cols)));
+                const size_t lds = ((size_t)1 << (ns + log_cols)) * RR::N * 4;
+                if (small)
+                    hipLaunchKernelGGL((k_ntt_first_pass28<P, RR, 256>), grid, dim3(256), lds, ctx->stream, (const Fr *)d, tmp, tw28, log_n, ns, log_cols, pair_stages);
+                else
+                    hipLaunchKernelGGL((k_ntt_first_pass28<P, RR, 512>), grid, dim3(512), lds, ctx->stream, (const Fr *)d, tmp, tw28, log_n, ns, log_cols, pair_stages);
             } else {
                 if (s0 < log_cols) log_cols = s0;
-                hipLaunchKernelGGL((k_ntt_pass28<P, RR>), dim3((unsigned)(n >> (ns + log_cols))), dim3(L28_THREADS),
-                                   ((size_t)1 << (ns + log_cols)) * RR::N * 4, ctx->stream, (const Fr *)tmp, last ? d : tmp, tw28, log_n, s0, ns,
-                                   log_cols, scale_int, last && inv_dir ? 1 : 0, pair_stages);
+                const dim3 grid((unsigned)(n >> (ns + log_cols)));
+                const size_t lds = ((size_t)1 << (ns + log_cols)) * RR::N * 4;
+                if (small)
+                    hipLaunchKernelGGL((k_ntt_pass28<P, RR, 256>), grid, dim3(256), lds, ctx->stream, (const Fr *)tmp, last ? d : tmp, tw28, log_n, s0, ns,
+                                       log_cols, scale_int, last && inv_dir ? 1 : 0, pair_stages);
+                else
+                    hipLaunchKernelGGL((k_ntt_pass28<P, RR, 512>), grid, dim3(512), lds, ctx->stream, (const Fr *)tmp, last ? d : tmp, tw28, log_n, s0, ns,
+                                       log_cols, scale_int, last && inv_dir ? 1 : 0, pair_stages);
             }
             PM_HIP(ctx, hipGetLastError());
             s0 += ns;
