@@ -98,8 +98,14 @@ if err:
 t0 = time.time()
 child = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "msm_bench.py"), "--tables", "--log-len", str(a.log_len), "--reps", "100000"],
                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-time.sleep(8.0 + 2.0 * max(0, a.log_len - 24))     # key upload + window tables before the loop proper
-mid, _ = metric_snapshot()
+# the bases and their window tables are built first (tens of seconds at 2^26): wait until the socket draws > 1 kW for a second
+t_wait, hot = time.time(), 0
+while time.time() - t_wait < 240 and hot < 20:
+    pw = read_num(f_power, 1e6) if f_power else None
+    hot = hot + 1 if (pw or 0) > 1000 else 0
+    time.sleep(0.05)
+print("== load reached after %.1f s (socket power > 1 kW for a second: %s)" % (time.time() - t_wait, hot >= 20))
+mid0, _ = metric_snapshot()
 samples = []
 t_loop = time.time()
 while time.time() - t_loop < a.seconds:
@@ -108,7 +114,7 @@ while time.time() - t_loop < a.seconds:
     dt = 0.010 - (time.time() - ts)
     if dt > 0:
         time.sleep(dt)
-after, _ = metric_snapshot()
+mid, _ = metric_snapshot()          # still under load: `mid0` -> `mid` brackets exactly the traced seconds
 child.terminate()
 try:
     child.wait(20)
@@ -124,15 +130,17 @@ for name, idx, unit in (("socket power", 1, "W"), ("sclk", 2, "MHz")):
         print("%-13s not readable from sysfs on this box" % name)
 print("first 40 samples (s, W, MHz):", [(round(t, 3), p and round(p), c and round(c)) for t, p, c in samples[:40]])
 
-print("== amd-smi metric, during the loop (everything that mentions a clock, power, throttle or violation)")
+time.sleep(3.0)
+after, _ = metric_snapshot()        # idle again
+print("== amd-smi metric under load: per-XCD gfx clocks, power, temperatures, throttle status")
 for k in sorted(mid):
     kl = k.lower()
-    if any(w in kl for w in ("thrott", "violation", "clk", "clock", "power", "ppt", "prochot", "residency", "below_host", "temperature.hotspot", "temperature.mem")):
+    if (".clock.gfx_" in kl and kl.endswith("clk.value")) or "power" in kl or "temperature" in kl or ("throttle" in kl and "xcp" not in kl):
         print("  %-70s %s" % (k, mid[k]))
-print("== counters that MOVED between the snapshot taken during the loop and the one %.0f s later (accumulators: the deltas name the limiter)" % a.seconds)
+print("== accumulators that MOVED during the %.0f traced seconds under load (the deltas name the limiter)" % a.seconds)
 moved = 0
-for k in sorted(after):
-    x, y = mid.get(k), after[k]
+for k in sorted(mid):
+    x, y = mid0.get(k), mid[k]
     if isinstance(x, (int, float)) and isinstance(y, (int, float)) and x != y:
         kl = k.lower()
         if any(w in kl for w in ("acc", "thrott", "violation", "residency", "below_host", "count", "energy")):
@@ -140,10 +148,10 @@ for k in sorted(after):
             moved += 1
 if not moved:
     print("  none of the accumulator-like fields moved (or this amd-smi exposes none)")
-print("== the same fields idle -> loop (for scale)")
-for k in sorted(mid):
-    x, y = before.get(k), mid[k]
-    if isinstance(x, (int, float)) and isinstance(y, (int, float)) and x != y and any(w in k.lower() for w in ("acc", "thrott", "violation", "residency", "below_host")):
-        print("  %-70s %s -> %s" % (k, x, y))
+print("== the same accumulators over 3 idle seconds afterwards (for scale: which of them count idleness, not throttling)")
+for k in sorted(after):
+    x, y = mid.get(k), after[k]
+    if isinstance(x, (int, float)) and isinstance(y, (int, float)) and x != y and any(w in k.lower() for w in ("acc", "residency", "below_host")):
+        print("  %-70s %s -> %s   (delta %s)" % (k, x, y, y - x))
 print("== amd-smi metric --throttle (text, after the loop)")
 print(smi("metric", "--throttle").strip()[:3000])
