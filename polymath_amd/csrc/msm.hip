@@ -1244,6 +1244,9 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             hipLaunchKernelGGL(k_hist_small, dim3(sblocks), dim3(1024), 0, st, keys2, sub_off, nsub, 0u, FIN_BINS, chunk, counts);
             PM_HIP(ctx, hipGetLastError());
             PM_TRY(bucket_scan());
+            // (round 5 measured the last level WITHOUT LDS staging -- lanes storing their 4-byte indices straight into the sub-region's
+            // 120 KB output window, which stays in L2: the sort of a 2^24-pair MSM 2.66 -> 3.70 ms, a proof +2.2 ms; 64 partial-line
+            // stores per wave instruction cost more than the staging saves: profiles/r05_sort_final_direct_negative.txt)
             hipLaunchKernelGGL(k_region_pass_staged<RS_FINAL>, dim3(stblocks), dim3(1024), 0, st, keys2, vals2, sub_off, nsub, 0u,
                                FIN_BINS, S.bucket_off.as<uint32_t>(), cursor, S.sorted.as<uint32_t>(), (uint16_t *)nullptr,
                                (uint32_t *)nullptr);
