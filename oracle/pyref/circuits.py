@@ -165,7 +165,7 @@ def first_entry_dot(r, row, zz):
     return s % r
 
 
-def random_r1cs(c, seed, m0, nr, max_entries=4, unused_every=5):
+def random_r1cs(c, seed, m0, nr, max_entries=4, unused_every=5, extreme=False):
     """A seeded random R1CS of ARBITRARY shape for differential testing of the witness map
     (common.rs:77-97, 131-207; prover.rs:75-96, 156-166) -- everything the harness circuits never do:
     m0 - 1 free public inputs (m0 = 1: none), 0..max_entries entries per row in each of A, B, C, entries on
@@ -173,11 +173,17 @@ def random_r1cs(c, seed, m0, nr, max_entries=4, unused_every=5):
     (only the first counts: m_at), empty rows, witness columns no row uses (points at infinity in
     uj_wj_lcs), a fresh witness per gate with a random non-zero coefficient somewhere inside its C row.
     Satisfied under m_at's first-entry semantics.  Draw order: instance values, seed witnesses, then per
-    gate: the A row, the B row, the C row."""
+    gate: the A row, the B row, the C row.  extreme: the free values (public inputs, seed and unused witnesses)
+    come from {0, 1, r - 1, r - 2, 2} three times out of four -- zero scalars, 1 - x = 0, products that vanish."""
     r = c.r
     g = SplitMix64(seed)
-    inst = [1] + [g.fr(r) for _ in range(m0 - 1)]
-    z = inst + [g.fr(r) for _ in range(1 + g.below(3))]          # One, instance, then the witnesses as they are allocated
+
+    def free_value():
+        if extreme and g.below(4):
+            return (0, 1, r - 1, r - 2, 2)[g.below(5)]
+        return g.fr(r)
+    inst = [1] + [free_value() for _ in range(m0 - 1)]
+    z = inst + [free_value() for _ in range(1 + g.below(3))]     # One, instance, then the witnesses as they are allocated
 
     def coef():
         k = g.below(8)
@@ -222,7 +228,7 @@ def random_r1cs(c, seed, m0, nr, max_entries=4, unused_every=5):
         B.append(rb)
         Cm.append(rc)
         if unused_every and g.below(unused_every) == 0:
-            z.append(g.fr(r))                                        # a witness no row refers to
+            z.append(free_value())                                   # a witness no row refers to
     wit = z[m0:]
     q = R1CS(m0, len(wit), A, B, Cm)
     assert all(first_entry_dot(r, a, z) * first_entry_dot(r, b, z) % r == first_entry_dot(r, cc, z) for a, b, cc in zip(A, B, Cm))

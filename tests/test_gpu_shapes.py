@@ -203,3 +203,43 @@ def test_differential_fuzz_of_r1cs_shapes_on_rank_threads(oracle, api, seed):
             assert all(p == want for p in _run_ranks(N, lambda r: pms[r].prove_native(pks[r], lc.inst_limbs, lc.wit_limbs, r_a), comms))
     for pk in pks:
         pk.free()
+
+
+@pytest.mark.parametrize("seed", range(60, 76))
+def test_differential_fuzz_with_extreme_assignments(gpu_ctx, oracle, api, seed):
+    """16 shapes whose FREE values (public inputs, seed and unused witnesses) are mostly 0, 1, r - 1, r - 2, 2: zero scalars in
+    z_tail and in the MSMs (arkworks' msm skips them), 1 - x_i = 0 in the head rows (common.rs:77-97), gate products that vanish,
+    -1 digits in every window.  Whatever the CPU oracle returns -- a proof or a status -- the HIP path returns the same."""
+    from polymath_amd.polymath import Polymath, PolymathProverError
+    curve, m0, nr, tables = fuzz_shape(seed)
+    c = CURVES[curve]
+    gpu_ctx.set_option("tables", tables)
+    q, inst, wit = CI.random_r1cs(c, 0xE000 + seed, m0, nr, extreme=True)
+    g = CI.SplitMix64(12000 + seed)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    if seed % 4 == 0:
+        r_a = [0, 0]                      # the reference would draw this with probability 2^-510; A(X) = u(X) then
+    opk = oracle.OraclePk(curve, q, x, z, 8)
+    omega = oracle.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+    TR = T.make_transcripts(c)["keccak256"]
+    try:
+        want, rc = SE.ser_proof(c, DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, TR)), 0
+    except DR.ProverError as e:
+        want, rc = None, e.rc
+    A, B, C = __import__("helpers").pm_csrs(curve, q)
+    gpk = api.ProvingKey.generate(gpu_ctx, curve, q.m0, q.mw, q.nr, A, B, C, oracle.fr_to_mont_limbs(curve, [x])[0], oracle.fr_to_mont_limbs(curve, [z])[0])
+    for i in range(6):
+        assert np.array_equal(gpk.export_bases(i), opk.export_bases(i)), i
+    pm = Polymath(curve, "keccak256", ctx=gpu_ctx)
+    try:
+        got, grc = pm.prove_native(gpk, pm.field.fr_limbs(inst), pm.field.fr_limbs(wit), r_a), 0
+    except PolymathProverError as e:
+        got, grc = None, e.status
+    assert (grc, got) == (rc, want)
+    if rc == 0:
+        for which in range(8):
+            a, b = gpk.tap(which, 1 << 16), opk.tap(which, 1 << 16)
+            k = min(len(a), len(b))
+            assert k > 0 and np.array_equal(a[:k], b[:k]) and not a[k:].any() and not b[k:].any(), which
+        assert pm.verify(pm.make_vk(gpk, x, z), inst[1:], got)
+    gpk.free()
