@@ -70,6 +70,7 @@ def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
     t_setup = time.time() - t0
     omega = CO.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
     inst = lc.instance
+    os.environ.setdefault("PO_PROFILE", "1")      # the restatement's stage clock on stderr: where its seconds go
     t0 = time.time()
     ref = DR.prove(opk, opk.n, opk.sigma, omega, inst, None, r_a, OT.make_transcripts(c)[transcript], w_limbs=lc.wit_limbs)
     dt = time.time() - t0

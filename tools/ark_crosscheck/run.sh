@@ -2,8 +2,8 @@
 # One command for a machine that has cargo (this repo's build image does not):
 #   POLYMATH_REF=/path/to/sigma0-dev/polymath ./run.sh [--bench]
 # 1. emit   : the reference's own setup/prove on tests/dummy.rs and tests/mimc.rs shapes, test_rng seeds
-#             -> tests/golden/ref_dummy.json, ref_mimc322.json   (consumed by tests/test_reference_fixtures.py)
-# 2. verify : this repo's 15 BLS12-381 golden proofs through the reference's Polymath::verify -> must print "15 / 15 accepted"
+#             -> tests/golden/ref_dummy.json, ref_inputs11.json, ref_inputs0.json, ref_mimc322.json   (consumed by tests/test_reference_fixtures.py)
+# 2. verify : this repo's 24 BLS12-381 golden proofs (m0 = 1, 2, 3 and 12) through the reference's Polymath::verify -> must print "24 / 24 accepted"
 # 3. --bench: ark-ec msm_unchecked / ark-poly fft at 2^20 .. 2^24 -> tests/golden/ref_cpu_baseline.json
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"

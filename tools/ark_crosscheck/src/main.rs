@@ -4,8 +4,9 @@
 //! (src/lib.rs:52-91, src/data_structures.rs:9-73) and arkworks' algebra HEAD, which the reference patches in.
 //!
 //!   emit <dir>            reference setup + prove on the shapes of tests/dummy.rs:37-80 and tests/mimc.rs:145-227, with the
-//!                         same seeds (`StdRng::seed_from_u64(test_rng().next_u64())`), for the three transcripts; writes
-//!                         <dir>/ref_dummy.json and <dir>/ref_mimc322.json in the schema of tests/golden/proofs.json:
+//!                         same seeds (`StdRng::seed_from_u64(test_rng().next_u64())`), plus two product chains with 11 and 0 public
+//!                         inputs (m0 = 12 and 1: the reference's tests only have m0 = 2), for the three transcripts; writes
+//!                         <dir>/ref_dummy.json, ref_inputs11.json, ref_inputs0.json and ref_mimc322.json in the schema of tests/golden/proofs.json:
 //!                         R1CS, assignment, the trapdoors x, z and the prover's r_a (recovered by replaying the draws on a
 //!                         clone of the RNG and CHECKED against [x]_2, [z]_2 and the proof itself), proof bytes, vk bytes,
 //!                         and (dummy only) the whole serialised ProvingKey.
@@ -47,6 +48,35 @@ impl ConstraintSynthesizer<Fr> for Product {
         let b = cs.new_witness_variable(|| self.b.ok_or(SynthesisError::AssignmentMissing))?;
         let c = cs.new_input_variable(|| Ok(self.a.ok_or(SynthesisError::AssignmentMissing)? * self.b.ok_or(SynthesisError::AssignmentMissing)?))?;
         cs.enforce_constraint(lc!() + a, lc!() + b, lc!() + c)
+    }
+}
+
+/// A chain of products v_i * v_{i+1} = p_i whose first `public` outputs are PUBLIC inputs and the rest witnesses: m0 = public + 1.
+/// The reference's own tests only ever have one public input (m0 = 2); its SAP matrices have arms for every m0
+/// (common.rs:77-97, 138-207) and the witness-only part of u is cut at column m0 (prover.rs:156-166).  public = 11 gives m0 = 12
+/// (2 m0 > 16: this repository's HIP path then runs a fifth transform), public = 0 gives m0 = 1 (no public input at all).
+#[derive(Clone)]
+struct Chain {
+    vals: Vec<Option<Fr>>,
+    public: usize,
+}
+impl ConstraintSynthesizer<Fr> for Chain {
+    fn generate_constraints(self, cs: ConstraintSystemRef<Fr>) -> Result<(), SynthesisError> {
+        let missing = || SynthesisError::AssignmentMissing;
+        let mut vars = Vec::with_capacity(self.vals.len());
+        for v in &self.vals {
+            let v = *v;
+            vars.push(cs.new_witness_variable(|| v.ok_or(missing()))?);
+        }
+        for i in 0..self.vals.len() - 1 {
+            let prod = match (self.vals[i], self.vals[i + 1]) {
+                (Some(a), Some(b)) => Some(a * b),
+                _ => None,
+            };
+            let out = if i < self.public { cs.new_input_variable(|| prod.ok_or(missing()))? } else { cs.new_witness_variable(|| prod.ok_or(missing()))? };
+            cs.enforce_constraint(lc!() + vars[i], lc!() + vars[i + 1], lc!() + out)?;
+        }
+        Ok(())
     }
 }
 
@@ -224,6 +254,13 @@ fn emit(out_dir: &str) {
         });
         (Product { a: None, b: None }, make)
     });
+    // m0 = 12 and m0 = 1 (round 5): 40 chained values, the first 11 / 0 products public
+    for (case, public) in [("inputs11", 11usize), ("inputs0", 0usize)] {
+        emit_case(out_dir, case, false, move |_rng: &mut StdRng| {
+            let make: Box<dyn Fn(&mut StdRng) -> Chain> = Box::new(move |rng: &mut StdRng| Chain { vals: (0..40).map(|_| Some(Fr::rand(rng))).collect(), public });
+            (Chain { vals: vec![None; 40], public }, make)
+        });
+    }
     emit_case(out_dir, "mimc322", false, |rng: &mut StdRng| {
         let k: Vec<Fr> = (0..ROUNDS).map(|_| rng.gen()).collect(); // mimc.rs:155
         let k2 = k.clone();
