@@ -68,26 +68,25 @@ def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
     for i in range(6):
         opk.import_bases(i, gpk.export_bases(i))
     t_setup = time.time() - t0
-    omega = CO.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
-    inst = lc.instance
-    os.environ.setdefault("PO_PROFILE", "1")      # the restatement's stage clock on stderr: where its seconds go
-    t0 = time.time()
-    ref = DR.prove(opk, opk.n, opk.sigma, omega, inst, None, r_a, OT.make_transcripts(c)[transcript], w_limbs=lc.wit_limbs)
-    dt = time.time() - t0
-    same = gpu_proof is None or SE.ser_proof(c, ref) == gpu_proof
-    pairs = 14 * opk.n + 30
-    # The metric's second half on the CPU: the restatement's standalone Pippenger on a bounded sample of the
-    # quotient MSM's own bases -- all threads, half and a quarter of them (where does it peak?) and ONE thread (the per-thread rate
-    # a reader can hold against a tuned library: arkworks' msm_unchecked does ~0.2-0.3 M pairs/s per core on BLS12-381).
+    # The metric's second half on the CPU FIRST: the restatement's standalone Pippenger on a bounded sample of the
+    # quotient MSM's own bases at cores, cores / 2, / 4, / 8 threads (os.cpu_count() counts SMT siblings and ignores the container's
+    # CPU quota: where does it peak?) and on ONE thread (the per-thread rate a reader can hold against a tuned library: arkworks'
+    # msm_unchecked does ~0.2-0.3 M pairs/s per core on BLS12-381).  The whole prove below then runs at the peak's thread count.
     import numpy as np
-    msm = {}
+    msm, threads = {}, cores
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        msm["cgroup_cpu_max"] = " ".join(quota)
+    except Exception:         # noqa: BLE001
+        pass
     try:
         ln = min(1 << 20, opk.base_lens[3])
         bases = opk.export_bases(3, 0, ln)
         rng = np.random.default_rng(5)
         sc = rng.integers(0, 1 << 64, size=(ln, 4), dtype=np.uint64)
         sc[:, 3] &= np.uint64((1 << (c.r.bit_length() - 193)) - 1)            # below r: one bit under its top limb
-        sweep = sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True)
+        CO.msm(curve, bases[:4096], sc[:4096], 2)                             # warm-up: tables, page faults
+        sweep = sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True)
         rates = {}
         for nt in sweep:
             t0 = time.time()
@@ -97,18 +96,29 @@ def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
         t0 = time.time()
         CO.msm(curve, bases[:l1], sc[:l1], 1)
         one = l1 / (time.time() - t0)
-        best = max(rates, key=rates.get)
-        msm = {"msm_sample": "standalone oracle/cpp Pippenger, 2^%d pairs of the quotient MSM's bases, uniform scalars" % (ln.bit_length() - 1),
-               "msm_pairs_per_sec_by_threads": {str(k): v for k, v in rates.items()}, "msm_pairs_per_sec": rates[best], "msm_threads_at_peak": best,
-               "msm_pairs_per_sec_one_thread": one, "msm_one_thread_sample_pairs": l1}
+        threads = max(rates, key=rates.get)
+        msm.update({"msm_sample": "standalone oracle/cpp Pippenger, 2^%d pairs of the quotient MSM's bases, uniform scalars" % (ln.bit_length() - 1),
+                    "msm_pairs_per_sec_by_threads": {str(k): v for k, v in rates.items()}, "msm_pairs_per_sec": rates[threads], "msm_threads_at_peak": threads,
+                    "msm_pairs_per_sec_one_thread": one, "msm_one_thread_sample_pairs": l1})
     except Exception as e:    # noqa: BLE001 -- the baseline leg must not cost the run its line
-        msm = {"msm_error": repr(e)}
+        msm["msm_error"] = repr(e)
+    opk.nthreads = threads
+    omega = CO.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+    inst = lc.instance
+    os.environ.setdefault("PO_PROFILE", "1")      # the restatement's stage clock on stderr: where its seconds go
+    t0 = time.time()
+    ref = DR.prove(opk, opk.n, opk.sigma, omega, inst, None, r_a, OT.make_transcripts(c)[transcript], w_limbs=lc.wit_limbs)
+    dt = time.time() - t0
+    same = gpu_proof is None or SE.ser_proof(c, ref) == gpu_proof
+    pairs = 14 * opk.n + 30
+    cores = threads           # what the timed prove really used
     out = {"value": lc.nr / dt, "unit": "constraints/s", "cores": cores, "kind": "port",
            "sample": "oracle/cpp CPU restatement (not arkworks; 64-bit-limb C++, %d threads): ONE whole prove of the 2^%d-100-gate "
                      "synthetic R1CS (n=%d, %d MSM pairs) in %.2f s, on the key exported from HBM (import %.1f s untimed); "
                      "proof bytes %s the GPU's" % (cores, log_nr, opk.n, pairs, dt, t_setup, "==" if same else "!="),
            "seconds": dt, "proof_identical_to_gpu": same, "msm_pairs_per_sec_whole_prove": pairs / dt}
     out.update(msm)
+    out["host_threads_online"] = os.cpu_count()
     return out
 
 
