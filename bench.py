@@ -308,6 +308,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-micro", default="20,22,24,26", help="log2 lengths of the standalone resident MSM legs ('' = none)")
     ap.add_argument("--ntt-micro", default="21,22,24", help="log2 sizes of the standalone resident NTT legs ('' = none)")
+    ap.add_argument("--inflight", type=int, default=2, help="proofs in flight of the serving-throughput leg beside `value` (0 = skip; single GPU only)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure `roofline.traffic`")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="pm_ctx_set_option on the proving context before the key is generated, e.g. --opt msm_overlap=0 --opt tables=wide")
@@ -633,6 +634,43 @@ def worker(args):
                     out["valu"]["effective_clock_source"] = LIVE_EXTRAS["effective_clock_source"]
                     out["valu"]["clock_limiter"] = ("package power tracking (PPT): amd-smi's throttle accumulators over a loop of this kernel -- PPT violation "
                                                     "active 57 % of the samples, PROCHOT / socket / VR / HBM thermal counters at 0 (profiles/r05_clock_limiter.txt)")
+            if args.inflight > 1 and native:
+                # A prover that SERVES keeps more than one proof in flight: K host threads, one context each (own stream, workspaces and
+                # proof state), the same resident key (pm_pk is immutable: include/polymath_hip.h, "Threading").  One proof's latency-bound
+                # stretches -- bucket reductions, sort tails, the host's transcript between the phases -- fill with another's accumulation.
+                # Reported BESIDE `value` (which stays one proof at a time, as benches/bench.rs:79 times it), never instead of it.
+                try:
+                    import threading
+                    K, per = args.inflight, max(3, args.steps // 2)
+                    pms = [pm] + [Polymath(curve, args.transcript, device=local) for _ in range(K - 1)]
+                    for extra in pms[1:]:
+                        for kv in args.opt:
+                            name, value = kv.split("=", 1)
+                            extra.ctx.set_option(name, int(value) if value.lstrip("-").isdigit() else value)
+                    views = [pk] + [pk.view(e.ctx) for e in pms[1:]]
+                    outs = [None] * K
+                    for e, v in zip(pms, views):                       # warm-up: every context allocates its workspaces
+                        assert e.prove_native(v, x_l, w_l, r_a) == proof_b
+
+                    def serve(i):
+                        for _ in range(per):
+                            outs[i] = pms[i].prove_native(views[i], x_l, w_l, r_a)
+                    th = [threading.Thread(target=serve, args=(i,)) for i in range(K)]
+                    torch.cuda.synchronize()
+                    t_s = time.perf_counter()
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    torch.cuda.synchronize()
+                    dt_s = time.perf_counter() - t_s
+                    out["throughput_in_flight"] = {"proofs_in_flight": K, "proofs": K * per, "ms_per_proof": dt_s / (K * per) * 1e3,
+                                                   "constraints_per_sec": nr * K * per / dt_s, "proofs_identical": all(o == proof_b for o in outs),
+                                                   "note": "serving throughput: %d host threads, one pm_ctx each, one resident pm_pk; `value` above is one proof at a time" % K}
+                    for e in pms[1:]:
+                        e.ctx.close()
+                except Exception as e:      # noqa: BLE001 -- an extra leg must not cost the run its line
+                    out["throughput_in_flight"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
                 cores = os.cpu_count() or 1
                 cb_log = args.cpu_baseline_log or (args.log_constraints if cores >= 32 and args.log_constraints <= 20 else 16)
