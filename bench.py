@@ -74,9 +74,13 @@ def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
     # msm_unchecked does ~0.2-0.3 M pairs/s per core on BLS12-381).  The whole prove below then runs at the peak's thread count.
     import numpy as np
     msm, threads = {}, cores
+    quota_cores = None
     try:
         quota = open("/sys/fs/cgroup/cpu.max").read().split()
         msm["cgroup_cpu_max"] = " ".join(quota)
+        if quota[0] != "max":
+            quota_cores = max(1, -(-int(quota[0]) // int(quota[1])))          # the CPUs this container may really use
+            msm["cpu_quota_cores"] = quota_cores
     except Exception:         # noqa: BLE001
         pass
     try:
@@ -86,7 +90,10 @@ def cpu_baseline(curve, log_nr, lc, gpk, r_a, gpu_proof, transcript):
         sc = rng.integers(0, 1 << 64, size=(ln, 4), dtype=np.uint64)
         sc[:, 3] &= np.uint64((1 << (c.r.bit_length() - 193)) - 1)            # below r: one bit under its top limb
         CO.msm(curve, bases[:4096], sc[:4096], 2)                             # warm-up: tables, page faults
-        sweep = sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True)
+        sweep = {cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}
+        if quota_cores:
+            sweep |= {min(cores, quota_cores), min(cores, 2 * quota_cores)}
+        sweep = sorted(sweep, reverse=True)
         rates = {}
         for nt in sweep:
             t0 = time.time()
