@@ -1,7 +1,7 @@
 # Collects the judged evidence on an MI355X box: bench JSON lines, rocprofv3 kernel stats, the two PMC traffic passes.
 #   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh <tag>'   -> gpurun_out/<tag>/
 set -x
-TAG=${1:-r04x}
+TAG=${1:-r05_final}
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $O
