@@ -493,9 +493,44 @@ impl GpuKey {
         Ok(GpuKey { raw, curve, m0: k.m0, mw: k.mw })
     }
 
+    /// `pm_pk_load_sharded`: this rank's share of a key for ONE proof over `shard_count` GPUs (one process per GPU).  `layout`:
+    /// [`ShardLayout::Vector`] shards witness map, transforms, scans and MSM pairs (the context must have been joined to its
+    /// rank's [`Comm`] first); [`ShardLayout::Pairs`] shards the MSM pair ranges only and the phases return PARTIAL points
+    /// (sum them with [`Comm::combine_points`]).  Every rank then runs exactly the three phases of a single-GPU proof.
+    pub fn upload_sharded<E: Pairing>(ctx: &mut Context, k: &KeyParts<'_, E>, shard_rank: i32, shard_count: i32, layout: ShardLayout) -> Result<GpuKey, HipError> {
+        let curve = curve_checked::<E>()?;
+        let (a, b, c) = (flatten(k.a)?, flatten(k.b)?, flatten(k.c)?);
+        let stride = core::mem::size_of::<E::G1Affine>();
+        let arr = |s: &[E::G1Affine]| sys::pm_base_array { points: s.as_ptr() as *const c_void, len: s.len(), stride };
+        let bases = [
+            arr(k.x_powers_g1),
+            arr(k.x_powers_y_alpha_g1),
+            arr(k.x_powers_y_gamma_g1),
+            arr(k.x_powers_y_gamma_z_g1),
+            arr(k.x_powers_zh_by_y_alpha_g1),
+            arr(k.uj_wj_lcs_by_y_alpha_g1),
+        ];
+        let mut raw = core::ptr::null_mut();
+        // SAFETY: as in `upload`; a collective only in the sense that every rank must make the same call for its own share.
+        let rc = unsafe {
+            sys::pm_pk_load_sharded(ctx.raw, curve.id(), k.n, k.m0, k.mw, k.nr, k.sigma, &a.raw(), &b.raw(), &c.raw(), bases.as_ptr(), shard_rank, shard_count,
+                                    layout as i32, &mut raw)
+        };
+        ctx.check(rc)?;
+        Ok(GpuKey { raw, curve, m0: k.m0, mw: k.mw })
+    }
+
     pub fn raw(&self) -> *const sys::pm_pk {
         self.raw
     }
+}
+
+/// `pm_shard_layout`
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+#[repr(i32)]
+pub enum ShardLayout {
+    Pairs = 0,
+    Vector = 1,
 }
 
 impl Drop for GpuKey {
@@ -529,6 +564,101 @@ impl GpuKeyCache {
 pub fn global_key_cache() -> &'static GpuKeyCache {
     static CACHE: OnceLock<GpuKeyCache> = OnceLock::new();
     CACHE.get_or_init(GpuKeyCache::default)
+}
+
+// ------------------------------------------------------------------------------------------ multi-GPU exchange layer
+/// One rank's `pm_comm` (include/polymath_hip.h, "multi-GPU exchange layer"): RCCL inside the library, one process per GPU.
+/// Rank 0 makes the 128-byte id ([`Comm::rccl_unique_id`]) and ships it to the other ranks over the job's own channel (MPI, a
+/// TCP store, a file); every rank then calls [`Comm::rccl`] (collective: ncclCommInitRank) and joins its context with
+/// [`Context::set_comm`].  Collectives have a deadline; a failed communicator stays failed ([`Comm::failed`]).
+pub struct Comm {
+    raw: *mut sys::pm_comm,
+}
+
+// SAFETY: a pm_comm is used by the one thread that drives its rank's context (plus the library's own watchdog thread).
+unsafe impl Send for Comm {}
+
+impl Comm {
+    pub fn rccl_unique_id() -> Result<[u8; 128], HipError> {
+        let mut id = [0u8; 128];
+        // SAFETY: 128 writable bytes.
+        let rc = unsafe { sys::pm_comm_rccl_unique_id(id.as_mut_ptr() as *mut c_void) };
+        if rc != sys::PM_OK {
+            return Err(err(Status::from_raw(rc), "pm_comm_rccl_unique_id failed (librccl could not be loaded?)"));
+        }
+        Ok(id)
+    }
+
+    pub fn rccl(unique_id: &[u8; 128], rank: i32, world: i32, device: i32) -> Result<Comm, HipError> {
+        let mut raw = core::ptr::null_mut();
+        // SAFETY: 128 readable bytes, a valid out-pointer.
+        let rc = unsafe { sys::pm_comm_rccl_create(unique_id.as_ptr() as *const c_void, rank, world, device, &mut raw) };
+        if rc != sys::PM_OK || raw.is_null() {
+            return Err(err(Status::from_raw(rc), "pm_comm_rccl_create failed"));
+        }
+        Ok(Comm { raw })
+    }
+
+    pub fn set_timeout_ms(&mut self, ms: i64) -> Result<(), HipError> {
+        // SAFETY: live communicator.
+        let rc = unsafe { sys::pm_comm_set_timeout_ms(self.raw, ms as core::ffi::c_long) };
+        if rc == sys::PM_OK { Ok(()) } else { Err(err(Status::from_raw(rc), "pm_comm_set_timeout_ms")) }
+    }
+
+    pub fn failed(&self) -> bool {
+        // SAFETY: live communicator.
+        unsafe { sys::pm_comm_failed(self.raw) != 0 }
+    }
+
+    pub fn last_error(&self) -> String {
+        // SAFETY: live communicator; the library returns a NUL-terminated copy it owns.
+        unsafe { CStr::from_ptr(sys::pm_comm_last_error(self.raw)) }.to_string_lossy().into_owned()
+    }
+
+    /// Sum over the ranks of `points` (a [`ShardLayout::Pairs`] key's partial results), in place: all-gather + `pm_g1_sum`
+    /// (RCCL has no elliptic-curve reduction).
+    pub fn combine_points<E: Pairing>(&mut self, points: &mut [E::G1Affine]) -> Result<(), HipError> {
+        let curve = curve_checked::<E>()?;
+        let words = 2 * curve.fq_limbs();
+        let mut xy = vec![0u64; words * points.len()];
+        let mut inf = vec![0i32; points.len()];
+        for (i, p) in points.iter().enumerate() {
+            let raw = raw_words(p, words);
+            inf[i] = raw_byte(p, 8 * words) as i32;
+            if inf[i] == 0 {
+                xy[i * words..(i + 1) * words].copy_from_slice(&raw);
+            }
+        }
+        // SAFETY: `count` points of `words` u64 each and as many flags.
+        let rc = unsafe { sys::pm_comm_combine_points(self.raw, curve.id(), points.len() as i32, xy.as_mut_ptr(), inf.as_mut_ptr()) };
+        if rc != sys::PM_OK {
+            return Err(HipError { status: Status::from_raw(rc), message: self.last_error() });
+        }
+        for (i, p) in points.iter_mut().enumerate() {
+            let mut buf = [0u64; 12];
+            buf[..words].copy_from_slice(&xy[i * words..(i + 1) * words]);
+            *p = g1_from_raw::<E>(curve, &buf, inf[i]);
+        }
+        Ok(())
+    }
+}
+
+impl Drop for Comm {
+    fn drop(&mut self) {
+        // SAFETY: created by pm_comm_rccl_create, destroyed once; detach it from its context first (`Context::set_comm(None)`).
+        unsafe { sys::pm_comm_destroy(self.raw) }
+    }
+}
+
+impl Context {
+    /// Join this context to its rank's communicator (required before proving on a [`ShardLayout::Vector`] key), or detach it.
+    /// The context does not own the communicator: keep the `Comm` alive for as long as it is attached.
+    pub fn set_comm(&mut self, comm: Option<&mut Comm>) -> Result<(), HipError> {
+        let raw = comm.map_or(core::ptr::null_mut(), |c| c.raw);
+        // SAFETY: live context; a null communicator detaches.
+        let rc = unsafe { sys::pm_ctx_set_comm(self.raw, raw) };
+        self.check(rc)
+    }
 }
 
 /// The device this process proves on: `POLYMATH_HIP_DEVICE`, else `LOCAL_RANK` (one process per GPU), else 0.
