@@ -12,7 +12,7 @@ timeout 1500 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --msm-micro 
 for n in 2 4 8; do timeout 300 python tools/shard_emulation.py --ranks $n --steps 3 > $O/shard_emulation_vector_$n.json 2>> $O/bench.log; done
 timeout 300 python tools/shard_emulation.py --ranks 8 --steps 3 --layout pairs > $O/shard_emulation_pairs_8.json 2>> $O/bench.log
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --msm-micro "" --ntt-micro "" --no-live-traffic > $O/bench_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --msm-micro "" --ntt-micro "" --no-live-traffic --inflight 0 > $O/bench_under_rocprof.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --msm-micro "" --ntt-micro "" --no-live-traffic --opt msm_overlap=0 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --msm-micro "" --ntt-micro "" --no-live-traffic --opt msm_overlap=0 > /dev/null 2>&1
 # where a rank-proof goes at N = 8: kernel trace of the emulation, split by rank thread
