@@ -858,10 +858,16 @@ __global__ __launch_bounds__(1024) void k_hist_small(const uint16_t *keys, const
 // the global stores are coalesced: consecutive lanes write consecutive addresses of a bin's run
 // (the direct version above issues 64 scattered 4-byte stores per wave-instruction).
 //   LDS: h[nbins] | start[nbins] | delta[nbins] | staged vals (u32 x ST_CHUNK) | staged keys (u16 x ST_CHUNK)
-constexpr unsigned ST_CHUNK = 8192, ST_PER_LANE = ST_CHUNK / 1024, ST_MAX_BINS = 256;
+#ifndef PM_ST_THREADS
+#define PM_ST_THREADS 1024
+#endif
+#ifndef PM_ST_PER_LANE
+#define PM_ST_PER_LANE 8
+#endif
+constexpr unsigned ST_THREADS = PM_ST_THREADS, ST_PER_LANE = PM_ST_PER_LANE, ST_CHUNK = ST_PER_LANE * ST_THREADS, ST_MAX_BINS = 256;
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_region_pass_staged(const uint16_t *keys, const uint32_t *vals, const uint32_t *seg_off,
+__global__ __launch_bounds__(ST_THREADS) void k_region_pass_staged(const uint16_t *keys, const uint32_t *vals, const uint32_t *seg_off,
                                                              unsigned nseg, unsigned bin_shift, unsigned nbins,
                                                              const uint32_t *out_off, uint32_t *cursor, uint32_t *sorted,
                                                              uint16_t *keys_out, uint32_t *vals_out) {
@@ -892,17 +898,24 @@ __global__ __launch_bounds__(1024) void k_region_pass_staged(const uint16_t *key
         // 2-byte + eight 4-byte ones.  The passes are bound by the number of vector-memory instructions, not by bytes (13.4 M wave
         // instructions for 2.4 GB per pass at ~3.3 TB/s; the address coalescer takes a wave's 64 lanes in 16 clocks whatever their
         // width): 16 -> 3 load instructions per lane.  The piece [s0, s1) is widened down to a multiple of 8 entries so that the loads are
-        // aligned (the buffers are; a piece starts inside the chunk, so 1024 lanes still cover it); `vm` masks the entries outside it.
+        // aligned (the buffers are; a piece starts inside the chunk, so the workgroup's lanes still cover it); `vm` masks the entries outside it.
         uint32_t rank[ST_PER_LANE], val[ST_PER_LANE];
         uint16_t key[ST_PER_LANE];
-        static_assert(ST_PER_LANE == 8, "one uint4 of keys per lane");
-        const uint32_t e0 = (s0 & ~7u) + 8u * t;
+        static_assert(ST_PER_LANE % 8 == 0, "whole uint4s of keys per lane");
+        const uint32_t e0 = (s0 & ~(ST_PER_LANE - 1u)) + ST_PER_LANE * t;
         uint32_t vm = 0;
-        if (e0 < s1 && e0 + 8u > s0) {
-            const uint4 kv = *(const uint4 *)(keys + e0);
-            const uint4 va = *(const uint4 *)(vals + e0), vb = *(const uint4 *)(vals + e0 + 4);
-            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
-            const uint32_t vw[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        if (e0 < s1 && e0 + ST_PER_LANE > s0) {
+            uint32_t kw[ST_PER_LANE / 2], vw[ST_PER_LANE];
+#pragma unroll
+            for (unsigned g = 0; g < ST_PER_LANE / 8; ++g) {
+                const uint4 kv = *(const uint4 *)(keys + e0 + 8 * g);
+                kw[4 * g] = kv.x; kw[4 * g + 1] = kv.y; kw[4 * g + 2] = kv.z; kw[4 * g + 3] = kv.w;
+            }
+#pragma unroll
+            for (unsigned g = 0; g < ST_PER_LANE / 4; ++g) {
+                const uint4 va = *(const uint4 *)(vals + e0 + 4 * g);
+                vw[4 * g] = va.x; vw[4 * g + 1] = va.y; vw[4 * g + 2] = va.z; vw[4 * g + 3] = va.w;
+            }
 #pragma unroll
             for (unsigned q = 0; q < ST_PER_LANE; ++q) {
                 const uint32_t e = e0 + q;
@@ -936,7 +949,7 @@ __global__ __launch_bounds__(1024) void k_region_pass_staged(const uint16_t *key
             }
         }
         __syncthreads();
-        for (uint32_t i = t; i < cnt; i += 1024) {
+        for (uint32_t i = t; i < cnt; i += ST_THREADS) {
             const uint16_t k = st_key[i];
             const uint32_t pos = delta[k >> bin_shift] + i;
             if (MODE == RS_FINAL) {
@@ -1150,7 +1163,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     const size_t max_tasks = NB + Emax / seg + 1;
     const unsigned chunk = 1u << RS_CHUNK_LOG;
     const size_t keys_bytes = (Emax * 2 + 15) & ~(size_t)15;
-    PM_HIP(ctx, ws.digits.reserve(keys_bytes + Emax * 4 + 64));      // + 64: the staged passes read whole 8-entry groups
+    PM_HIP(ctx, ws.digits.reserve(keys_bytes + Emax * 4 + 128));     // + 128: the staged passes read whole groups of ST_PER_LANE entries
     PM_HIP(ctx, ws.region.reserve((3 * (size_t)regions + 4) * 4));
     PM_HIP(ctx, ws.cursor.reserve(((NB + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
     MsmSet &S = ws.set;
@@ -1182,7 +1195,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     const unsigned nsub = regions * SUB_BINS;
     if (lo_buckets == (1u << LO_BITS)) {
         PM_HIP(ctx, ws.sub.reserve((3 * (size_t)nsub + 4) * 4));
-        PM_HIP(ctx, ws.digits2.reserve(keys_bytes + Emax * 4 + 64));
+        PM_HIP(ctx, ws.digits2.reserve(keys_bytes + Emax * 4 + 128));
     }
 
     // ---- the sort: (scalar, window) entries -> table indices grouped by bucket, task order
@@ -1252,7 +1265,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, sub_count, sub_off, sub_cursor, nsub);
             PM_HIP(ctx, hipGetLastError());
             const unsigned stblocks = (unsigned)((E + ST_CHUNK - 1) / ST_CHUNK);
-            hipLaunchKernelGGL(k_region_pass_staged<RS_MID>, dim3(stblocks), dim3(1024), 0, st, keys, vals, region_off, regions,
+            hipLaunchKernelGGL(k_region_pass_staged<RS_MID>, dim3(stblocks), dim3(ST_THREADS), 0, st, keys, vals, region_off, regions,
                                FIN_BITS, SUB_BINS, sub_off, sub_cursor, (uint32_t *)nullptr, keys2, vals2);
             PM_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(k_hist_small, dim3(sblocks), dim3(1024), 0, st, keys2, sub_off, nsub, 0u, FIN_BINS, chunk, counts);
@@ -1261,7 +1274,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             // (round 5 measured the last level WITHOUT LDS staging -- lanes storing their 4-byte indices straight into the sub-region's
             // 120 KB output window, which stays in L2: the sort of a 2^24-pair MSM 2.66 -> 3.70 ms, a proof +2.2 ms; 64 partial-line
             // stores per wave instruction cost more than the staging saves: profiles/r05_sort_final_direct_negative.txt)
-            hipLaunchKernelGGL(k_region_pass_staged<RS_FINAL>, dim3(stblocks), dim3(1024), 0, st, keys2, vals2, sub_off, nsub, 0u,
+            hipLaunchKernelGGL(k_region_pass_staged<RS_FINAL>, dim3(stblocks), dim3(ST_THREADS), 0, st, keys2, vals2, sub_off, nsub, 0u,
                                FIN_BINS, S.bucket_off.as<uint32_t>(), cursor, S.sorted.as<uint32_t>(), (uint16_t *)nullptr,
                                (uint32_t *)nullptr);
             PM_HIP(ctx, hipGetLastError());
