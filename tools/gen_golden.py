@@ -161,7 +161,7 @@ def pk_wire_fixtures():
     cases = {e["name"]: e for e in json.load(open(os.path.join(OUT, "proofs.json")))}
     I = lambda h: int(h, 16)
     out = []
-    for name in ["dummy", "dup_column", "mimc2"]:
+    for name in ["dummy", "dup_column", "mimc2", "m0_1", "m0_12"]:      # round 5: keys whose SAP header says m0 = 1 and 12
         e = cases[name]
         rows = lambda m: [[(I(v), j) for v, j in rw] for rw in m]
         q = PR.R1CS(e["r1cs"]["m0"], e["r1cs"]["mw"], rows(e["r1cs"]["a"]), rows(e["r1cs"]["b"]), rows(e["r1cs"]["c"]))
