@@ -1183,7 +1183,10 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     uint16_t *keys = (uint16_t *)ws.digits.p;
     uint32_t *vals = (uint32_t *)((uint8_t *)ws.digits.p + keys_bytes);
     uint32_t *region_count = ws.region.as<uint32_t>(), *region_off = region_count + regions, *region_cursor = region_off + regions + 1;
-    const unsigned pbd = nwin <= 16 ? 512 : 256;                       // scalars per partition workgroup
+#ifndef PM_PARTITION_LANES
+#define PM_PARTITION_LANES 512
+#endif
+    const unsigned pbd = nwin <= 16 ? PM_PARTITION_LANES : 256;        // scalars per partition workgroup
     if (regions > pbd) return PM_ERR_INVALID_ARG;                      // one scan lane per region
     const size_t plds = 2 * 1024 * 4 + (size_t)pbd * nwin * 8;
     {
