@@ -163,6 +163,8 @@ def live_traffic(args, timeout_s=None):
             except subprocess.TimeoutExpired:
                 os.killpg(proc.pid, signal.SIGKILL)
                 proc.wait()
+                if ctr == "GRBM_GUI_ACTIVE":          # the clock pass is an extra: its failure must not cost the traffic figure
+                    continue
                 return None, "%s pass exceeded %d s and was killed" % (ctr, timeout_s)
             if rc != 0:
                 if ctr == "GRBM_GUI_ACTIVE":
