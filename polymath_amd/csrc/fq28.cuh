@@ -247,6 +247,46 @@ PM_HD Fp<typename RR::Dense> f28_to_std(const F28<RR> &a) {
     return out;
 }
 
+
+// ---- scalar-field values that have grown lazily (NTT tiles, the division scan's Horner chains): back to the canonical range.
+// tight limbs (after f28_weak_norm; the top limb keeps the excess), value < 2^(JMAX+1) p  ->  canonical (< p): conditional subtraction
+// of 2^JMAX p, ..., 2p, p (limbs of p << j by constant shifts).  JMAX <= 5: the top limb of p << j stays below 2^28 for both scalar
+// fields (255 / 254 bits on 9 limbs of 29).  After a product the value is < 2p and JMAX = 0 does; after <= 7 butterfly stages < 30p
+// and JMAX = 4.
+template <class RR, int JMAX = 5>
+PM_HD F28<RR> f28_canonical_lazy(F28<RR> x) {
+#pragma unroll
+    for (int j = JMAX; j >= 0; --j) {
+        uint32_t t[RR::N];
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < RR::N; ++i) {
+            uint32_t m = (RR::MOD[i] << j) & RR::MASK;
+            if (i > 0 && j > 0) m |= RR::MOD[i - 1] >> (RR::W - j);
+            const uint32_t v = x.l[i] - m - borrow;
+            borrow = v >> 31;
+            t[i] = v & RR::MASK;
+        }
+        if (!borrow) {
+#pragma unroll
+            for (int i = 0; i < RR::N; ++i) x.l[i] = t[i];
+        }
+    }
+    return x;
+}
+// canonical W-bit limbs -> dense 32-bit limbs
+template <class RR>
+PM_HD void f28_pack_canonical(const F28<RR> &c, uint32_t *d) {
+#pragma unroll
+    for (int w = 0; w < RR::N32; ++w) {
+        const int bit = 32 * w, i = bit / RR::W, s = bit % RR::W;
+        uint64_t v = (uint64_t)c.l[i] >> s;
+        if (i + 1 < RR::N) v |= (uint64_t)c.l[i + 1] << (RR::W - s);
+        if (i + 2 < RR::N && 2 * RR::W - s < 32) v |= (uint64_t)c.l[i + 2] << (2 * RR::W - s);
+        d[w] = (uint32_t)v;
+    }
+}
+
 // ---------------------------------------------------------------------------- XYZZ on F28
 template <class C>
 struct XYZZ28 {

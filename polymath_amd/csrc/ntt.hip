@@ -170,41 +170,11 @@ __device__ __forceinline__ void l28_store(uint32_t *t, unsigned tile, unsigned e
 #pragma unroll
     for (int l = 0; l < RR::N; ++l) t[l * tile + e] = v.l[l];
 }
-// tight limbs, value < 64 p  ->  canonical (< p): conditional subtraction of 32p, 16p, ..., p (limbs of p << j by constant shifts)
-// JMAX: the largest multiple 2^JMAX p the value can reach (round 5: the chain used to start at 32p everywhere; after a product the
-// value is < 2p and one step does, after <= 7 stages it is < 30p and the 32p step never fires)
+// canonicalisation of lazily grown tile values: fq28.cuh (f28_canonical / f28_pack_canonical; shared with the division scan since round 5)
 template <class RR, int JMAX = 5>
-__device__ __forceinline__ F28<RR> l28_canonical(F28<RR> x) {
-#pragma unroll
-    for (int j = JMAX; j >= 0; --j) {
-        uint32_t t[RR::N];
-        uint32_t borrow = 0;
-#pragma unroll
-        for (int i = 0; i < RR::N; ++i) {
-            uint32_t m = (RR::MOD[i] << j) & RR::MASK;
-            if (i > 0 && j > 0) m |= RR::MOD[i - 1] >> (RR::W - j);
-            const uint32_t v = x.l[i] - m - borrow;       // the top limb of p << j (j <= 5) stays below 2^28 for both scalar fields
-            borrow = v >> 31;
-            t[i] = v & RR::MASK;
-        }
-        if (!borrow) {
-#pragma unroll
-            for (int i = 0; i < RR::N; ++i) x.l[i] = t[i];
-        }
-    }
-    return x;
-}
+__device__ __forceinline__ F28<RR> l28_canonical(const F28<RR> &x) { return f28_canonical_lazy<RR, JMAX>(x); }
 template <class RR>
-__device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d) {   // canonical 28-bit limbs -> dense 32-bit limbs
-#pragma unroll
-    for (int w = 0; w < RR::N32; ++w) {
-        const int bit = 32 * w, i = bit / RR::W, s = bit % RR::W;
-        uint64_t v = (uint64_t)c.l[i] >> s;
-        if (i + 1 < RR::N) v |= (uint64_t)c.l[i + 1] << (RR::W - s);
-        if (i + 2 < RR::N && 2 * RR::W - s < 32) v |= (uint64_t)c.l[i + 2] << (2 * RR::W - s);
-        d[w] = (uint32_t)v;
-    }
-}
+__device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d) { f28_pack_canonical<RR>(c, d); }
 
 // the ns butterfly stages on the tile; element (r, c) sits at slot r * cols + (FIRST ? (c + r) & (cols - 1) : c).
 // Carries are propagated after every second stage only: a stage adds at most 2^(W+1) to a limb (x + yw: + 2^W; x + K4 - yw: K4's

@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "internal.h"
+#include "fq28.cuh"
 #include "prove_common.cuh"
 
 namespace pm {
@@ -252,12 +253,76 @@ __device__ __forceinline__ Fp<P> numerator_at(uint64_t k, const NumParams &np, c
     return Fp<P>::zero();
 }
 
+// Round 5: the two kernels that walk the numerator -- k_div_level0 and k_div_expand0, 0.77 of the scan's 0.89 ms -- run their Horner
+// chains in REDUCED RADIX (fq28.cuh: 9 limbs of 29 bits), as the transform tiles do: the multipliers x1, x2, 2 x2 r_a are handed over
+// in the internal Montgomery form (value 2^261 mod p), so that f28_mul(standard-form value, multiplier) is again a standard-form
+// value, sums are limb-wise, and a dense canonical element is only rebuilt where one is STORED.  The dense product mul<P> unpacks both
+// operands and shifts / reduces / packs its result every time: ~370 instructions for 162 multiplier operations against ~200.
+// Values are the same residues, the stored elements the same canonical words.
+template <class RR>
+struct NumMul28 {
+    F28<RR> x1, x2, two_x2_r0, two_x2_r1;      // internal form, canonical, tight limbs
+};
+template <class P>
+static inline NumMul28<typename Radix28<P>::RR> make_num_mul28(const Fp<P> &x1, const NumConsts<P> &nc) {
+    typedef typename Radix28<P>::RR RR;
+    Fp<P> k;
+    for (int i = 0; i < P::N; ++i) k.l[i] = RR::STD2INT[i];
+    NumMul28<RR> m;
+    m.x1 = f28_unpack<RR>(mul<P>(x1, k).l);
+    m.x2 = f28_unpack<RR>(mul<P>(nc.x2, k).l);
+    m.two_x2_r0 = f28_unpack<RR>(mul<P>(nc.two_x2_r0, k).l);
+    m.two_x2_r1 = f28_unpack<RR>(mul<P>(nc.two_x2_r1, k).l);
+    return m;
+}
+// numerator_at on reduced-radix limbs: a LAZY standard-form value, limbs < 4 * 2^29, value < 7p (u + two products + a constant)
+template <class P, class RR>
+__device__ __forceinline__ F28<RR> numerator28_at(uint64_t k, const NumParams &np, const NumConsts<P> &nc, const NumMul28<RR> &m, const Fp<P> *u,
+                                                  const Fp<P> *wit_u, const Fp<P> *u2) {
+    const uint64_t s = np.sigma, n = np.n;
+    if (k >= 8 * s) {
+        const uint64_t i = k - 8 * s;
+        return i < 2 * n - 1 ? f28_mul<RR>(f28_unpack<RR>(u2[i].l), m.x2) : f28_zero<RR>();
+    }
+    if (k >= 5 * s) {
+        const uint64_t i = k - 5 * s;
+        if (i > n) return f28_zero<RR>();
+        F28<RR> t = f28_zero<RR>();
+        if (i < n) {
+            const F28<RR> ui = f28_unpack<RR>(u[i].l);
+            t = f28_add<RR>(ui, f28_mul<RR>(ui, m.two_x2_r0));
+        }
+        if (i > 0) t = f28_add<RR>(t, f28_mul<RR>(f28_unpack<RR>(u[i - 1].l), m.two_x2_r1));
+        if (i == 0) t = f28_add<RR>(t, f28_unpack<RR>(nc.minus_const.l));
+        return t;
+    }
+    if (k >= 3 * s) {
+        const uint64_t i = k - 3 * s;
+        return i < n ? f28_mul<RR>(f28_unpack<RR>(wit_u[i].l), m.x2) : f28_zero<RR>();
+    }
+    if (k >= 2 * s) {
+        const uint64_t i = k - 2 * s;
+        return i < 3 ? f28_unpack<RR>(nc.b2[i].l) : f28_zero<RR>();
+    }
+    if (k == 0) return f28_unpack<RR>(nc.x2r0.l);
+    if (k == 1) return f28_unpack<RR>(nc.x2r1.l);
+    return f28_zero<RR>();
+}
+// one Horner step: acc (tight limbs, value < 9p) -> acc x1 + N_k: the product is < 2p, the sum < 9p; carries propagated so that the
+// next product's columns stay inside 64 bits (9 * 2^29 * 2^29 * 2 < 2^63)
+template <class P, class RR>
+__device__ __forceinline__ F28<RR> horner28_step(const F28<RR> &acc, uint64_t k, const NumParams &np, const NumConsts<P> &nc, const NumMul28<RR> &m,
+                                                 const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2) {
+    return f28_weak_norm<RR>(f28_add<RR>(f28_mul<RR>(acc, m.x1), numerator28_at<P, RR>(k, np, nc, m, u, wit_u, u2)));
+}
+
 // Synthetic division by (X - x1): H_k = N_k + x1 H_{k+1}, quotient q_{k-1} = H_k, remainder H_0.
 // Level 0: lane t owns coefficients [tL, tL+L): V_t = local Horner value (carry-in 0).
 // Then carry_t = V_t + x1^L carry_{t+1} is the same recurrence on V with multiplier x1^L: recurse.
 template <class P>
-__global__ void k_div_level0(NumParams np, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2,
-                             Fp<P> x1, unsigned L, uint64_t nchunks, Fp<P> *V) {
+__global__ void k_div_level0(NumParams np, NumConsts<P> nc, NumMul28<typename Radix28<P>::RR> m28, const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2,
+                             unsigned L, uint64_t nchunks, Fp<P> *V) {
+    typedef typename Radix28<P>::RR RR;
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
     uint64_t lo = t * L, hi = lo + L;
@@ -269,9 +334,11 @@ __global__ void k_div_level0(NumParams np, NumConsts<P> nc, const Fp<P> *u, cons
                            (lo >= 5 * s + n + 1 && hi <= 8 * s);
         if (zeros) { V[t] = Fp<P>::zero(); return; }
     }
-    Fp<P> acc = Fp<P>::zero();
-    for (uint64_t k = hi; k-- > lo;) acc = add<P>(mul<P>(acc, x1), numerator_at<P>(k, np, nc, u, wit_u, u2));
-    V[t] = acc;
+    F28<RR> acc = f28_zero<RR>();
+    for (uint64_t k = hi; k-- > lo;) acc = horner28_step<P, RR>(acc, k, np, nc, m28, u, wit_u, u2);
+    Fp<P> out;
+    f28_pack_canonical<RR>(f28_canonical_lazy<RR, 3>(acc), out.l);       // < 9p < 16p
+    V[t] = out;
 }
 
 template <class P>
@@ -316,29 +383,34 @@ __global__ void k_div_expandN(const Fp<P> *in, uint64_t count, Fp<P> xp, unsigne
 
 // Level 0 expansion writes the quotient: q_{k-1} = H_k for k >= 1; H_0 is the remainder.
 template <class P>
-__global__ void k_div_expand0(NumParams np, NumConsts<P> nc, const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2,
-                              Fp<P> x1, unsigned L, uint64_t nchunks, const Fp<P> *Hup, Fp<P> *q, unsigned *flags) {
+__global__ void k_div_expand0(NumParams np, NumConsts<P> nc, NumMul28<typename Radix28<P>::RR> m28, const Fp<P> *u, const Fp<P> *wit_u, const Fp<P> *u2,
+                              unsigned L, uint64_t nchunks, const Fp<P> *Hup, Fp<P> *q, unsigned *flags) {
+    typedef typename Radix28<P>::RR RR;
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nchunks) return;
     uint64_t lo = t * L, hi = lo + L;
     if (hi > np.len) hi = np.len;
-    Fp<P> acc = Hup[t + 1];
+    F28<RR> acc = f28_unpack<RR>(Hup[t + 1].l);
     {   // inside a zero stretch (k_div_level0) the quotient is a geometric tail: one product per coefficient, no table walk
         const uint64_t s = np.sigma, n = np.n;
         const bool zeros = (lo >= 2 && hi <= 2 * s) || (lo >= 2 * s + 3 && hi <= 3 * s) || (lo >= 3 * s + n && hi <= 5 * s) ||
                            (lo >= 5 * s + n + 1 && hi <= 8 * s);
         if (zeros) {
             for (uint64_t k = hi; k-- > lo;) {
-                acc = mul<P>(acc, x1);
-                q[k - 1] = acc;        // lo >= 2 here
+                acc = f28_mul<RR>(acc, m28.x1);                     // < 2p, tight: one conditional subtraction on the way out
+                Fp<P> out;
+                f28_pack_reduced<RR>(acc, out.l);
+                q[k - 1] = out;        // lo >= 2 here
             }
             return;
         }
     }
     for (uint64_t k = hi; k-- > lo;) {
-        acc = add<P>(mul<P>(acc, x1), numerator_at<P>(k, np, nc, u, wit_u, u2));
-        if (k > 0) q[k - 1] = acc;
-        else if (!acc.is_zero()) atomicOr(flags, 8u);  // rem != 0, prover.rs:221
+        acc = f28_canonical_lazy<RR, 3>(horner28_step<P, RR>(acc, k, np, nc, m28, u, wit_u, u2));   // the stored element: canonical
+        Fp<P> out;
+        f28_pack_canonical<RR>(acc, out.l);
+        if (k > 0) q[k - 1] = out;
+        else if (!out.is_zero()) atomicOr(flags, 8u);  // rem != 0, prover.rs:221
     }
 }
 
@@ -603,6 +675,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
     memcpy(rah, ctx->ra_host, sizeof(rah));          // phase 1 kept the host copy of r_a: no device read-back, no synchronisation here
     NumParams np{n, sigma, 8 * sigma + 2 * n - 1};
     const NumConsts<P> nc = make_num_consts<P>(x2, rah, a_at, c_at);
+    const NumMul28<typename Radix28<P>::RR> m28 = make_num_mul28<P>(x1, nc);     // the chains' multipliers in reduced radix, internal form
     // levels of the chunked recurrence
     const unsigned L = 16;   // coefficients per lane and level: 16 puts 20 K waves on the chip (32: 10 K, half of its wave slots idle): 0.98 -> 0.90 ms
     uint64_t cnt[8];
@@ -634,11 +707,11 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
             PM_HIP(ctx, ctx->lvl[0].reserve(2 * sizeof(Fr)));
             Fr *zero = ctx->lvl[0].as<Fr>();
             PM_HIP(ctx, hipMemsetAsync(zero, 0, 2 * sizeof(Fr), st));
-            hipLaunchKernelGGL(k_div_expand0<P>, dim3(1), dim3(64), 0, st, np, nc, u, wit_u, u2, x1, (unsigned)np.len, (uint64_t)1,
+            hipLaunchKernelGGL(k_div_expand0<P>, dim3(1), dim3(64), 0, st, np, nc, m28, u, wit_u, u2, (unsigned)np.len, (uint64_t)1,
                                zero, q, flags);
             PM_HIP(ctx, hipGetLastError());
         } else {
-            hipLaunchKernelGGL(k_div_level0<P>, dim3(nblk(cnt[1])), dim3(256), 0, st, np, nc, u, wit_u, u2, x1, L, cnt[1], V[1]);
+            hipLaunchKernelGGL(k_div_level0<P>, dim3(nblk(cnt[1])), dim3(256), 0, st, np, nc, m28, u, wit_u, u2, L, cnt[1], V[1]);
             PM_HIP(ctx, hipGetLastError());
             for (int l = 1; l < levels; ++l) {
                 hipLaunchKernelGGL(k_div_levelN<P>, dim3(nblk(cnt[l + 1])), dim3(256), 0, st, V[l], cnt[l], xp[l], L,
@@ -652,7 +725,7 @@ int prove_phase3_impl(pm_ctx *ctx, const uint64_t *x1_in, const uint64_t *x2_in,
                                    cnt[l + 1], H[l + 1], H[l]);
                 PM_HIP(ctx, hipGetLastError());
             }
-            hipLaunchKernelGGL(k_div_expand0<P>, dim3(nblk(cnt[1])), dim3(256), 0, st, np, nc, u, wit_u, u2, x1, L, cnt[1],
+            hipLaunchKernelGGL(k_div_expand0<P>, dim3(nblk(cnt[1])), dim3(256), 0, st, np, nc, m28, u, wit_u, u2, L, cnt[1],
                                H[1], q, flags);
             PM_HIP(ctx, hipGetLastError());
         }
