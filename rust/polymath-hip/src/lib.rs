@@ -325,13 +325,17 @@ impl Context {
 
     /// Phase 1 (prover.rs:75-123): witness map, inverse transforms, u^2, h, then `[a]_1` and `[c]_1`.
     /// `instance` INCLUDES the leading one (prover.rs:56); `r_a` = the two `F::rand` draws of prover.rs:110, constant term first.
-    pub fn prove_phase1<E: Pairing>(
-        &mut self,
-        key: &GpuKey,
+    ///
+    /// The C context keeps a pointer to the key between the phases (`pm_prove_phase3` reads the key's bases), so the phases
+    /// that follow live on the returned [`ProofInFlight`], which borrows BOTH the context and the key: safe code cannot drop
+    /// the key, start another proof on the context, or free the context while a proof is between its phases.
+    pub fn prove_phase1<'c, 'k, E: Pairing>(
+        &'c mut self,
+        key: &'k GpuKey,
         instance: &[E::ScalarField],
         witness: &[E::ScalarField],
         r_a: &[E::ScalarField; 2],
-    ) -> Result<(E::G1Affine, E::G1Affine), HipError> {
+    ) -> Result<(ProofInFlight<'c, 'k>, E::G1Affine, E::G1Affine), HipError> {
         let curve = curve_checked::<E>()?;
         if curve != key.curve || instance.len() as u64 != key.m0 || witness.len() as u64 != key.mw {
             return Err(err(Status::InvalidArg, "assignment does not fit the key"));
@@ -344,35 +348,8 @@ impl Context {
             sys::pm_prove_phase1(self.raw, key.raw, fr_ptr(instance), fr_ptr(witness), fr_ptr(&r_a[..]), a.as_mut_ptr(), &mut a_inf, c.as_mut_ptr(), &mut c_inf)
         };
         self.check(rc)?;
-        Ok((g1_from_raw::<E>(curve, &a, a_inf), g1_from_raw::<E>(curve, &c, c_inf)))
-    }
-
-    /// Phase 2 (prover.rs:132): `u_poly.evaluate(&x1)`; the caller adds `r_a(x1) * y1^alpha`.
-    pub fn prove_phase2<E: Pairing>(&mut self, x1: &E::ScalarField) -> Result<E::ScalarField, HipError> {
-        let curve = curve_checked::<E>()?;
-        let mut out = [0u64; 4];
-        // SAFETY: one field element in, one out.
-        let rc = unsafe { sys::pm_prove_phase2(self.raw, fr_ptr(core::slice::from_ref(x1)), out.as_mut_ptr()) };
-        self.check(rc)?;
-        Ok(fr_from_raw::<E>(curve, out))
-    }
-
-    /// Phase 3 (prover.rs:142-229): the Y^-gamma-scaled numerator, its division by (X - x1), `[d]_1`.
-    pub fn prove_phase3<E: Pairing>(
-        &mut self,
-        x1: &E::ScalarField,
-        x2: &E::ScalarField,
-        a_at_x1: &E::ScalarField,
-        c_at_x1: &E::ScalarField,
-    ) -> Result<E::G1Affine, HipError> {
-        let curve = curve_checked::<E>()?;
-        let mut d = [0u64; 12];
-        let mut d_inf = 0i32;
-        let one = |v: &E::ScalarField| fr_ptr(core::slice::from_ref(v));
-        // SAFETY: four field elements in, 2 * fq_limbs <= 12 words out.
-        let rc = unsafe { sys::pm_prove_phase3(self.raw, one(x1), one(x2), one(a_at_x1), one(c_at_x1), d.as_mut_ptr(), &mut d_inf) };
-        self.check(rc)?;
-        Ok(g1_from_raw::<E>(curve, &d, d_inf))
+        let (a_g1, c_g1) = (g1_from_raw::<E>(curve, &a, a_inf), g1_from_raw::<E>(curve, &c, c_inf));
+        Ok((ProofInFlight { ctx: self, _key: key, curve }, a_g1, c_g1))
     }
 
     /// `E::G1::msm_unchecked(bases, scalars)` (prover.rs:380-384) on host slices, zipped to the shorter length like arkworks.
@@ -408,6 +385,48 @@ impl Drop for Context {
     }
 }
 
+/// A proof between its phases: phase 1 has run on `ctx` against `key`; phases 2 and 3 are methods of this guard and nothing
+/// else can touch the context or drop the key until it is gone (the library's `pm_ctx` holds a raw pointer to the `pm_pk`).
+pub struct ProofInFlight<'c, 'k> {
+    ctx: &'c mut Context,
+    _key: &'k GpuKey,
+    curve: Curve,
+}
+
+impl ProofInFlight<'_, '_> {
+    /// Phase 2 (prover.rs:132): `u_poly.evaluate(&x1)`; the caller adds `r_a(x1) * y1^alpha`.
+    pub fn prove_phase2<E: Pairing>(&mut self, x1: &E::ScalarField) -> Result<E::ScalarField, HipError> {
+        if curve_checked::<E>()? != self.curve {
+            return Err(err(Status::InvalidArg, "phase 2 called with another pairing engine than phase 1"));
+        }
+        let mut out = [0u64; 4];
+        // SAFETY: one field element in, one out; the key of phase 1 is still alive (borrowed by `self`).
+        let rc = unsafe { sys::pm_prove_phase2(self.ctx.raw, fr_ptr(core::slice::from_ref(x1)), out.as_mut_ptr()) };
+        self.ctx.check(rc)?;
+        Ok(fr_from_raw::<E>(self.curve, out))
+    }
+
+    /// Phase 3 (prover.rs:142-229): the Y^-gamma-scaled numerator, its division by (X - x1), `[d]_1`.  Consumes the guard.
+    pub fn prove_phase3<E: Pairing>(
+        self,
+        x1: &E::ScalarField,
+        x2: &E::ScalarField,
+        a_at_x1: &E::ScalarField,
+        c_at_x1: &E::ScalarField,
+    ) -> Result<E::G1Affine, HipError> {
+        if curve_checked::<E>()? != self.curve {
+            return Err(err(Status::InvalidArg, "phase 3 called with another pairing engine than phase 1"));
+        }
+        let mut d = [0u64; 12];
+        let mut d_inf = 0i32;
+        let one = |v: &E::ScalarField| fr_ptr(core::slice::from_ref(v));
+        // SAFETY: four field elements in, 2 * fq_limbs <= 12 words out; the key of phase 1 is still alive (borrowed by `self`).
+        let rc = unsafe { sys::pm_prove_phase3(self.ctx.raw, one(x1), one(x2), one(a_at_x1), one(c_at_x1), d.as_mut_ptr(), &mut d_inf) };
+        self.ctx.check(rc)?;
+        Ok(g1_from_raw::<E>(self.curve, &d, d_inf))
+    }
+}
+
 // ------------------------------------------------------------------------------------------ proving key
 /// The fields of the reference's `ProvingKey<E>` (data_structures.rs:56-73) the GPU needs, borrowed.  The wrapper cannot
 /// name that type (the reference depends on this crate, not the other way round).
@@ -427,6 +446,56 @@ pub struct KeyParts<'a, E: Pairing> {
     pub x_powers_y_gamma_z_g1: &'a [E::G1Affine],
     pub x_powers_zh_by_y_alpha_g1: &'a [E::G1Affine],
     pub uj_wj_lcs_by_y_alpha_g1: &'a [E::G1Affine],
+}
+
+/// `pm_base_vec` (include/polymath_hip.h): the six base vectors of `ProvingKey<E>` (data_structures.rs:56-73), in the order
+/// of `pm_pk_load`'s array and of `pm_pk_info`'s lengths.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+#[repr(i32)]
+pub enum BaseVec {
+    XPowers = 0,
+    XPowersYAlpha = 1,
+    XPowersYGamma = 2,
+    XPowersYGammaZ = 3,
+    XPowersZhByYAlpha = 4,
+    UjWjLcsByYAlpha = 5,
+}
+
+impl BaseVec {
+    pub const ALL: [BaseVec; 6] =
+        [BaseVec::XPowers, BaseVec::XPowersYAlpha, BaseVec::XPowersYGamma, BaseVec::XPowersYGammaZ, BaseVec::XPowersZhByYAlpha, BaseVec::UjWjLcsByYAlpha];
+}
+
+/// What `generate_proving_key` has in hand after synthesis (generator.rs:46-54): the R1CS matrices of `cs.to_matrices()`
+/// and their shape.  `m0` counts the leading one (`num_instance_variables`).
+pub struct R1csParts<'a, E: Pairing> {
+    pub m0: u64,
+    pub mw: u64,
+    pub nr: u64,
+    pub a: &'a [Vec<(E::ScalarField, usize)>],
+    pub b: &'a [Vec<(E::ScalarField, usize)>],
+    pub c: &'a [Vec<(E::ScalarField, usize)>],
+}
+
+/// `pm_pk_info`: the scalars of the verifying key (data_structures.rs:38-52) a resident key was made for, and the lengths of
+/// its six base vectors ([`BaseVec`] order).
+pub struct KeyInfo<E: Pairing> {
+    pub n: u64,
+    pub m0: u64,
+    pub sigma: u64,
+    /// `domain.group_gen()` (generator.rs:156)
+    pub omega: E::ScalarField,
+    pub base_lens: [u64; 6],
+}
+
+/// The six `Vec<E::G1Affine>` of `ProvingKey<E>` (data_structures.rs:60-72), copied back from the device.
+pub struct ExportedBases<E: Pairing> {
+    pub x_powers_g1: Vec<E::G1Affine>,
+    pub x_powers_y_alpha_g1: Vec<E::G1Affine>,
+    pub x_powers_y_gamma_g1: Vec<E::G1Affine>,
+    pub x_powers_y_gamma_z_g1: Vec<E::G1Affine>,
+    pub x_powers_zh_by_y_alpha_g1: Vec<E::G1Affine>,
+    pub uj_wj_lcs_by_y_alpha_g1: Vec<E::G1Affine>,
 }
 
 struct Csr<F> {
@@ -520,6 +589,84 @@ impl GpuKey {
         Ok(GpuKey { raw, curve, m0: k.m0, mw: k.mw })
     }
 
+    /// `pm_pk_generate` == `generate_proving_key` (generator.rs:24-167) from the point where it holds the matrices and the two
+    /// trapdoor draws: `x` then `z`, both `domain.sample_element_outside_domain(rng)` (generator.rs:72,77) -- the RNG stays with
+    /// the caller.  The dense, serial `uj_wj_lcs` loop (generator.rs:112-136: n * (m - m0) calls of `SAPMatrices::u / w`) is
+    /// replaced by an O(nnz) pass and the ~14 n scalar multiplications of `Self::generate` (generator.rs:169-177) by a
+    /// fixed-base batch on the device; the base vectors are born resident, so the first `prove` uploads nothing.
+    /// The library derives `n` and `sigma = n + 3` itself (`SAPMatrices::size`, common.rs:130-134); read them with [`GpuKey::info`].
+    pub fn generate<E: Pairing>(ctx: &mut Context, r1cs: &R1csParts<'_, E>, x: &E::ScalarField, z: &E::ScalarField) -> Result<GpuKey, HipError> {
+        let curve = curve_checked::<E>()?;
+        if r1cs.a.len() as u64 != r1cs.nr || r1cs.b.len() as u64 != r1cs.nr || r1cs.c.len() as u64 != r1cs.nr {
+            return Err(err(Status::InvalidArg, "matrices do not have num_constraints rows"));
+        }
+        let (a, b, c) = (flatten(r1cs.a)?, flatten(r1cs.b)?, flatten(r1cs.c)?);
+        let one = |v: &E::ScalarField| fr_ptr(core::slice::from_ref(v));
+        let mut raw = core::ptr::null_mut();
+        // SAFETY: the CSR vectors outlive the call; `x` and `z` are one field element (4 limbs, layout checked) each.
+        let rc = unsafe { sys::pm_pk_generate(ctx.raw, curve.id(), r1cs.m0, r1cs.mw, r1cs.nr, &a.raw(), &b.raw(), &c.raw(), one(x), one(z), 0, 1, &mut raw) };
+        ctx.check(rc)?;
+        Ok(GpuKey { raw, curve, m0: r1cs.m0, mw: r1cs.mw })
+    }
+
+    /// `pm_pk_info`: n, m0, sigma, omega and the six base-vector lengths of this key.
+    pub fn info<E: Pairing>(&self) -> Result<KeyInfo<E>, HipError> {
+        let curve = curve_checked::<E>()?;
+        if curve != self.curve {
+            return Err(err(Status::InvalidArg, "key of another curve"));
+        }
+        let (mut n, mut m0, mut sigma) = (0u64, 0u64, 0u64);
+        let mut omega = [0u64; 4];
+        let mut base_lens = [0u64; 6];
+        // SAFETY: live key; five valid out-pointers (4 limbs for omega, PM_NUM_BASE_VECS = 6 lengths).
+        let rc = unsafe { sys::pm_pk_info(self.raw, &mut n, &mut m0, &mut sigma, omega.as_mut_ptr(), base_lens.as_mut_ptr()) };
+        if rc != sys::PM_OK {
+            return Err(err(Status::from_raw(rc), "pm_pk_info failed"));
+        }
+        Ok(KeyInfo { n, m0, sigma, omega: fr_from_raw::<E>(curve, omega), base_lens })
+    }
+
+    /// `pm_pk_export_bases`: one base vector back on the host as `Vec<E::G1Affine>`, ready for a `ProvingKey<E>` field.  The
+    /// device hands over `x || y` in Montgomery form (16 * fq_limbs bytes per point, the identity as all-zero x, y); records are
+    /// rebuilt with `Affine::new_unchecked` / `Affine::identity()` -- no decompression, no subgroup check (the points were
+    /// computed as multiples of the generator).  Copied in chunks of 2^18 points so the staging buffer stays small.
+    pub fn export_bases<E: Pairing>(&self, ctx: &mut Context, which: BaseVec) -> Result<Vec<E::G1Affine>, HipError> {
+        let info = self.info::<E>()?;
+        let curve = self.curve;
+        let words = 2 * curve.fq_limbs();
+        let total = info.base_lens[which as usize] as usize;
+        let mut out = Vec::with_capacity(total);
+        const CHUNK: usize = 1 << 18;
+        let mut staging = vec![0u64; words * CHUNK.min(total.max(1))];
+        let mut offset = 0usize;
+        while offset < total {
+            let len = CHUNK.min(total - offset);
+            // SAFETY: live key and context; `staging` has room for `len` points of `words` u64 each.
+            let rc = unsafe { sys::pm_pk_export_bases(ctx.raw, self.raw, which as i32, offset, len, staging.as_mut_ptr()) };
+            ctx.check(rc)?;
+            for p in staging[..words * len].chunks_exact(words) {
+                let mut xy = [0u64; 12];
+                xy[..words].copy_from_slice(p);
+                let inf = p.iter().all(|&w| w == 0) as i32;
+                out.push(g1_from_raw::<E>(curve, &xy, inf));
+            }
+            offset += len;
+        }
+        Ok(out)
+    }
+
+    /// All six vectors, in the shape of `ProvingKey<E>`'s fields.
+    pub fn export_all<E: Pairing>(&self, ctx: &mut Context) -> Result<ExportedBases<E>, HipError> {
+        Ok(ExportedBases {
+            x_powers_g1: self.export_bases::<E>(ctx, BaseVec::XPowers)?,
+            x_powers_y_alpha_g1: self.export_bases::<E>(ctx, BaseVec::XPowersYAlpha)?,
+            x_powers_y_gamma_g1: self.export_bases::<E>(ctx, BaseVec::XPowersYGamma)?,
+            x_powers_y_gamma_z_g1: self.export_bases::<E>(ctx, BaseVec::XPowersYGammaZ)?,
+            x_powers_zh_by_y_alpha_g1: self.export_bases::<E>(ctx, BaseVec::XPowersZhByYAlpha)?,
+            uj_wj_lcs_by_y_alpha_g1: self.export_bases::<E>(ctx, BaseVec::UjWjLcsByYAlpha)?,
+        })
+    }
+
     pub fn raw(&self) -> *const sys::pm_pk {
         self.raw
     }
@@ -535,7 +682,7 @@ pub enum ShardLayout {
 
 impl Drop for GpuKey {
     fn drop(&mut self) {
-        // SAFETY: created by pm_pk_load, freed once.
+        // SAFETY: created by pm_pk_load / pm_pk_generate, freed once.
         unsafe { sys::pm_pk_free(self.raw) }
     }
 }
@@ -554,6 +701,13 @@ impl GpuKeyCache {
         }
         let k = Arc::new(upload()?); // outside the lock: an upload takes seconds (window tables are built on the device)
         Ok(self.map.lock().expect("key cache poisoned").entry(id).or_insert(k).clone())
+    }
+
+    /// Register a key that is ALREADY resident (made by [`GpuKey::generate`]) under `id`, so the first proof with the
+    /// `ProvingKey<E>` built from its exported vectors neither re-uploads ~3 GB of bases nor rebuilds the window tables.
+    /// An entry already present under `id` wins (and `key` is freed).
+    pub fn adopt(&self, id: [u8; 32], key: GpuKey) -> Arc<GpuKey> {
+        self.map.lock().expect("key cache poisoned").entry(id).or_insert_with(|| Arc::new(key)).clone()
     }
 
     pub fn forget(&self, id: &[u8; 32]) {

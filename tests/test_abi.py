@@ -136,8 +136,64 @@ def test_rust_wrapper_and_reference_patch_are_consistent():
     exported = set(re.findall(r"pub (?:fn|struct|enum) ([A-Za-z_][A-Za-z0-9_]*)", wrapper))
     used = set(re.findall(r"polymath_hip::\{([^}]*)\}", added)[0].replace(" ", "").split(",")) | set(re.findall(r"polymath_hip::([a-z_]+)", added))
     assert used <= exported, used - exported
-    for fn in ("prove_phase1", "prove_phase2", "prove_phase3", "get_or_upload", "with_thread_local"):
+    for fn in ("prove_phase1", "prove_phase2", "prove_phase3", "get_or_upload", "with_thread_local", "generate", "info", "export_all", "adopt"):
         assert "pub fn " + fn in wrapper and fn in added
+
+
+REFERENCE = "/root/reference"
+
+
+def _patch_files(patch):
+    return re.findall(r"^diff --git a/(\S+) b/", patch, flags=re.M)
+
+
+def test_every_snark_method_of_the_reference_has_a_route_in_the_patch():
+    """`Polymath<E, T>: SNARK<F>` (src/lib.rs:63-90) has three O(n) or larger entry points.  The reference-side binding must
+    cover each: circuit_specific_setup -> generate_proving_key (generator.rs:24) through pm_pk_generate + pm_pk_export_bases
+    (the dense CPU loop cannot finish at any BASELINE size), prove -> create_proof_with_assignment (prover.rs:66) through the
+    three phases, verify -> stays on the CPU (O(m0) + one pairing product), said so in hip.rs.  The wrapper binds every C
+    entry point those routes need, and the phases are tied to the key's lifetime (no use-after-free in safe code)."""
+    wrapper = open(os.path.join(ROOT, "rust", "polymath-hip", "src", "lib.rs")).read()
+    called = set(re.findall(r"sys::(pm_[a-z0-9_]+)\s*\(", wrapper))
+    for needed in ("pm_pk_generate", "pm_pk_export_bases", "pm_pk_info", "pm_pk_load", "pm_prove_phase1", "pm_prove_phase2", "pm_prove_phase3"):
+        assert needed in called, needed
+    patch = open(os.path.join(ROOT, "rust", "reference-patch", "sigma0-polymath-hip.patch")).read()
+    files = _patch_files(patch)
+    assert {"src/generator.rs", "src/prover.rs", "src/hip.rs", "src/lib.rs", "Cargo.toml"} == set(files), files
+    added = "\n".join(l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
+    assert "unsafe" not in added.replace("forbid(unsafe_code)", "")
+    # the generator hook: behind the feature, AFTER both trapdoor draws (same rng stream as the CPU path), G2 on the CPU
+    gen = patch[patch.index("diff --git a/src/generator.rs"):patch.index("diff --git a/src/hip.rs")]
+    gen_added = [l[1:] for l in gen.splitlines() if l.startswith("+") and not l.startswith("+++")]
+    assert any('#[cfg(feature = "hip")]' in l for l in gen_added)
+    assert any("generate_bases_hip" in l for l in gen_added) and any("adopt_resident_key_hip" in l for l in gen_added)
+    ctx_before = gen[:gen.index("generate_bases_hip")]
+    assert "let z: F = domain.sample_element_outside_domain(rng);" in ctx_before       # hooked after generator.rs:77
+    assert any("x_g2: (g2 * &x).into()" in l for l in gen_added) and any("z_g2: (g2 * &z).into()" in l for l in gen_added)
+    assert "GpuKey::generate::<E>" in added and "export_all::<E>" in added and "global_key_cache().adopt" in added
+    assert "src/verifier.rs:19" in added and "stays on the CPU" in added
+    # ADVICE r5: phases 2 and 3 only exist on the guard that borrows the key
+    guard = wrapper[wrapper.index("pub struct ProofInFlight<'c, 'k>"):]
+    guard = guard[:guard.index("\n// ----")]
+    assert "ctx: &'c mut Context" in guard and "_key: &'k GpuKey" in guard
+    assert "pub fn prove_phase2" in guard and "pub fn prove_phase3" in guard
+    ctx_impl = wrapper[wrapper.index("impl Context {"):wrapper.index("pub struct ProofInFlight")]
+    assert "pub fn prove_phase2" not in ctx_impl and "pub fn prove_phase3" not in ctx_impl
+    assert "in_flight.prove_phase2" in added and "in_flight.prove_phase3" in added
+
+
+def test_reference_patch_applies_to_the_reference(tmp_path):
+    """With the reference checkout present (this container; never on the GPU box): `patch -p1 --dry-run` of the committed
+    patch against an untouched copy succeeds with no fuzz and no rejects."""
+    import shutil
+    import subprocess
+    if not os.path.isdir(REFERENCE) or not shutil.which("patch"):
+        pytest.skip("no reference checkout / no patch(1) here")
+    work = tmp_path / "ref"
+    shutil.copytree(REFERENCE, work, ignore=shutil.ignore_patterns(".git", "target"))
+    run = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(ROOT, "rust", "reference-patch", "sigma0-polymath-hip.patch")],
+                         cwd=work, capture_output=True, text=True)
+    assert run.returncode == 0 and "fuzz" not in run.stdout and "FAILED" not in run.stdout, run.stdout + run.stderr
 
 
 def test_integration_md_quotes_the_rust_sources():

@@ -328,6 +328,53 @@ def test_pk_load_path_equals_generate(gpu_ctx, oracle, api):
     assert po == pg
 
 
+@pytest.mark.parametrize("curve", CURVE_LIST)
+def test_setup_hook_sequence_generate_export_reload_proves_same_bytes(api, curve):
+    """The sequence of the reference-side setup hook (rust/reference-patch: generator.rs:79 -> hip.rs: generate_bases_hip),
+    through the same C ABI calls, at 2^16 - 100 gates: pm_pk_generate from the two trapdoor draws, pm_pk_info, the six
+    vectors copied out in chunks with pm_pk_export_bases (GpuKey::export_bases: 2^18 points per call), rebuilt as arkworks'
+    G1Affine records (104 / 72 bytes: x, y, `infinity: bool` -- the identity arrives as all-zero x, y), then a `prove` with
+    (a) the key left resident by setup (GpuKeyCache::adopt) and (b) a second key made by pm_pk_load from the exported
+    records (what a deserialised ProvingKey<E> goes through): the three transcripts' proof bytes must be identical."""
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import Polymath
+    c = CURVES[curve]
+    nq = 6 if curve == "bls12_381" else 4
+    nr = (1 << 16) - 100
+    lc = PC.synthetic_r1cs_native(curve, nr)
+    g = CI.SplitMix64(616)
+    x, z, r_a = g.fr(c.r), g.fr(c.r), [g.fr(c.r), g.fr(c.r)]
+    ctx_setup, ctx_prove = api.Context(0), api.Context(0)       # setup and prove may run on different threads' contexts
+    pm = Polymath(curve, "merlin", ctx=ctx_setup)
+    resident = pm.setup(lc, x, z)
+    assert resident.n == 1 << 17 and resident.sigma == resident.n + 3 and resident.m0 == lc.m0
+    lens = resident.base_lens
+    n = resident.n
+    # generator.rs:81-110 (max_index + 1 each); uj_wj_lcs: columns m0 .. 2 m0 + (m0 + mw) + nr of the SAP matrices (common.rs:130-134)
+    assert list(lens) == [n + 1, 3, 2, 2 * (n - 1) + 8 * (n + 3) + 1, n - 1, 2 * lc.m0 + lc.mw + lc.nr]
+    records = []
+    for which in range(6):
+        total, stride_words = int(lens[which]), 2 * nq + 1
+        rec = np.zeros((total, stride_words), dtype=np.uint64)
+        for off in range(0, total, 1 << 18):
+            ln = min(1 << 18, total - off)
+            xy = resident.export_bases(which, off, ln)
+            rec[off:off + ln, :2 * nq] = xy
+            rec[off:off + ln, 2 * nq] = (~xy.any(axis=1)).astype(np.uint64)      # Affine::identity(): infinity = true
+        assert rec.strides[0] == (104 if curve == "bls12_381" else 72)
+        records.append(rec)
+    A, B, C = lc.csrs
+    reloaded = api.ProvingKey.load(ctx_prove, curve, resident.n, lc.m0, lc.mw, lc.nr, resident.sigma, A, B, C, records)
+    for tname in ("merlin", "keccak256", "blake3"):
+        p_res = Polymath(curve, tname, ctx=ctx_prove).prove_native(resident.view(ctx_prove), lc.inst_limbs, lc.wit_limbs, r_a)
+        p_rel = Polymath(curve, tname, ctx=ctx_prove).prove_native(reloaded, lc.inst_limbs, lc.wit_limbs, r_a)
+        assert p_res == p_rel and len(p_res) == (176 if curve == "bls12_381" else 128)
+    reloaded.free()
+    resident.free()
+    ctx_prove.close()
+    ctx_setup.close()
+
+
 def test_sharded_pk_partials_sum_to_whole(gpu_ctx, oracle, api):
     """MSM pairs sharded over ranks; partial points summed with pm_g1_sum equal the
     unsharded commitments (two shards emulated on one GPU)."""
