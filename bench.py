@@ -152,7 +152,7 @@ def live_traffic(args, timeout_s=None):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):
         d = tempfile.mkdtemp(prefix="pm_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "run", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--msm-micro", "", "--ntt-micro", "", "--no-live-traffic",
+               os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--msm-micro", "", "--ntt-micro", "", "--no-live-traffic", "--inflight", "0", "--other-configs", "",
                "--log-constraints", str(args.log_constraints), "--curve", args.curve, "--transcript", args.transcript, "--opt", "msm_overlap=0"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
@@ -305,6 +305,59 @@ def stage_report(curve, r1cs, pk, tm1, tm3, plans):
     }
 
 
+def other_config(ctx, curve, log_nr, transcript, proofs=3):
+    """One more BASELINE.json configuration on this GPU, after the headline: `proofs` whole proofs through
+    pm_host_prove from pinned host buffers (the headline's entry point and clock), one msm_overlap = 0 proof for the stage
+    block, Polymath::verify on the bytes.  Reported under `other_configs`; never part of `value`."""
+    import numpy as np
+    import torch
+    from polymath_amd import circuits as PC
+    from polymath_amd.polymath import FIELDS, Polymath
+    r = FIELDS[curve]["r"]
+    nr = (1 << log_nr) - 100
+    t0 = time.time()
+    lc = PC.synthetic_r1cs_native(curve, nr)
+    t_synth = time.time() - t0
+    pm = Polymath(curve, transcript, ctx=ctx)
+    g = PC.SplitMix64(0xBE7C4 + log_nr)
+    x_trap, z_trap, r_a = g.fr(r), g.fr(r), [g.fr(r), g.fr(r)]
+    t0 = time.time()
+    pk = pm.setup(lc, x_trap, z_trap)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t0
+    x_pin = torch.from_numpy(np.ascontiguousarray(lc.inst_limbs).view("int64")).pin_memory()
+    w_pin = torch.from_numpy(np.ascontiguousarray(lc.wit_limbs).view("int64")).pin_memory()
+    x_l, w_l = x_pin.numpy().view("uint64"), w_pin.numpy().view("uint64")
+    proof = pm.prove_native(pk, x_l, w_l, r_a)                       # warm-up: workspaces, twiddles
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(proofs):
+        again = pm.prove_native(pk, x_l, w_l, r_a)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / proofs * 1e3
+    overlap_was = ctx.get_option("msm_overlap")
+    ctx.set_option("msm_overlap", 0)
+    pm.collect_timings = True
+    serial = pm.prove_limbs(pk, lc.instance, x_l, w_l, r_a).to_bytes()
+    pm.collect_timings = False
+    ctx.set_option("msm_overlap", overlap_was)
+    plans = [pk.msm_plan(k) for k in range(3)]
+    n = pk.n
+    pairs = (n + 3) + (2 * lc.m0 + lc.mw + nr + (n - 1) + (n + 1) + 5) + 10 * n + 22
+    out = {"workload": "2^%d-100-constraint synthetic R1CS (random A*B=C gates), %s, n=2^%d, transcript=%s, one GPU" % (log_nr, curve, n.bit_length() - 1, transcript),
+           "proofs": proofs, "ms_per_proof": ms, "constraints_per_sec": nr / (ms * 1e-3), "msm_pairs_per_sec": pairs / (ms * 1e-3),
+           "timed_entry_point": "pm_host_prove from pinned HOST buffers (%.1f MB H2D inside every proof)" % ((x_l.nbytes + w_l.nbytes) / 1e6),
+           "proofs_identical": again == proof and serial == proof,
+           "proof_verified": bool(pm.verify(pm.make_vk(pk, x_trap, z_trap), lc.instance[1:], proof)),
+           "msm_plan": [{"msm": "acd"[k], "pairs": p[0], "windows": p[1], "window_bits": p[2], "tables": p[3]} for k, p in enumerate(plans)],
+           "stages": stage_report(curve, lc, pk, dict(pm.phase_timings[0]), dict(pm.phase_timings[2]), plans),
+           "setup_s": t_setup, "synthesis_s": t_synth, "proof_bytes": proof.hex()}
+    pk.free()
+    del x_pin, w_pin
+    torch.cuda.empty_cache()
+    return out
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -317,6 +370,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-micro", default="20,22,24,26", help="log2 lengths of the standalone resident MSM legs ('' = none)")
     ap.add_argument("--ntt-micro", default="21,22,24", help="log2 sizes of the standalone resident NTT legs ('' = none)")
+    ap.add_argument("--other-configs", default="bn254:20,bls12_381:22",
+                    help="curve:log2(constraints) legs run after the headline on the same GPU (BASELINE.json configs[4], configs[2] on one GPU; '' = none)")
     ap.add_argument("--inflight", type=int, default=2, help="proofs in flight of the serving-throughput leg beside `value` (0 = skip; single GPU only)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure `roofline.traffic`")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -641,8 +696,8 @@ def worker(args):
                     clk = LIVE_EXTRAS["effective_clock_GHz"]
                     out["valu"]["effective_clock_GHz"] = clk
                     out["valu"]["effective_clock_source"] = LIVE_EXTRAS["effective_clock_source"]
-                    out["valu"]["clock_limiter"] = ("package power tracking (PPT): amd-smi's throttle accumulators over a loop of this kernel -- PPT violation "
-                                                    "active 57 % of the samples, PROCHOT / socket / VR / HBM thermal counters at 0 (profiles/r05_clock_limiter.txt)")
+                    out["valu"]["clock_limiter_note"] = ("NOT measured by this run: see profiles/r05_clock_limiter.txt (tools/clock_limiter.py, an earlier box) for which "
+                                                         "limiter held the clock there")
             if args.inflight > 1 and native:
                 # A prover that SERVES keeps more than one proof in flight: K host threads, one context each (own stream, workspaces and
                 # proof state), the same resident key (pm_pk is immutable: include/polymath_hip.h, "Threading").  One proof's latency-bound
@@ -700,6 +755,15 @@ def worker(args):
             if args.msm_micro:
                 log(rank, "standalone resident MSM legs: 2^{%s} pairs ..." % args.msm_micro)
                 out["msm_micro"] = msm_micro(pm.ctx, curve, [int(v) for v in args.msm_micro.split(",")])
+            if args.other_configs:
+                out["other_configs"] = []
+                for spec in args.other_configs.split(","):
+                    cv, lg = spec.split(":")
+                    log(rank, "other BASELINE configuration on this GPU: %s at 2^%s - 100 gates ..." % (cv, lg))
+                    try:
+                        out["other_configs"].append(other_config(pm.ctx, cv, int(lg), args.transcript))
+                    except Exception as e:      # noqa: BLE001 -- an extra leg must not cost the run its line
+                        out["other_configs"].append({"workload": spec, "error": repr(e)})
         stage("final agreement", 120)
         line = json.dumps(out)
     if multi:

@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpolymath_hip.so")
+# POLYMATH_HIP_LIB: another BUILD of the same library (same-box A/B runs load variants from ab/ through this instead of
+# copying them over the in-tree file; tools/README.md).  Still the HIP library: there is no CPU fallback behind it.
+LIB_PATH = os.environ.get("POLYMATH_HIP_LIB") or os.path.join(HERE, "libpolymath_hip.so")
 
 PM_BLS12_381, PM_BN254 = 0, 1
 CURVE_IDS = {"bls12_381": PM_BLS12_381, "bn254": PM_BN254}

@@ -496,8 +496,9 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         Fr *tmp = ctx->ntt_tmp.as<Fr>();
         typedef typename C::FrNttRR RR;
         const Tw28<RR> *tw28 = twb.as<Tw28<RR>>();
-        // workgroup shape (round 5): TH = 256 lanes on 2^10-element tiles where every pass still reads segments of >= 8 elements
-        // (256 B), TH = 512 on 2^11-element tiles otherwise (9-stage passes, domains above 2^24)
+        // workgroup shape (round 5): TH = 256 lanes on 2^10-element tiles where no pass has more than 8 stages -- an 8-stage pass
+        // reads segments of 2^(10 - 8) = 4 elements (128 B), shorter passes longer ones; TH = 512 on 2^11-element tiles otherwise
+        // (9-stage passes, domains above 2^24), where the small tile's segments would shrink to 64 B
         const unsigned p8 = (log_n + 7) / 8, p9 = (log_n + 8) / 9, npass = p9 < p8 ? p9 : p8;
         const unsigned ns_max = log_n / npass + (log_n % npass ? 1 : 0);
         // same-box A/B (profiles/r05_ntt_workgroup_shape_ab.txt): 2^21 forward 0.289 -> 0.276 ms, 2^22 inverse 0.562 -> 0.533 ms; 9-stage

@@ -217,28 +217,30 @@ def agree_on_retry(env, rank, world, k, wait_s=90.0):
         guess = 20000 + (guess % 40000)
     port_file = os.path.join(d, "attempt%d.port" % k)
     if rank == 0:
-        try:                                    # nothing older than this arrival may be taken for the agreement
+        try:                                    # rank 0 publishes afresh on every arrival
             os.unlink(port_file)
         except OSError:
             pass
     mine = os.path.join(d, "attempt%d.rank%d" % (k, rank))
     open(mine, "w").close()
-    t_arrival = os.stat(mine).st_mtime_ns
+    # Which incarnation of the job a port file belongs to is said IN the file (launcher pid, restart count, attempt), not guessed
+    # from its age: the supervisors notice a failed attempt seconds to minutes apart -- one child crashes at once, its peers sit
+    # out their collective deadline -- so "rank 0 published long before I arrived" is the normal case, not a stale file.
+    token = "%s:%s:%d" % (env.get("PM_LAUNCHER_PID", os.getppid()), env.get("TORCHELASTIC_RESTART_COUNT", "0"), k)
     if rank == 0:
         port = free_port()
         tmp = port_file + ".tmp"
         with open(tmp, "w") as f:
-            f.write(str(port))
+            f.write("%d %s" % (port, token))
         os.replace(tmp, port_file)
     t_end = time.time() + wait_s
     port = None
     while time.time() < t_end:
         if port is None and os.path.exists(port_file):
             try:
-                # a port file left by an earlier incarnation is older than every arrival of this one; rank 0 publishes after its
-                # own arrival, which is not before this rank's by more than the skew the 2 s allow for
-                if rank == 0 or os.stat(port_file).st_mtime_ns >= t_arrival - 2_000_000_000:
-                    port = int(open(port_file).read().strip())
+                fields = open(port_file).read().split()
+                if len(fields) == 2 and fields[1] == token:
+                    port = int(fields[0])
             except (ValueError, OSError):
                 port = None
         if port is not None and all(os.path.exists(os.path.join(d, "attempt%d.rank%d" % (k, r))) for r in range(world)):

@@ -91,8 +91,24 @@ def test_retry_port_is_agreed_between_the_supervisors(tmp_path):
         t.join(30)
     assert got[0] == got[1] == got[2] and 1024 < got[0] < 65536
     assert time.time() - t0 >= 0.55                        # nobody left before the slowest supervisor had arrived
+    # the supervisors notice a failed attempt at very different times (one child crashes at once, the others sit out
+    # their collective deadline).  A rank that arrives 3 s after rank 0 published must still take rank 0's port.
+    env_skew = dict(env, TORCHELASTIC_RUN_ID="k%d" % os.getpid())
+    late = [None] * 2
+
+    def sup_skew(r, delay):
+        time.sleep(delay)
+        late[r] = launch.agree_on_retry(env_skew, r, 2, 1, wait_s=20.0)
+    th = [threading.Thread(target=sup_skew, args=(r, 3.0 * r)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(40)
+    assert late[0] == late[1] and 1024 < late[0] < 65536, late
+    for r in range(2):
+        launch._leave_rendezvous(env_skew, r)
     # a second incarnation under the same launcher (torchrun --max-restarts: same parent, run id and port) meets in its own
-    # directory; and inside ONE directory a port file that is older than a supervisor's arrival is not taken for the agreement
+    # directory; and inside ONE directory a port file that does not carry this incarnation's token is not taken for the agreement
     assert launch._rendezvous_dir(env) != launch._rendezvous_dir(dict(env, TORCHELASTIC_RESTART_COUNT="1"))
     env3 = dict(env, TORCHELASTIC_RUN_ID="s%d" % os.getpid())
     d3 = launch._rendezvous_dir(env3)
