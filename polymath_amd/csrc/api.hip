@@ -659,7 +659,7 @@ static int pk_fill_bases(pm_ctx *ctx, pm_pk *pk, F fill) {
             // sort / accumulate / reduce kernels on the plain base array, one bucket set per window, 13 additions per pair
             // instead of the 16 of the one-shot pipeline.  Costs one infinity-flag byte per point.  PM_TABLES_NO_WIDE disables.
             const size_t piece = (size_t)(len < pk->max_piece ? len : pk->max_piece);
-            MsmTables wt = tmode == PM_TABLES_NO_WIDE ? MsmTables() : wide_plan(piece);
+            MsmTables wt = tmode == PM_TABLES_NO_WIDE ? MsmTables() : wide_plan(piece, (unsigned)ctx->opt.v[PM_OPT_TABLE_WINDOW_BITS]);
             if (wt.c && (piece >= ((size_t)1 << 18) || force_wide) && (double)len < budget) {
                 budget -= (double)len;
                 PM_HIP(ctx, hipMalloc(&pk->d_tab_inf[k], len));

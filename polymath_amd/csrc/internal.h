@@ -347,7 +347,7 @@ inline size_t msm_max_piece(const pm_ctx *ctx) {
 void msm_plan_query(size_t len, unsigned scalar_bits, unsigned *nwin, unsigned *c);
 MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points, unsigned scalar_bits, unsigned force_c = 0);
 // the plan of an MSM that gets no tables (MsmTables::wide); c == 0 if none applies (short MSMs: the per-window pipeline)
-MsmTables wide_plan(size_t piece);
+MsmTables wide_plan(size_t piece, unsigned force_c = 0);
 // window 0 of d_table <- the `count` internal-form affine points at d_points; then windows 1..nwin-1
 template <class C>
 struct TablePoint;   // fq28.cuh: 128-byte, 28-bit-limb record

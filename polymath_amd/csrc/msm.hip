@@ -324,8 +324,27 @@ __global__ __launch_bounds__(128) void k_accumulate(const uint32_t *sorted, cons
     if (start + seg < end) end = start + seg;
     XYZZ28<C> acc;
     acc.X = acc.Y = acc.ZZ = acc.ZZZ = f28_zero<RR>();
+#ifndef PM_ACC_IDX_VEC
+#define PM_ACC_IDX_VEC 4
+#endif
+#if PM_ACC_IDX_VEC == 4
+    // The task's indices are read four at a time (one aligned 16-byte load per four additions): a lane's 4-byte load used to pull a
+    // whole line of sorted[] through L2 for one entry, and by the lane's next addition (~4 500 instructions and 3 MB of gathered
+    // points per XCD later) the line was gone again.  sorted[] carries 16 bytes of padding for the last quad.
+    uint4 quad = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t quad_at = 0xffffffffu;
+#endif
     for (uint32_t e = start; e < end; ++e) {
+#if PM_ACC_IDX_VEC == 4
+        if ((e & ~3u) != quad_at) {
+            quad_at = e & ~3u;
+            quad = *(const uint4 *)(sorted + quad_at);
+        }
+        const unsigned q = e & 3u;
+        const uint32_t v = q == 0 ? quad.x : q == 1 ? quad.y : q == 2 ? quad.z : quad.w;
+#else
         const uint32_t v = sorted[e];
+#endif
         const bool neg = (v & 1u) != 0;
         if (TABLE) {   // window tables: one aligned 128-byte record, already on 28-bit limbs
             const TablePoint<C> tp = ((const TablePoint<C> *)points)[v >> 1];
@@ -548,7 +567,7 @@ __device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned lo, unsigned c
 // workgroup's offset inside each region, so neither kernel touches a global atomic: 41 K workgroups x 64
 // regions hammering 64 addresses serialised in L2 and cost more than the rest of the kernel.
 template <class P, unsigned NWIN>
-__global__ __launch_bounds__(512) void k_tbl_count(const Fp<P> *scalars, const unsigned char *inf, size_t len, unsigned regions,
+__global__ __launch_bounds__(1024) void k_tbl_count(const Fp<P> *scalars, const unsigned char *inf, size_t len, unsigned regions,
                                                    uint32_t *block_cnt, uint32_t win_buckets) {
     __shared__ uint32_t cnt[1024];
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
@@ -666,7 +685,7 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *region_
 // stores are coalesced (consecutive lanes -> consecutive addresses of a region's run).
 //   LDS: cnt[1024] | delta[1024] | staged vals (u32 x blockDim nwin) | staged region<<16|key (u32 x same)
 template <class P, unsigned NWIN>
-__global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, const unsigned char *inf, size_t len,
+__global__ __launch_bounds__(1024) void k_tbl_partition(const Fp<P> *scalars, const unsigned char *inf, size_t len,
                                                        unsigned regions, const uint32_t *region_off, const uint32_t *block_off, size_t tbl_stride, size_t base_index, uint16_t *keys,
                                                        uint32_t *vals, uint32_t win_buckets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -689,13 +708,23 @@ __global__ __launch_bounds__(512) void k_tbl_partition(const Fp<P> *scalars, con
             if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) rank[w] = atomicAdd(&cnt[(b + w * win_buckets) >> LO_BITS], 1u);
     }
     __syncthreads();
-    {   // exclusive scan over the regions (regions <= blockDim, checked by the host): lane r owns region r
-        const uint32_t c = t < regions ? cnt[t] : 0u;
-        const uint32_t incl = block_inclusive_scan(c, wt);
-        if (t < regions) {
-            const uint32_t ex = incl - c;
-            cnt[t] = ex;                                                                  // first staged slot of the region
-            delta[t] = region_off[t] + block_off[(size_t)blockIdx.x * regions + t] - ex;  // global = delta[region] + slot
+    {   // exclusive scan over the regions: lane t owns regions [t rpl, (t + 1) rpl), rpl = 1 or 2 (regions <= 2 blockDim, checked by
+        // the host: the 768 regions of a 12-window wide plan on 512 lanes)
+        const unsigned rpl = (regions + BD - 1) / BD;
+        uint32_t c[2] = {0u, 0u};
+        for (unsigned j = 0; j < rpl; ++j) {
+            const unsigned r = t * rpl + j;
+            c[j] = r < regions ? cnt[r] : 0u;
+        }
+        const uint32_t incl = block_inclusive_scan(c[0] + c[1], wt);
+        uint32_t ex = incl - (c[0] + c[1]);
+        for (unsigned j = 0; j < rpl; ++j) {
+            const unsigned r = t * rpl + j;
+            if (r < regions) {
+                cnt[r] = ex;                                                                  // first staged slot of the region
+                delta[r] = region_off[r] + block_off[(size_t)blockIdx.x * regions + r] - ex;  // global = delta[region] + slot
+                ex += c[j];
+            }
         }
         if (t == BD - 1) tot = incl;
     }
@@ -1063,7 +1092,7 @@ static int msm_piece(pm_ctx *ctx, const Affine<C> *d_bases, const Fp<typename C:
     MsmSet &S = ws.set;
     const size_t G = (size_t)p.nwin * p.nbuckets;
     PM_HIP(ctx, ws.digits.reserve((size_t)p.nwin * len * 4));
-    PM_HIP(ctx, S.sorted.reserve((size_t)p.nwin * len * 4));
+    PM_HIP(ctx, S.sorted.reserve((size_t)p.nwin * len * 4 + 16));   // + 16: k_accumulate reads aligned quads of indices
     PM_HIP(ctx, S.counts.reserve(2 * G * 4));  // counts | cursor, one memset
     PM_HIP(ctx, S.bucket_off.reserve((G + 1) * 4));
     PM_HIP(ctx, S.task_off.reserve((G + 1) * 4));
@@ -1171,7 +1200,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     PM_HIP(ctx, ws.cursor.reserve(((NB + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
     MsmSet &S = ws.set;
     {
-        PM_HIP(ctx, S.sorted.reserve(Emax * 4));
+        PM_HIP(ctx, S.sorted.reserve(Emax * 4 + 16));      // + 16: k_accumulate reads aligned quads of indices
         PM_HIP(ctx, S.counts.reserve(2 * NB * 4));
         PM_HIP(ctx, S.bucket_off.reserve((NB + 1) * 4));
         PM_HIP(ctx, S.task_off.reserve((NB + 1) * 4));
@@ -1189,8 +1218,13 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
 #ifndef PM_PARTITION_LANES
 #define PM_PARTITION_LANES 512
 #endif
-    const unsigned pbd = nwin <= 16 ? PM_PARTITION_LANES : 256;        // scalars per partition workgroup
-    if (regions > pbd) return PM_ERR_INVALID_ARG;                      // one scan lane per region
+#ifndef PM_PARTITION_WIDE_LANES
+#define PM_PARTITION_WIDE_LANES 1024
+#endif
+    // scalars per partition workgroup.  More than 512 regions (the 768 of a 12-window wide plan): 1024, so that a workgroup's run
+    // inside a region is 16 entries (64 B of values), not 8 -- same-box A/B at 2^24 gates in profiles/r06_wide_12_windows_ab.txt
+    const unsigned pbd = regions > 512 ? PM_PARTITION_WIDE_LANES : nwin <= 16 ? PM_PARTITION_LANES : 256;
+    if (regions > 2 * pbd) return PM_ERR_INVALID_ARG;                  // at most two regions per scan lane (k_tbl_partition)
     const size_t plds = 2 * 1024 * 4 + (size_t)pbd * nwin * 8;
     {
         const unsigned pblocks_max = (unsigned)((len + pbd - 1) / pbd);

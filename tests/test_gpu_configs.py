@@ -33,8 +33,14 @@ def _accepts(curve, vk, proof, public_inputs, tname="merlin"):
 
 
 # ------------------------------------------------- whole proofs, bit-exact against the CPU restatement, at size
-@pytest.mark.parametrize("curve", CURVE_LIST)
-@pytest.mark.parametrize("log_nr,tables", [(16, "1"), (16, "0"), (16, "wide"), (18, "1"), (18, "0"), (18, "wide")])
+_ORACLE_AT_SIZE = {}       # (curve, log_nr) -> the oracle's proof, transcript trace, taps and the bases it proved on
+
+
+# grouped by (curve, size): the CPU restatement's proof is computed for the first of a group and reused by the others
+_AT_SIZE_CASES = [(cv, lg, tb) for cv in CURVE_LIST for lg, modes in ((16, ("1", "0", "wide", "wide22")), (18, ("1", "0", "wide"))) for tb in modes]
+
+
+@pytest.mark.parametrize("curve,log_nr,tables", _AT_SIZE_CASES, ids=["%d-%s-%s" % (lg, tb, cv) for cv, lg, tb in _AT_SIZE_CASES])
 def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, log_nr, tables, monkeypatch):
     """2^16-100 and 2^18-100 synthetic gates (n = 2^17 / 2^19: three-pass NTT, per-MSM window tables with 12-13 windows,
     three-level sort, two-level bucket reduction), both curves, with the key's tables, with PM_OPT_TABLES = off (the per-window
@@ -43,6 +49,12 @@ def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, lo
     The CPU restatement's key is seeded with the GPU's exported bases (their parity is tested at mid size: the CPU
     setup would take minutes here); proof, challenges and all 8 intermediate vectors must be identical."""
     import os
+    wide22 = tables == "wide22"
+    if wide22:
+        # the plan a 2^24-gate key's [c]_1 / [d]_1 get on one GPU (round 6): 12 windows of 22 / 21 bits = 768 regions of 2^15 buckets,
+        # two regions per scan lane in k_tbl_partition -- forced here at a size the CPU restatement can check bit for bit
+        tables = "wide"
+        gpu_ctx.set_option("table_window_bits", 22)
     gpu_ctx.set_option("tables", TABLES_OPT[tables])        # read by pm_pk_generate below; restored by conftest
     from polymath_amd import circuits as PC
     from polymath_amd.polymath import Polymath
@@ -58,20 +70,35 @@ def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, lo
     assert gpk.msm_plan(2)[3] == (tables == "1")
     if tables == "wide":
         assert all(12 <= gpk.msm_plan(k)[1] <= 16 and gpk.msm_plan(k)[2] >= 16 for k in range(3))     # wide_plan: big windows, no tables
+    if wide22:
+        assert all(gpk.msm_plan(k)[1:] == (12, 22, False) for k in range(3)), [gpk.msm_plan(k) for k in range(3)]
     threads = os.cpu_count() or 8
-    opk = oracle.OraclePk(curve, q, None, None, threads)
-    for i in range(6):
-        opk.import_bases(i, gpk.export_bases(i))
-    omega = oracle.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
-    assert omega == gpk.omega
     TR = T.make_transcripts(c)
-    tr_o, tr_g = {}, {}
-    po = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_o)
+    cap = 10 * gpk.n + 64
+    # The CPU restatement's run depends on the circuit, the trapdoors and r_a only -- not on how the GPU key lays its MSMs out -- so
+    # it is computed ONCE per (curve, size) and shared by the tables / off / wide parametrisations (it is most of this test's time).
+    # Every parametrisation still checks that ITS key's bases are the ones the oracle proved on.
+    exported = [gpk.export_bases(i) for i in range(6)]
+    memo = _ORACLE_AT_SIZE.get((curve, log_nr))
+    if memo is None:
+        opk = oracle.OraclePk(curve, q, None, None, threads)
+        for i in range(6):
+            opk.import_bases(i, exported[i])
+        omega = oracle.fr_from_mont_limbs(curve, opk.omega_limbs)[0]
+        tr_o = {}
+        po = DR.prove(opk, opk.n, opk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_o)
+        memo = {"omega": omega, "proof": po, "trace": tr_o, "taps": [opk.tap(which, cap) for which in range(8)],
+                "bases": [b.copy() for b in exported]}
+        _ORACLE_AT_SIZE.clear()                      # one size at a time: the taps of a 2^18-gate proof are ~200 MB
+        _ORACLE_AT_SIZE[(curve, log_nr)] = memo
+    assert all(np.array_equal(a, b) for a, b in zip(exported, memo["bases"]))
+    omega, po, tr_o = memo["omega"], memo["proof"], memo["trace"]
+    assert omega == gpk.omega
+    tr_g = {}
     pg = DR.prove(gpk, gpk.n, gpk.sigma, omega, inst, wit, r_a, TR["merlin"], tr_g)
     assert pg == po and tr_g == tr_o
-    cap = 10 * gpk.n + 64
     for which in range(8):
-        a, b = gpk.tap(which, cap), opk.tap(which, cap)
+        a, b = gpk.tap(which, cap), memo["taps"][which]
         k = min(len(a), len(b))
         assert k > 0 and np.array_equal(a[:k], b[:k]) and not a[k:].any() and not b[k:].any(), which
     # the one-call native path (C++ glue inside the library) returns the same bytes
@@ -123,11 +150,12 @@ def test_config_2p22_one_gpu():
 def test_config_2p24_one_gpu_piece_split():
     """BASELINE configs[3] circuit (2^24-100 gates, n = 2^25, 470 M MSM pairs) on ONE GPU: nine-stage NTT passes, and the
     335 M-pair quotient MSM runs in > 2^27-pair pieces (msm.hip: msm_run).  Its window tables would take 515 GB, so the key runs
-    it (and the 100 M-pair [c]_1) in the WIDE mode: 13 windows of 20 / 19 bits on the plain base array, 13 additions per
-    pair instead of the per-window pipeline's 16 (pm_pk_msm_plan shows the plan)."""
+    it (and the 100 M-pair [c]_1) in the WIDE mode: 12 windows of 22 / 21 bits on the plain base array (768 regions of 2^15
+    buckets in the sort's first level: two per scan lane, round 6), 12 additions per pair instead of the per-window
+    pipeline's 16 (pm_pk_msm_plan shows the plan)."""
     plans = _full_size_config("bls12_381", 24, 0x2424)
     assert plans[2][0] == 10 * (1 << 25) + 22 and plans[2][0] > (1 << 27)
-    assert plans[0][3] and not plans[2][3] and plans[2][1] == 13 and plans[1][1] == 13, plans     # [a]: tables; [c], [d]: wide, 13 windows
+    assert plans[0][3] and not plans[2][3] and plans[2][1] == 12 and plans[1][1] == 12, plans     # [a]: tables; [c], [d]: wide, 12 windows
 
 
 def test_config_bn254_2p20():
