@@ -274,6 +274,37 @@ PM_HD F28<RR> f28_canonical_lazy(F28<RR> x) {
     }
     return x;
 }
+// The same map with ONE quotient step instead of JMAX + 1 conditional subtractions (round 6; the transforms' passes canonicalise every
+// element once per pass, and the chain above was a quarter of a pass's instructions).  With X = the top limb, P = the top limb of p:
+//   q' = floor(X M / 2^45), M = floor(2^45 / (P + 1))   satisfies   q - 1 <= q' <= q = floor(x / p):
+//   x / p >= X / (P + 1) >= X M / 2^45 (lower limbs are tight: x < (X + 1) 2^(W (N - 1))), and
+//   x / p - X M / 2^45 < (X + P + 1) / (P (P + 1)) + X / 2^45 < 2^-15 for x < 64p (P > 2^21, X < 2^29),
+// so x - q' p lies in [0, 2p) and one conditional subtraction finishes.  q' p is formed limb by limb (q' < 64: one v_mad_u64_u32 and a
+// carry per limb) and subtracted with the borrow chain of the step above.  Same inputs, same (unique) canonical outputs.
+template <class RR, int JMAX = 5>
+PM_HD F28<RR> f28_canonical_quot(F28<RR> x) {
+    static_assert(JMAX <= 5, "value < 64p");
+    constexpr int N = RR::N;
+    constexpr uint64_t M = ((uint64_t)1 << 45) / ((uint64_t)RR::MOD[N - 1] + 1);
+    static_assert(RR::MOD[N - 1] > (1u << 21) && M < ((uint64_t)1 << 32), "quotient estimate: top limb of p too short");
+    const uint32_t q = (uint32_t)(((uint64_t)x.l[N - 1] * (uint32_t)M) >> 45);
+    uint64_t carry = 0;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const uint64_t t = (uint64_t)q * RR::MOD[i] + carry;
+        carry = t >> RR::W;
+        const uint32_t lo = i + 1 < N ? ((uint32_t)t & RR::MASK) : (uint32_t)t;
+        const uint32_t v = x.l[i] - lo - borrow;
+        if (i + 1 < N) {
+            borrow = v >> 31;
+            x.l[i] = v & RR::MASK;
+        } else {
+            x.l[i] = v;            // >= 0: q' <= q
+        }
+    }
+    return f28_canonical_lazy<RR, 0>(x);
+}
 // canonical W-bit limbs -> dense 32-bit limbs
 template <class RR>
 PM_HD void f28_pack_canonical(const F28<RR> &c, uint32_t *d) {

@@ -158,21 +158,32 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const Fp<P> *a, Fp<P> *dst, co
 constexpr unsigned L28_BPL = 2;   // butterflies per lane and stage of a full tile
 constexpr unsigned L28_EPL = 4;   // elements per lane of a full tile
 
-template <class RR>
-__device__ __forceinline__ F28<RR> l28_load(const uint32_t *t, unsigned tile, unsigned e) {
+// TILE (elements per limb plane) is a compile-time constant: the nine accesses of an element are then ONE address register plus the
+// immediate offsets l * TILE * 4 of ds_read_b32 / ds_write_b32 (round 6; with a run-time plane stride the compiler kept one address
+// VGPR per limb plane and element -- 36 live registers and as many adds in the two-stage body, at the 128-VGPR cap)
+template <class RR, unsigned TILE>
+__device__ __forceinline__ F28<RR> l28_load(const uint32_t *t, unsigned e) {
     F28<RR> r;
+    const uint32_t *q = t + e;
 #pragma unroll
-    for (int l = 0; l < RR::N; ++l) r.l[l] = t[l * tile + e];
+    for (int l = 0; l < RR::N; ++l) r.l[l] = q[l * TILE];
     return r;
 }
-template <class RR>
-__device__ __forceinline__ void l28_store(uint32_t *t, unsigned tile, unsigned e, const F28<RR> &v) {
+template <class RR, unsigned TILE>
+__device__ __forceinline__ void l28_store(uint32_t *t, unsigned e, const F28<RR> &v) {
+    uint32_t *q = t + e;
 #pragma unroll
-    for (int l = 0; l < RR::N; ++l) t[l * tile + e] = v.l[l];
+    for (int l = 0; l < RR::N; ++l) q[l * TILE] = v.l[l];
 }
 // canonicalisation of lazily grown tile values: fq28.cuh (f28_canonical / f28_pack_canonical; shared with the division scan since round 5)
+#ifndef PM_NTT_CANONICAL_QUOT
+#define PM_NTT_CANONICAL_QUOT 1
+#endif
 template <class RR, int JMAX = 5>
-__device__ __forceinline__ F28<RR> l28_canonical(const F28<RR> &x) { return f28_canonical_lazy<RR, JMAX>(x); }
+__device__ __forceinline__ F28<RR> l28_canonical(const F28<RR> &x) {
+    if (JMAX >= 2 && PM_NTT_CANONICAL_QUOT) return f28_canonical_quot<RR, JMAX>(x);      // one quotient step + one conditional subtraction
+    return f28_canonical_lazy<RR, JMAX>(x);
+}
 template <class RR>
 __device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d) { f28_pack_canonical<RR>(c, d); }
 
@@ -182,8 +193,9 @@ __device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d
 // (W = 29, N = 9: 9 * 1.5 * 2^30 * 2^29 + 9 * 2^58 < 2^63 against a tight twiddle; the n^-1 product of l28_emit sees at most
 // 2.5 * 2^30: < 2^63.8).  The stage that ends the pass leaves its carries to l28_emit.
 template <class P, class RR, bool FIRST, unsigned TH>
-__device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols,
+__device__ __forceinline__ void l28_stages(uint32_t *t, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols,
                                            size_t lo0, bool pair_stages) {
+    constexpr unsigned tile = L28_EPL * TH;      // every workgroup of every pass holds a full tile (checked by the host: ntt_run)
     const unsigned cols = 1u << log_cols, cm = cols - 1, rows = 1u << ns, nbf = (rows >> 1) * cols, tid = threadIdx.x;
     // Two stages per LDS round trip (round 3): a lane takes the four rows r0 + {0, h, 2h, 3h} of one column, runs stage st on
     // (r0, r0 + h), (r0 + 2h, r0 + 3h) and stage st + 1 on (r0, r0 + 2h), (r0 + h, r0 + 3h) in registers -- the same four products,
@@ -210,12 +222,12 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
                 for (int i = 0; i < RR::N; ++i) w.l[i] = wA.l[i];
             }
             {
-                const F28<RR> p1 = f28_mul<RR>(l28_load<RR>(t, tile, e1), w), x0 = l28_load<RR>(t, tile, e0);
+                const F28<RR> p1 = f28_mul<RR>(l28_load<RR, tile>(t, e1), w), x0 = l28_load<RR, tile>(t, e0);
                 a0 = f28_add<RR>(x0, p1);
                 a1 = f28_sub_k4<RR>(x0, p1);
             }
             {
-                const F28<RR> p3 = f28_mul<RR>(l28_load<RR>(t, tile, e3), w), x2 = l28_load<RR>(t, tile, e2);
+                const F28<RR> p3 = f28_mul<RR>(l28_load<RR, tile>(t, e3), w), x2 = l28_load<RR, tile>(t, e2);
                 a2 = f28_add<RR>(x2, p3);
                 a3 = f28_sub_k4<RR>(x2, p3);
             }
@@ -227,11 +239,11 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
             const F28<RR> q2 = f28_mul<RR>(a2, w);
             const F28<RR> b0 = f28_add<RR>(a0, q2), b2 = f28_sub_k4<RR>(a0, q2);
             if (NORM) {
-                l28_store<RR>(t, tile, e0, f28_weak_norm<RR>(b0));
-                l28_store<RR>(t, tile, e2, f28_weak_norm<RR>(b2));
+                l28_store<RR, tile>(t, e0, f28_weak_norm<RR>(b0));
+                l28_store<RR, tile>(t, e2, f28_weak_norm<RR>(b2));
             } else {
-                l28_store<RR>(t, tile, e0, b0);
-                l28_store<RR>(t, tile, e2, b2);
+                l28_store<RR, tile>(t, e0, b0);
+                l28_store<RR, tile>(t, e2, b2);
             }
             {
                 const Tw28<RR> wB1 = tw[jB1 << (log_n - sB)];
@@ -241,11 +253,11 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
             const F28<RR> q3 = f28_mul<RR>(a3, w);
             const F28<RR> b1 = f28_add<RR>(a1, q3), b3 = f28_sub_k4<RR>(a1, q3);
             if (NORM) {
-                l28_store<RR>(t, tile, e1, f28_weak_norm<RR>(b1));
-                l28_store<RR>(t, tile, e3, f28_weak_norm<RR>(b3));
+                l28_store<RR, tile>(t, e1, f28_weak_norm<RR>(b1));
+                l28_store<RR, tile>(t, e3, f28_weak_norm<RR>(b3));
             } else {
-                l28_store<RR>(t, tile, e1, b1);
-                l28_store<RR>(t, tile, e3, b3);
+                l28_store<RR, tile>(t, e1, b1);
+                l28_store<RR, tile>(t, e3, b3);
             }
         }
     };
@@ -273,18 +285,18 @@ __device__ __forceinline__ void l28_stages(uint32_t *t, unsigned tile, const Tw2
         auto stage = [&](auto norm_tag) {
             constexpr bool NORM = decltype(norm_tag)::value;
             auto bfly = [&](unsigned e0, unsigned e1, const Tw28<RR> &wd) {
-                const F28<RR> x = l28_load<RR>(t, tile, e0), y = l28_load<RR>(t, tile, e1);
+                const F28<RR> x = l28_load<RR, tile>(t, e0), y = l28_load<RR, tile>(t, e1);
                 F28<RR> w;
 #pragma unroll
                 for (int i = 0; i < RR::N; ++i) w.l[i] = wd.l[i];
                 const F28<RR> yw = f28_mul<RR>(y, w);                                    // tight, < 2p
                 const F28<RR> lo = f28_add<RR>(x, yw), hi = f28_sub_k4<RR>(x, yw);       // values < V + 2, < V + 4
                 if (NORM) {
-                    l28_store<RR>(t, tile, e0, f28_weak_norm<RR>(lo));
-                    l28_store<RR>(t, tile, e1, f28_weak_norm<RR>(hi));
+                    l28_store<RR, tile>(t, e0, f28_weak_norm<RR>(lo));
+                    l28_store<RR, tile>(t, e1, f28_weak_norm<RR>(hi));
                 } else {
-                    l28_store<RR>(t, tile, e0, lo);
-                    l28_store<RR>(t, tile, e1, hi);
+                    l28_store<RR, tile>(t, e0, lo);
+                    l28_store<RR, tile>(t, e1, hi);
                 }
             };
             if (nbf == L28_BPL * TH) {   // full tile: the twiddle loads of this lane's butterflies are issued before the arithmetic
@@ -337,7 +349,8 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                              unsigned log_cols, Fp<P> scale_int, int do_scale, int pair_stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
-    const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols;
+    constexpr unsigned tile = L28_EPL * TH;      // == rows * cols: full tiles only (ntt_run)
+    const unsigned cols = 1u << log_cols;
     const size_t lo_groups = ((size_t)1 << s0) >> log_cols, g = blockIdx.x;
     const size_t hi = g / lo_groups, lo0 = (g % lo_groups) << log_cols, base = (hi << (s0 + ns)) + lo0;
     // every load of the tile is in flight before the first one is unpacked (a 2^11-element tile is 8 per lane = 64 VGPRs):
@@ -352,15 +365,15 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
             const unsigned e = e8 + q * TH;
-            if (e < tile) l28_store<RR>(t, tile, e, f28_unpack<RR>(v[q].l));
+            if (e < tile) l28_store<RR, tile>(t, e, f28_unpack<RR>(v[q].l));
         }
     }
     __syncthreads();
-    l28_stages<P, RR, false, TH>(t, tile, tw, log_n, s0, ns, log_cols, lo0, pair_stages != 0);
+    l28_stages<P, RR, false, TH>(t, tw, log_n, s0, ns, log_cols, lo0, pair_stages != 0);
     const F28<RR> sc = f28_unpack<RR>(scale_int.l);
     for (unsigned e = threadIdx.x; e < tile; e += TH) {
         const unsigned r = e >> log_cols, c = e & (cols - 1);
-        l28_emit<P, RR>(l28_load<RR>(t, tile, e), &dst[base + ((size_t)r << s0) + c], sc, do_scale, ns <= 7);
+        l28_emit<P, RR>(l28_load<RR, tile>(t, e), &dst[base + ((size_t)r << s0) + c], sc, do_scale, ns <= 7);
     }
 }
 
@@ -375,7 +388,8 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                                    unsigned log_cols, int pair_stages) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *t = (uint32_t *)smem_raw;
-    const unsigned cols = 1u << log_cols, rows = 1u << ns, tile = rows * cols, H = log_n - ns, cm = cols - 1;
+    constexpr unsigned tile = L28_EPL * TH;      // == rows * cols: full tiles only (ntt_run)
+    const unsigned cols = 1u << log_cols, rows = 1u << ns, H = log_n - ns, cm = cols - 1;
     const size_t g = blockIdx.x;
     for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * TH) {      // loads batched as in k_ntt_pass28
         Fp<P> v[L28_EPL];
@@ -387,16 +401,16 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
             const unsigned e = e8 + q * TH, rb = e >> log_cols, c = e & cm, r = __brev(rb) >> (32 - ns);
-            if (e < tile) l28_store<RR>(t, tile, r * cols + ((c + r) & cm), f28_unpack<RR>(v[q].l));
+            if (e < tile) l28_store<RR, tile>(t, r * cols + ((c + r) & cm), f28_unpack<RR>(v[q].l));
         }
     }
     __syncthreads();
-    l28_stages<P, RR, true, TH>(t, tile, tw, log_n, 0, ns, log_cols, 0, pair_stages != 0);
+    l28_stages<P, RR, true, TH>(t, tw, log_n, 0, ns, log_cols, 0, pair_stages != 0);
     const F28<RR> none = f28_zero<RR>();
     for (unsigned e = threadIdx.x; e < tile; e += TH) {
         const unsigned c = e >> ns, r = e & (rows - 1);
         const size_t hi = __brevll((unsigned long long)((g << log_cols) + c)) >> (64 - H);
-        l28_emit<P, RR>(l28_load<RR>(t, tile, r * cols + ((c + r) & cm)), &dst[(hi << ns) + r], none, 0, ns <= 7);
+        l28_emit<P, RR>(l28_load<RR, tile>(t, r * cols + ((c + r) & cm)), &dst[(hi << ns) + r], none, 0, ns <= 7);
     }
 }
 
@@ -526,6 +540,7 @@ int ntt_run(pm_ctx *ctx, Fp<typename C::FrP> *d, unsigned log_n, bool inv_dir) {
         for (unsigned k = 0; k < npass; ++k) {
             const unsigned ns = log_n / npass + (k < log_n % npass ? 1 : 0);
             unsigned log_cols = tile_log28 - ns;
+            if (k && s0 < log_cols) return PM_ERR_STATE;          // never for log_n >= 11: the kernels' limb-plane stride is the FULL tile
             const bool last = s0 + ns == log_n;
             if (k == 0) {
                 const dim3 grid((unsigned)(n >> (ns + log_cols)));

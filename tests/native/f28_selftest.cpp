@@ -158,10 +158,47 @@ static int dense_mul_check(const char *name, int iters) {
     return bad;
 }
 
+
+// f28_canonical_quot (one quotient step) against f28_canonical_lazy (the chain of conditional subtractions) on values k p + r,
+// k < 2^(JMAX+1): random r, r = 0 / 1 / p - 1, every k -- the lazily grown tile values of the transforms, tight limbs, excess in the top limb.
+template <class RR, int JMAX>
+static int canonical_check(const char *name, int iters) {
+    int fails = 0;
+    constexpr int N = RR::N;
+    for (int it = 0; it < iters; ++it) {
+        // r < p in W-bit limbs
+        F28<RR> r;
+        if (it % 7 == 0) { for (int i = 0; i < N; ++i) r.l[i] = 0; }
+        else if (it % 7 == 1) { for (int i = 0; i < N; ++i) r.l[i] = RR::MOD[i]; r.l[0] -= 1; }       // p - 1 (p is odd)
+        else if (it % 7 == 2) { for (int i = 0; i < N; ++i) r.l[i] = 0; r.l[0] = 1; }
+        else {
+            for (int i = 0; i < N; ++i) r.l[i] = (uint32_t)next_u64() & RR::MASK;
+            r.l[N - 1] %= RR::MOD[N - 1];                                                                // top limb below p's: r < p
+        }
+        const unsigned k = (unsigned)(next_u64() % (1u << (JMAX + 1)));
+        // x = r + k p, carries propagated, excess in the top limb
+        F28<RR> x;
+        uint64_t c = 0;
+        for (int i = 0; i < N; ++i) {
+            const uint64_t t = (uint64_t)r.l[i] + (uint64_t)k * RR::MOD[i] + c;
+            x.l[i] = i + 1 < N ? (uint32_t)(t & RR::MASK) : (uint32_t)t;
+            c = t >> RR::W;
+        }
+        const F28<RR> a = f28_canonical_lazy<RR, JMAX>(x), b = f28_canonical_quot<RR, JMAX>(x);
+        bool same = true, is_r = true;
+        for (int i = 0; i < N; ++i) { same = same && a.l[i] == b.l[i]; is_r = is_r && b.l[i] == r.l[i]; }
+        if (!same || !is_r) { if (fails++ < 5) printf("%s canonical_quot mismatch (k = %u, JMAX = %d)\n", name, k, JMAX); }
+    }
+    return fails;
+}
+
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 2000;
     int f = run<BlsCurve>("bls12_381", iters) + run<BnCurve>("bn254", iters);
     f += dense_mul_check<BlsFrP>("BlsFr", 50 * iters) + dense_mul_check<BnFrP>("BnFr", 50 * iters) + dense_mul_check<BlsFqP>("BlsFq", 50 * iters) +
          dense_mul_check<BnFqP>("BnFq", 50 * iters);
+    f += canonical_check<BlsFrRR29, 5>("BlsFr29", 200 * iters) + canonical_check<BlsFrRR29, 4>("BlsFr29", 200 * iters) +
+         canonical_check<BnFrRR29, 5>("BnFr29", 200 * iters) + canonical_check<BnFrRR29, 4>("BnFr29", 200 * iters);
+    printf("canonical_quot: %s\n", f ? "FAILURES" : "ok");
     return f ? 1 : 0;
 }
