@@ -74,6 +74,13 @@ PM_HD F28<RR> f28_mul(const F28<RR> &a, const F28<RR> &b) {
     uint32_t m[N];
     F28<RR> r;
     uint64_t acc = 0;
+    // p = 1 (mod 2^W) (BLS12-381's scalar field on 29-bit limbs): the compiler folds m[k] * 1 into a 64-bit ADD of the zero-extended
+    // digit -- a v_mov for the high half plus a v_lshl_add_u64, N times per product (72 of the transforms' 1 144-instruction two-stage
+    // body).  Multiplying by a 1 it cannot see keeps the step what it is for every other modulus: one v_mad_u64_u32 on the chain.
+    uint32_t mod0 = RR::MOD[0];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PM_NO_OPAQUE_MOD0)
+    if (RR::MOD[0] == 1u) asm volatile("" : "+v"(mod0));
+#endif
 #pragma unroll
     for (int k = 0; k < 2 * N - 1; ++k) {
 #pragma unroll
@@ -82,7 +89,7 @@ PM_HD F28<RR> f28_mul(const F28<RR> &a, const F28<RR> &b) {
         for (int i = (k < N ? 0 : k - N + 1); i <= (k < N ? k - 1 : N - 1); ++i) { acc += (uint64_t)m[i] * RR::MOD[k - i]; PM_PIN64(acc); }
         if (k < N) {
             m[k] = ((uint32_t)acc * RR::INV) & RR::MASK;
-            { acc += (uint64_t)m[k] * RR::MOD[0]; PM_PIN64(acc); }
+            { acc += (uint64_t)m[k] * mod0; PM_PIN64(acc); }
         } else {
             r.l[k - N] = (uint32_t)acc & RR::MASK;
         }
