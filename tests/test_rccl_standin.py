@@ -1,7 +1,7 @@
 """The RCCL branch of polymath_amd/csrc/comm.hip (RcclComm) with REAL PEER PROCESSES on one GPU, through a test-only stand-in
 for librccl.so.1 (tests/native/fake_rccl.hip -- read its header: it moves bytes through host shared memory and says nothing
 about xGMI or RCCL's kernels).  What runs for the first time with a peer: the unique-id hand-off, ncclCommInitRank on
-N = 2, 4, 8 processes, per-peer byte counts of ncclAllToAll, the host all-gather's staging, two user streams on one
+N = 2, 4 processes (a GPU box admits 6 processes on its card: the test runner and 4 ranks), per-peer byte counts of ncclAllToAll, the host all-gather's staging, two user streams on one
 communicator (PM_OPT_NTT_OVERLAP), the watchdog's ncclCommAbort on a stalled peer, ncclCommGetAsyncError on a dead one.
 Rank processes are fresh children that never import torch (tests/rccl_standin_rank.py); the proofs they return are compared
 with the CPU ORACLE's bytes (oracle/cpp, its own setup) on the same circuit, trapdoors and r_a.
@@ -148,10 +148,10 @@ def _prove_case(oracle, tmp, world, curve, log_nr, overlap, reps=2, seconds=240)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4])          # the GPU boxes allow 6 processes on the card at once: pytest itself + 4 ranks
 @pytest.mark.parametrize("overlap", [1, 0])
 def test_sharded_proofs_over_rccl_branch_with_peer_processes(oracle, tmp_path, world, overlap):
-    """2^12 - 100 gates (n = 8192), N = 2 / 4 / 8 rank PROCESSES on one GPU over comm.hip's RcclComm: id hand-off through a
+    """2^12 - 100 gates (n = 8192), N = 2 / 4 rank PROCESSES on one GPU over comm.hip's RcclComm: id hand-off through a
     file, ncclCommInitRank, the fabric check, pm_pk_generate_sharded (PM_SHARD_VECTOR) and two pm_host_prove_sharded proofs per
     rank, all byte-equal to the CPU oracle's.  PM_OPT_NTT_OVERLAP on: w's all-to-all is issued on a SECOND stream of the same
     communicator (the stand-in counts the distinct streams and runs collectives in issue order, like NCCL); off: one stream."""
@@ -165,7 +165,7 @@ def test_sharded_proofs_over_rccl_branch_with_peer_processes(oracle, tmp_path, w
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,curve", [(2, "bls12_381"), (8, "bls12_381"), (4, "bn254")])
+@pytest.mark.parametrize("world,curve", [(2, "bls12_381"), (4, "bls12_381"), (4, "bn254")])
 def test_sharded_proofs_over_rccl_branch_at_2p16(oracle, tmp_path, world, curve):
     """2^16 - 100 gates (n = 2^17: three-pass local transforms, window tables on the shards, 2 MB per rank per all-to-all),
     default options (NTT overlap on), against the CPU oracle's bytes."""
