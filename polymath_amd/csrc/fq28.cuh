@@ -127,87 +127,6 @@ PM_HD F28<RR> f28_mul2_add(const F28<RR> &a, const F28<RR> &b, const F28<RR> &c,
     return r;
 }
 
-// ---- product by a FIXED multiplier w (a transform's twiddle) with a precomputed quotient wq = floor(w B / p), B = 2^(W N): Shoup's
-// form of Barrett's reduction on the reduced radix (round 6).  Returns t = y w - q p with q = the top N limbs of y wq, estimated from
-// the columns N-2 .. 2N-2 of that product; t is reduced modulo B as the low N limbs of y w + q (B - p) -- one unsigned column chain.
-//   mads: (N - 1) + N (N + 1) / 2 for q, N (N + 1) for t = 3 N (N + 1) / 2 + N - 1  (143 on 9 limbs; the Montgomery product: 2 N^2 = 162).
-// Bounds: y limbs < 2^31, value(y) < B; w canonical, wq < B, both tight.  With Q = floor(y w / p):
-//   wq > w B / p - 1  and  y < B   =>  floor(y wq / B) >= Q - 1;
-//   the dropped columns 0 .. N-3 weigh less than (N - 2) 2^(31 + W - 3 W) < 2^-24 of a unit of q, the low bits of column N-2 less than
-//   2^-W  =>  q >= Q - 2, and q <= Q:   0 <= t < 3p, limbs tight (masked) -- the multiplier's value is y w mod p, NOT divided by B:
-//   plain multipliers act on data of any Montgomery radix.
-// Column sums: N 2^(31 + W) + N 2^(2 W) + carry < 2^64 for N = 9, W = 29.
-template <class RR>
-PM_HD F28<RR> f28_mul_fixed(const F28<RR> &y, const F28<RR> &w, const F28<RR> &wq) {
-    constexpr int N = RR::N;
-    static_assert(N >= 3, "reduced radix");
-    uint32_t q[N];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int i = 0; i <= N - 2; ++i) { acc += (uint64_t)y.l[i] * wq.l[N - 2 - i]; PM_PIN64(acc); }      // column N-2: its carry only
-    acc >>= RR::W;
-#pragma unroll
-    for (int k = N - 1; k <= 2 * N - 2; ++k) {
-#pragma unroll
-        for (int i = k - N + 1; i <= N - 1; ++i) { acc += (uint64_t)y.l[i] * wq.l[k - i]; PM_PIN64(acc); }
-        if (k >= N) q[k - N] = (uint32_t)acc & RR::MASK;
-        acc >>= RR::W;
-    }
-    q[N - 1] = (uint32_t)acc;                 // < 2^W: q <= y w / p < B
-    // B - p has limbs like 2^W - 1 and 7 (p = 1 mod 2^32): seen as constants, the compiler turns those steps into shifts, 64-bit
-    // additions and v_mul_lo / v_mul_hi pairs (92 v_mul_lo_u32 + 28 v_lshl_add_u64 in the transforms' two-stage body); held in scalar
-    // registers it cannot see through, every step stays one v_mad_u64_u32 on the chain (cf. mod0 in f28_mul)
-    uint32_t nm[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        nm[i] = RR::NEGMOD[i];
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PM_NO_OPAQUE_MOD0)
-        asm volatile("" : "+s"(nm[i]));
-#endif
-    }
-    F28<RR> r;
-    acc = 0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-#pragma unroll
-        for (int i = 0; i <= k; ++i) { acc += (uint64_t)y.l[i] * w.l[k - i]; PM_PIN64(acc); }
-#pragma unroll
-        for (int i = 0; i <= k; ++i) { acc += (uint64_t)q[i] * nm[k - i]; PM_PIN64(acc); }
-        r.l[k] = (uint32_t)acc & RR::MASK;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PM_NO_OPAQUE_MOD0)
-        // the last column's carry is not needed (t is taken modulo B), so the compiler narrows its 2 N steps to v_mul_lo_u32 +
-        // v_add3_u32 pairs -- more issue cycles than the v_mad_u64_u32 they replace; a use of the whole accumulator keeps the chain
-        if (k == N - 1) asm volatile("" ::"v"(acc));
-#endif
-        acc >>= RR::W;
-    }
-    return r;
-}
-// wq = floor(w B / p) from wi = w B mod p (the multiplier's internal Montgomery form, canonical, != 0): w B = wq p + wi, so
-// wq = -wi p^-1 (mod B), and wq < B because w < p: the low N limbs of (B - wi) PINV.  Cold (twiddle tables).
-template <class RR>
-PM_HD F28<RR> f28_fixed_quotient(const F28<RR> &wi) {
-    constexpr int N = RR::N;
-    uint32_t u[N];
-    uint32_t carry = 1;                        // B - wi = ~wi + 1 on N W-bit limbs (wi != 0: no carry out)
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const uint32_t v = (~wi.l[i] & RR::MASK) + carry;
-        u[i] = v & RR::MASK;
-        carry = v >> RR::W;
-    }
-    F28<RR> r;
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-#pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (uint64_t)u[i] * RR::PINV[k - i];
-        r.l[k] = (uint32_t)acc & RR::MASK;
-        acc >>= RR::W;
-    }
-    return r;
-}
-
 // Montgomery square: the N(N-1)/2 cross products are taken once against the doubled operand
 // (limbs < 2^(29+e)), so a square costs N(N+1)/2 + N*N mads instead of 2 N*N.  Requires e_a <= 1.6
 // (2 e_a + 1 <= 4.2 under the same 64-bit column bound as f28_mul).  Output T.

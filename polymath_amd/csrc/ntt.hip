@@ -23,16 +23,14 @@ struct PowTable {
     Fp<P> w[33];  // w[k] = omega^(2^k)
 };
 
-// out[j] = omega^j in the standard Montgomery form.  The butterflies' multiplier records:
-//   small domains (k_ntt_pass, dense 32-bit limbs): out_int[j] = omega^j 2^(W N) mod p as a plain integer (the "internal" form of
-//     fq28.cuh): a reduced-radix Montgomery product of a standard-form value with it stays in the standard form;
-//   tile kernels (k_ntt_pass28, since round 6): out28[j] = Tw28 record = omega^j as a PLAIN canonical integer on N W-bit limbs and its
-//     precomputed quotient floor(omega^j 2^(W N) / p) -- fq28.cuh: f28_mul_fixed, 143 multiplier operations per butterfly instead of
-//     the Montgomery product's 162; a plain multiplier leaves the data in whatever Montgomery radix it is in.
+// out[j] = omega^j in the standard Montgomery form; out_int[j] = the same power as the plain integer
+// omega^j 2^(28 N) mod r ("internal" form of fq28.cuh): a reduced-radix product of a standard-form value with
+// it stays in the standard form, so the butterflies need no conversion of the data.
+// The internal form is kept either dense (out_int, 8 x u32: the 32-bit-limb tile kernels unpack it per butterfly) or already on
+// 28-bit limbs (out28, Tw28 records of 10 x u32: the 28-bit tile kernels load it ready for the product).
 template <class RR>
 struct alignas(8) Tw28 {
-    uint32_t l[RR::N];   // omega^j mod p
-    uint32_t q[RR::N];   // floor(omega^j 2^(W N) / p)
+    uint32_t l[RR::N];
 };
 
 template <class P, class RR>
@@ -45,16 +43,13 @@ __global__ void k_twiddles(Fp<P> *out, Fp<P> *out_int, Tw28<RR> *out28, size_t c
     out[j] = acc;
     Fp<P> c;
     for (int i = 0; i < P::N; ++i) c.l[i] = RR::STD2INT[i];
-    const Fp<P> wi = mul<P>(acc, c);                      // omega^j 2^(W N) mod p
+    const Fp<P> wi = mul<P>(acc, c);
     if (out_int) out_int[j] = wi;
     if (out28) {
-        Fp<P> one_int = Fp<P>::zero();
-        one_int.l[0] = 1;
-        const Fp<P> plain = mul<P>(acc, one_int);         // out of the Montgomery form: omega^j mod p
-        const F28<RR> w = f28_unpack<RR>(plain.l), wq = f28_fixed_quotient<RR>(f28_unpack<RR>(wi.l));
+        const F28<RR> u = f28_unpack<RR>(wi.l);
         Tw28<RR> r;
 #pragma unroll
-        for (int i = 0; i < RR::N; ++i) { r.l[i] = w.l[i]; r.q[i] = wq.l[i]; }
+        for (int i = 0; i < RR::N; ++i) r.l[i] = u.l[i];
         out28[j] = r;
     }
 }
@@ -150,7 +145,7 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const Fp<P> *a, Fp<P> *dst, co
 // multiplier: A/B runs on one box showed that removing 10 % of the instructions -- all of them cheap ones: masks,
 // shifts, adds, the twiddle unpack -- or batching the tile's loads changes nothing, so the lever is the number of v_mad_u64_u32:
 // 2 N^2 per product, 162 on 9 limbs of 29 bits against 200 on 10 limbs of 28.  A 255-bit field leaves 261 - 255 = 6 spare bits:
-// values grow by at most 4p per stage (x + yw < V + 3 since round 6's fixed-multiplier product returns < 3p, x + 4p - yw < V + 4), 37p after nine stages, below the 64p the radix holds
+// values grow by at most 4p per stage (x + yw < V + 2, x + 4p - yw < V + 4), 37p after nine stages, below the 64p the radix holds
 // and the 2^6 p the product tolerates; they are brought back to the canonical range once, on the way out (conditional subtractions
 // of 32p ... p; in the last pass of an inverse transform the n^-1 product does it).  Elements enter and leave in the dense
 // canonical form: the results are bit-identical.
@@ -192,205 +187,143 @@ __device__ __forceinline__ F28<RR> l28_canonical(const F28<RR> &x) {
 template <class RR>
 __device__ __forceinline__ void l28_pack_canonical(const F28<RR> &c, uint32_t *d) { f28_pack_canonical<RR>(c, d); }
 
-// a twiddle record as the loads deliver it (two 16-byte words and a limb): what is carried from one body to the next is the load's
-// own destination registers -- carried limb by limb, the values were copied out of them right after the request, i.e. waited for
-typedef uint32_t pm_u32x4 __attribute__((ext_vector_type(4)));
-typedef pm_u32x4 pm_u32x4_a8 __attribute__((aligned(8)));
-struct TwRaw {
-    pm_u32x4 a, b, c, d;     // limbs 0-3, 4-7, (8, q0-q2), q3-q6
-    uint32_t e0, e1;         // q7, q8
-};
-template <class RR>
-__device__ __forceinline__ void l28_tw_load(TwRaw &dst, const Tw28<RR> *rec) {
-    static_assert(RR::N == 9 && sizeof(Tw28<RR>) == 72, "a record is 9 + 9 limbs");
-    const uint32_t *p = &rec->l[0];
-    dst.a = *(const pm_u32x4_a8 *)(p + 0);
-    dst.b = *(const pm_u32x4_a8 *)(p + 4);
-    dst.c = *(const pm_u32x4_a8 *)(p + 8);
-    dst.d = *(const pm_u32x4_a8 *)(p + 12);
-    dst.e0 = p[16];
-    dst.e1 = p[17];
-}
-template <class RR>
-__device__ __forceinline__ F28<RR> l28_tw_w(const TwRaw &r) {
-    F28<RR> w;
-    w.l[0] = r.a.x; w.l[1] = r.a.y; w.l[2] = r.a.z; w.l[3] = r.a.w;
-    w.l[4] = r.b.x; w.l[5] = r.b.y; w.l[6] = r.b.z; w.l[7] = r.b.w;
-    w.l[8] = r.c.x;
-    return w;
-}
-template <class RR>
-__device__ __forceinline__ F28<RR> l28_tw_q(const TwRaw &r) {
-    F28<RR> w;
-    w.l[0] = r.c.y; w.l[1] = r.c.z; w.l[2] = r.c.w;
-    w.l[3] = r.d.x; w.l[4] = r.d.y; w.l[5] = r.d.z; w.l[6] = r.d.w;
-    w.l[7] = r.e0; w.l[8] = r.e1;
-    return w;
-}
-// y w mod p (< 3p, tight) by the record's precomputed quotient
-template <class RR>
-__device__ __forceinline__ F28<RR> l28_tw_mul(const F28<RR> &y, const TwRaw &r) {
-    return f28_mul_fixed<RR>(y, l28_tw_w<RR>(r), l28_tw_q<RR>(r));
-}
-// record indices of a body's multipliers: stage pair (stages st, st + 1): wA, wB0, wB1; single stage: the lane's L28_BPL = 2 butterflies
-// (i2 = i1).  A full tile is exactly ONE stage-pair group (or two single butterflies) per lane (tile = L28_EPL TH, checked by ntt_run),
-// so the records are a function of (st, lane) alone.
-template <bool FIRST, unsigned TH>
-__device__ __forceinline__ void l28_tw_index(size_t &i0, size_t &i1, size_t &i2, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols, size_t lo0,
-                                             bool pair_stages, unsigned st) {
-    const unsigned cm = (1u << log_cols) - 1, tid = threadIdx.x, half = 1u << st;
-#ifdef PM_NTT_TW_HACK_SAME_RECORDS   // measurement only (WRONG results): every tile asks for the first tile's records
-    lo0 = 0;
-#endif
-    if (pair_stages && st + 1 < ns) {
-        const unsigned c = tid & cm, k = tid >> log_cols, low = k & (half - 1), sA = s0 + st + 1, sB = sA + 1;
-        const size_t jA = FIRST ? (size_t)low : ((size_t)low << s0) + lo0 + c;
-        const size_t jB1 = FIRST ? (size_t)(low + half) : ((size_t)(low + half) << s0) + lo0 + c;
-        i0 = jA << (log_n - sA);
-        i1 = jA << (log_n - sB);
-        i2 = jB1 << (log_n - sB);
-    } else {
-        const unsigned s = s0 + st + 1;
-        static_assert(L28_BPL == 2, "two butterflies per lane and single stage");
-        auto idx = [&](unsigned e) {
-            const unsigned c = e & cm, k = e >> log_cols, low = k & (half - 1);
-            return (FIRST ? (size_t)low : ((size_t)low << s0) + lo0 + c) << (log_n - s);
-        };
-        i0 = idx(tid);
-        i1 = i2 = idx(tid + TH);
-    }
-}
-
 // the ns butterfly stages on the tile; element (r, c) sits at slot r * cols + (FIRST ? (c + r) & (cols - 1) : c).
 // Carries are propagated after every second stage only: a stage adds at most 2^(W+1) to a limb (x + yw: + 2^W; x + K4 - yw: K4's
-// limbs are < 2^(W+1)), so a limb entering a product is below 2^W + 2^(W+1) < 2^31 and the column sums stay in 64 bits
-// (f28_mul_fixed; the n^-1 product of l28_emit, a Montgomery product, sees at most 2.5 * 2^30: < 2^63.8).  The stage that ends the
-// pass leaves its carries to l28_emit.
-// Begins with the barrier that ends the caller's load phase.
-// Multiplier records (round 6): 72 bytes each (value + quotient), 18 registers.  Where they are REQUESTED is pinned
-// (__builtin_amdgcn_sched_barrier): left alone, the compiler hoists a body's three requests to its top -- 54 registers on top of the
-// four elements of a stage pair, spilled.  A body's first record is requested one body ahead, before the barrier that ends the
-// previous body (the first body's before the barrier that ends the load phase); the second during the first stage's second product,
-// the third during the second stage's first product.  PM_NTT_TW_AHEAD=0: the first record at the top of its own body.
-#ifndef PM_NTT_TW_AHEAD
-#define PM_NTT_TW_AHEAD 1
-#endif
-#define PM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// limbs are < 2^(W+1)), so a limb entering a product is below 2^W + 2^(W+1) and the column sums stay in 64 bits
+// (W = 29, N = 9: 9 * 1.5 * 2^30 * 2^29 + 9 * 2^58 < 2^63 against a tight twiddle; the n^-1 product of l28_emit sees at most
+// 2.5 * 2^30: < 2^63.8).  The stage that ends the pass leaves its carries to l28_emit.
 template <class P, class RR, bool FIRST, unsigned TH>
 __device__ __forceinline__ void l28_stages(uint32_t *t, const Tw28<RR> *tw, unsigned log_n, unsigned s0, unsigned ns, unsigned log_cols,
                                            size_t lo0, bool pair_stages) {
     constexpr unsigned tile = L28_EPL * TH;      // every workgroup of every pass holds a full tile (checked by the host: ntt_run)
-    const unsigned cols = 1u << log_cols, cm = cols - 1, tid = threadIdx.x;
+    const unsigned cols = 1u << log_cols, cm = cols - 1, rows = 1u << ns, nbf = (rows >> 1) * cols, tid = threadIdx.x;
     // Two stages per LDS round trip (round 3): a lane takes the four rows r0 + {0, h, 2h, 3h} of one column, runs stage st on
     // (r0, r0 + h), (r0 + 2h, r0 + 3h) and stage st + 1 on (r0, r0 + 2h), (r0 + h, r0 + 3h) in registers -- the same four products,
-    // additions and (after the odd stage) weak normalisations in the same order as a stage-at-a-time loop; three multiplier records
-    // instead of four (stage st's is shared), half the barriers and half the LDS traffic.  An odd stage count ends with one
-    // ordinary stage.
-    auto two_stages = [&](unsigned st, const TwRaw &wA, const Tw28<RR> *recB0, const Tw28<RR> *recB1, auto norm_tag) {
+    // additions and (after the odd stage) weak normalisations in the same order, so the values are bit-identical to the
+    // stage-at-a-time loop below; three twiddle records instead of four (stage st's is shared), half the barriers and half the
+    // LDS traffic.  An odd stage count ends with one ordinary stage.  PM_NTT_RADIX4=0: one stage at a time (round 2).
+    auto two_stages = [&](unsigned st, auto norm_tag) {
         constexpr bool NORM = decltype(norm_tag)::value;
-        const unsigned half = 1u << st;
-        const unsigned c = tid & cm, k = tid >> log_cols;
-        const unsigned r0 = ((k >> st) << (st + 2)) | (k & (half - 1)), r1 = r0 + half, r2 = r1 + half, r3 = r2 + half;
-        const unsigned e0 = r0 * cols + (FIRST ? ((c + r0) & cm) : c), e1 = r1 * cols + (FIRST ? ((c + r1) & cm) : c);
-        const unsigned e2 = r2 * cols + (FIRST ? ((c + r2) & cm) : c), e3 = r3 * cols + (FIRST ? ((c + r3) & cm) : c);
-        // register budget (4 waves per SIMD = 128 VGPRs): one butterfly's operands at a time -- an element is loaded right before
-        // its product
-        F28<RR> a0, a1, a2, a3;
-        TwRaw wB0, wB1;
-        {
-            const F28<RR> p1 = l28_tw_mul<RR>(l28_load<RR, tile>(t, e1), wA), x0 = l28_load<RR, tile>(t, e0);
-            a0 = f28_add<RR>(x0, p1);
-            a1 = f28_sub_k4<RR>(x0, p1);
-        }
-        PM_SCHED_FENCE();
-        l28_tw_load<RR>(wB0, recB0);
-        PM_SCHED_FENCE();
-        {
-            const F28<RR> p3 = l28_tw_mul<RR>(l28_load<RR, tile>(t, e3), wA), x2 = l28_load<RR, tile>(t, e2);
-            a2 = f28_add<RR>(x2, p3);
-            a3 = f28_sub_k4<RR>(x2, p3);
-        }
-        PM_SCHED_FENCE();
-        l28_tw_load<RR>(wB1, recB1);
-        PM_SCHED_FENCE();
-        const F28<RR> q2 = l28_tw_mul<RR>(a2, wB0);
-        const F28<RR> b0 = f28_add<RR>(a0, q2), b2 = f28_sub_k4<RR>(a0, q2);
-        if (NORM) {
-            l28_store<RR, tile>(t, e0, f28_weak_norm<RR>(b0));
-            l28_store<RR, tile>(t, e2, f28_weak_norm<RR>(b2));
-        } else {
-            l28_store<RR, tile>(t, e0, b0);
-            l28_store<RR, tile>(t, e2, b2);
-        }
-        const F28<RR> q3 = l28_tw_mul<RR>(a3, wB1);
-        const F28<RR> b1 = f28_add<RR>(a1, q3), b3 = f28_sub_k4<RR>(a1, q3);
-        if (NORM) {
-            l28_store<RR, tile>(t, e1, f28_weak_norm<RR>(b1));
-            l28_store<RR, tile>(t, e3, f28_weak_norm<RR>(b3));
-        } else {
-            l28_store<RR, tile>(t, e1, b1);
-            l28_store<RR, tile>(t, e3, b3);
+        const unsigned half = 1u << st, sA = s0 + st + 1, sB = sA + 1, ngroups = (rows >> 2) * cols;
+        for (unsigned e = tid; e < ngroups; e += TH) {
+            const unsigned c = e & cm, k = e >> log_cols;
+            const unsigned r0 = ((k >> st) << (st + 2)) | (k & (half - 1)), r1 = r0 + half, r2 = r1 + half, r3 = r2 + half;
+            const unsigned low = r0 & (half - 1);
+            const size_t jA = FIRST ? (size_t)low : ((size_t)low << s0) + lo0 + c;
+            const size_t jB0 = jA, jB1 = FIRST ? (size_t)(low + half) : ((size_t)(low + half) << s0) + lo0 + c;
+            const unsigned e0 = r0 * cols + (FIRST ? ((c + r0) & cm) : c), e1 = r1 * cols + (FIRST ? ((c + r1) & cm) : c);
+            const unsigned e2 = r2 * cols + (FIRST ? ((c + r2) & cm) : c), e3 = r3 * cols + (FIRST ? ((c + r3) & cm) : c);
+            // register budget (4 waves per SIMD = 128 VGPRs, a 64-bit column accumulator of 18 inside every product): one
+            // butterfly's operands at a time -- an element is loaded right before its product, a twiddle right before its stage
+            F28<RR> w, a0, a1, a2, a3;
+            {
+                const Tw28<RR> wA = tw[jA << (log_n - sA)];
+#pragma unroll
+                for (int i = 0; i < RR::N; ++i) w.l[i] = wA.l[i];
+            }
+            {
+                const F28<RR> p1 = f28_mul<RR>(l28_load<RR, tile>(t, e1), w), x0 = l28_load<RR, tile>(t, e0);
+                a0 = f28_add<RR>(x0, p1);
+                a1 = f28_sub_k4<RR>(x0, p1);
+            }
+            {
+                const F28<RR> p3 = f28_mul<RR>(l28_load<RR, tile>(t, e3), w), x2 = l28_load<RR, tile>(t, e2);
+                a2 = f28_add<RR>(x2, p3);
+                a3 = f28_sub_k4<RR>(x2, p3);
+            }
+            {
+                const Tw28<RR> wB0 = tw[jB0 << (log_n - sB)];
+#pragma unroll
+                for (int i = 0; i < RR::N; ++i) w.l[i] = wB0.l[i];
+            }
+            const F28<RR> q2 = f28_mul<RR>(a2, w);
+            const F28<RR> b0 = f28_add<RR>(a0, q2), b2 = f28_sub_k4<RR>(a0, q2);
+            if (NORM) {
+                l28_store<RR, tile>(t, e0, f28_weak_norm<RR>(b0));
+                l28_store<RR, tile>(t, e2, f28_weak_norm<RR>(b2));
+            } else {
+                l28_store<RR, tile>(t, e0, b0);
+                l28_store<RR, tile>(t, e2, b2);
+            }
+            {
+                const Tw28<RR> wB1 = tw[jB1 << (log_n - sB)];
+#pragma unroll
+                for (int i = 0; i < RR::N; ++i) w.l[i] = wB1.l[i];
+            }
+            const F28<RR> q3 = f28_mul<RR>(a3, w);
+            const F28<RR> b1 = f28_add<RR>(a1, q3), b3 = f28_sub_k4<RR>(a1, q3);
+            if (NORM) {
+                l28_store<RR, tile>(t, e1, f28_weak_norm<RR>(b1));
+                l28_store<RR, tile>(t, e3, f28_weak_norm<RR>(b3));
+            } else {
+                l28_store<RR, tile>(t, e1, b1);
+                l28_store<RR, tile>(t, e3, b3);
+            }
         }
     };
-    // NORM is a compile-time flag of the stage body (two instantiations behind one uniform branch): as a run-time select the
-    // compiler computes the carry chain in every stage and picks afterwards
-    auto one_stage = [&](unsigned st, const TwRaw &wq0, const Tw28<RR> *rec1, auto norm_tag) {
-        constexpr bool NORM = decltype(norm_tag)::value;
-        const unsigned half = 1u << st;
-        auto bfly = [&](unsigned e, const TwRaw &w) {
+    for (unsigned st = 0; st < ns; ++st) {
+        if (pair_stages && (st & 1) == 0 && st + 1 < ns) {          // stages st (even: no normalisation) and st + 1 (odd) together
+            if (st + 2 != ns)
+                two_stages(st, std::true_type{});
+            else
+                two_stages(st, std::false_type{});                    // the stage that ends the pass leaves its carries to l28_emit
+            __syncthreads();
+            ++st;
+            continue;
+        }
+        const unsigned s = s0 + st + 1, half = 1u << st;
+        const bool norm = (st & 1) == 1 && st + 1 != ns;
+        auto slots = [&](unsigned e, unsigned &e0, unsigned &e1, size_t &j) {
             const unsigned c = e & cm, k = e >> log_cols;
             const unsigned r0 = ((k >> st) << (st + 1)) | (k & (half - 1)), r1 = r0 + half;
-            const unsigned e0 = r0 * cols + (FIRST ? ((c + r0) & cm) : c), e1 = r1 * cols + (FIRST ? ((c + r1) & cm) : c);
-            const F28<RR> x = l28_load<RR, tile>(t, e0), y = l28_load<RR, tile>(t, e1);
-            const F28<RR> yw = l28_tw_mul<RR>(y, w);                                 // tight, < 3p
-            const F28<RR> lo = f28_add<RR>(x, yw), hi = f28_sub_k4<RR>(x, yw);       // values < V + 3, < V + 4
-            if (NORM) {
-                l28_store<RR, tile>(t, e0, f28_weak_norm<RR>(lo));
-                l28_store<RR, tile>(t, e1, f28_weak_norm<RR>(hi));
+            j = FIRST ? (size_t)(r0 & (half - 1)) : ((size_t)(r0 & (half - 1)) << s0) + lo0 + c;
+            e0 = r0 * cols + (FIRST ? ((c + r0) & cm) : c);
+            e1 = r1 * cols + (FIRST ? ((c + r1) & cm) : c);
+        };
+        // NORM is a compile-time flag of the stage body (two instantiations behind one uniform branch): as a run-time select the
+        // compiler computes the carry chain in every stage and picks afterwards
+        auto stage = [&](auto norm_tag) {
+            constexpr bool NORM = decltype(norm_tag)::value;
+            auto bfly = [&](unsigned e0, unsigned e1, const Tw28<RR> &wd) {
+                const F28<RR> x = l28_load<RR, tile>(t, e0), y = l28_load<RR, tile>(t, e1);
+                F28<RR> w;
+#pragma unroll
+                for (int i = 0; i < RR::N; ++i) w.l[i] = wd.l[i];
+                const F28<RR> yw = f28_mul<RR>(y, w);                                    // tight, < 2p
+                const F28<RR> lo = f28_add<RR>(x, yw), hi = f28_sub_k4<RR>(x, yw);       // values < V + 2, < V + 4
+                if (NORM) {
+                    l28_store<RR, tile>(t, e0, f28_weak_norm<RR>(lo));
+                    l28_store<RR, tile>(t, e1, f28_weak_norm<RR>(hi));
+                } else {
+                    l28_store<RR, tile>(t, e0, lo);
+                    l28_store<RR, tile>(t, e1, hi);
+                }
+            };
+            if (nbf == L28_BPL * TH) {   // full tile: the twiddle loads of this lane's butterflies are issued before the arithmetic
+                Tw28<RR> w[L28_BPL];
+                unsigned e0v[L28_BPL], e1v[L28_BPL];
+#pragma unroll
+                for (unsigned q = 0; q < L28_BPL; ++q) {
+                    size_t j;
+                    slots(tid + q * TH, e0v[q], e1v[q], j);
+                    w[q] = tw[j << (log_n - s)];
+                }
+#pragma unroll
+                for (unsigned q = 0; q < L28_BPL; ++q) bfly(e0v[q], e1v[q], w[q]);
             } else {
-                l28_store<RR, tile>(t, e0, lo);
-                l28_store<RR, tile>(t, e1, hi);
+                for (unsigned e = tid; e < nbf; e += TH) {
+                    unsigned e0, e1;
+                    size_t j;
+                    slots(e, e0, e1, j);
+                    bfly(e0, e1, tw[j << (log_n - s)]);
+                }
             }
         };
-        TwRaw w1;
-        l28_tw_load<RR>(w1, rec1);
-        PM_SCHED_FENCE();
-        bfly(tid, wq0);
-        bfly(tid + TH, w1);
-    };
-    size_t i0, i1, i2;
-    TwRaw wfirst;          // the current body's first record
-    l28_tw_index<FIRST, TH>(i0, i1, i2, log_n, s0, ns, log_cols, lo0, pair_stages, 0);
-    if (PM_NTT_TW_AHEAD) l28_tw_load<RR>(wfirst, &tw[i0]);
-    __syncthreads();                                                   // the tile is complete
-#ifdef PM_NTT_HACK_NO_STAGES   // measurement only (WRONG results): the tile's load and emit phases alone
-    ns = 0;
-#endif
-    for (unsigned st = 0; st < ns;) {
-        const bool pair = pair_stages && st + 1 < ns;                   // stages st (even: no normalisation) and st + 1 (odd) together
-        const unsigned st_next = st + (pair ? 2 : 1);
-        if (!PM_NTT_TW_AHEAD) {
-            l28_tw_load<RR>(wfirst, &tw[i0]);
-            PM_SCHED_FENCE();
-        }
-        if (pair) {
-            if (st + 2 != ns)
-                two_stages(st, wfirst, &tw[i1], &tw[i2], std::true_type{});
-            else
-                two_stages(st, wfirst, &tw[i1], &tw[i2], std::false_type{});   // the stage that ends the pass leaves its carries to l28_emit
-        } else {
-            if ((st & 1) == 1 && st + 1 != ns)
-                one_stage(st, wfirst, &tw[i1], std::true_type{});
-            else
-                one_stage(st, wfirst, &tw[i1], std::false_type{});
-        }
-        if (st_next < ns) {
-            PM_SCHED_FENCE();                                           // the request stays BEHIND the body's arithmetic
-            l28_tw_index<FIRST, TH>(i0, i1, i2, log_n, s0, ns, log_cols, lo0, pair_stages, st_next);
-            if (PM_NTT_TW_AHEAD) l28_tw_load<RR>(wfirst, &tw[i0]);
-        }
+        if (norm)
+            stage(std::true_type{});
+        else
+            stage(std::false_type{});
         __syncthreads();
-        st = st_next;
     }
 }
 
@@ -407,11 +340,7 @@ __device__ __forceinline__ void l28_emit(const F28<RR> &v, Fp<P> *dst, const F28
         l28_pack_canonical<RR>(l28_canonical<RR, 4>(f28_weak_norm<RR>(v)), out.l);
     else
         l28_pack_canonical<RR>(l28_canonical<RR, 5>(f28_weak_norm<RR>(v)), out.l);
-#ifdef PM_NTT_HACK_NO_IO        // measurement only: the stages without the tile's global traffic
-    if (out.l[0] == 0x12345u && out.l[7] == 0x54321u) *dst = out;
-#else
     *dst = out;
-#endif
 }
 
 // general pass: stages [s0, s0 + ns), tile of 2^ns rows x 2^log_cols contiguous columns, src -> dst at the same positions
@@ -424,12 +353,6 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const unsigned cols = 1u << log_cols;
     const size_t lo_groups = ((size_t)1 << s0) >> log_cols, g = blockIdx.x;
     const size_t hi = g / lo_groups, lo0 = (g % lo_groups) << log_cols, base = (hi << (s0 + ns)) + lo0;
-#ifdef PM_NTT_STAGGER           // experiment: de-phase the workgroups that start together
-    if (blockIdx.x < PM_NTT_STAGGER_RESIDENT) {
-        const unsigned slot = (blockIdx.x / PM_NTT_STAGGER_DIV) & 3;
-        for (unsigned k = 0; k < slot * PM_NTT_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     // every load of the tile is in flight before the first one is unpacked (a 2^11-element tile is 8 per lane = 64 VGPRs):
     // with one load per loop trip the workgroup paid eight HBM round trips in sequence, a quarter of its time
     for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * TH) {
@@ -437,12 +360,7 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
             const unsigned e = e8 + q * TH, r = e >> log_cols, c = e & (cols - 1);
-#ifdef PM_NTT_HACK_NO_IO
-            for (int i = 0; i < P::N; ++i) v[q].l[i] = (e * 2654435761u) >> (i & 3);
-            v[q].l[P::N - 1] &= 0x0fffffffu;
-#else
             if (e < tile) v[q] = a[base + ((size_t)r << s0) + c];
-#endif
         }
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
@@ -450,6 +368,7 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (e < tile) l28_store<RR, tile>(t, e, f28_unpack<RR>(v[q].l));
         }
     }
+    __syncthreads();
     l28_stages<P, RR, false, TH>(t, tw, log_n, s0, ns, log_cols, lo0, pair_stages != 0);
     const F28<RR> sc = f28_unpack<RR>(scale_int.l);
     for (unsigned e = threadIdx.x; e < tile; e += TH) {
@@ -472,23 +391,12 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     constexpr unsigned tile = L28_EPL * TH;      // == rows * cols: full tiles only (ntt_run)
     const unsigned cols = 1u << log_cols, rows = 1u << ns, H = log_n - ns, cm = cols - 1;
     const size_t g = blockIdx.x;
-#ifdef PM_NTT_STAGGER           // experiment: de-phase the workgroups that start together
-    if (blockIdx.x < PM_NTT_STAGGER_RESIDENT) {
-        const unsigned slot = (blockIdx.x / PM_NTT_STAGGER_DIV) & 3;
-        for (unsigned k = 0; k < slot * PM_NTT_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     for (unsigned e8 = threadIdx.x; e8 < tile; e8 += L28_EPL * TH) {      // loads batched as in k_ntt_pass28
         Fp<P> v[L28_EPL];
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
             const unsigned e = e8 + q * TH, rb = e >> log_cols, c = e & cm;
-#ifdef PM_NTT_HACK_NO_IO
-            for (int i = 0; i < P::N; ++i) v[q].l[i] = (e * 2654435761u) >> (i & 3);
-            v[q].l[P::N - 1] &= 0x0fffffffu;
-#else
             if (e < tile) v[q] = src[((size_t)rb << H) + (g << log_cols) + c];
-#endif
         }
 #pragma unroll
         for (unsigned q = 0; q < L28_EPL; ++q) {
@@ -496,6 +404,7 @@ __global__ __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (e < tile) l28_store<RR, tile>(t, r * cols + ((c + r) & cm), f28_unpack<RR>(v[q].l));
         }
     }
+    __syncthreads();
     l28_stages<P, RR, true, TH>(t, tw, log_n, 0, ns, log_cols, 0, pair_stages != 0);
     const F28<RR> none = f28_zero<RR>();
     for (unsigned e = threadIdx.x; e < tile; e += TH) {

@@ -192,76 +192,6 @@ static int canonical_check(const char *name, int iters) {
     return fails;
 }
 
-// f28_mul_fixed (Shoup / Barrett product by a fixed multiplier with a precomputed quotient; the transforms' twiddles since round 6)
-// against the dense Montgomery product, on lazily grown multiplicands (value r + k p, k < 40, limbs up to 1.5 * 2^30 as the butterflies
-// leave them), multipliers 1, p - 1, 2, random; f28_fixed_quotient checked by the identity w B == wq p + wi on 2N limbs.
-template <class P, class RR>
-static int fixed_mul_check(const char *name, int iters) {
-    int fails = 0;
-    constexpr int N = RR::N;
-    Fp<P> one_int = Fp<P>::zero(), s2i;
-    one_int.l[0] = 1;
-    for (int i = 0; i < P::N; ++i) s2i.l[i] = RR::STD2INT[i];
-    for (int it = 0; it < iters; ++it) {
-        // multiplier: Wm = w 2^(32 N32) mod p (any canonical word is some w's Montgomery form)
-        Fp<P> Wm = rand_fp<P>();
-        if (it % 11 == 0) Wm = Fp<P>::one();                                                        // w = 1
-        if (it % 11 == 1) { Wm = sub<P>(Fp<P>::zero(), Fp<P>::one()); }                             // w = p - 1
-        if (it % 11 == 2) { Wm = add<P>(Fp<P>::one(), Fp<P>::one()); }                              // w = 2
-        const Fp<P> w_plain = mul<P>(Wm, one_int), wi = mul<P>(Wm, s2i);
-        const F28<RR> w28 = f28_unpack<RR>(w_plain.l), wi28 = f28_unpack<RR>(wi.l), wq = f28_fixed_quotient<RR>(wi28);
-        {   // w B == wq p + wi
-            uint64_t col[2 * N + 1] = {0};
-            for (int i = 0; i < N; ++i)
-                for (int j = 0; j < N; ++j) {
-                    const uint64_t t = (uint64_t)wq.l[i] * RR::MOD[j];
-                    col[i + j] += t & RR::MASK;
-                    col[i + j + 1] += t >> RR::W;
-                }
-            for (int i = 0; i < N; ++i) col[i] += wi28.l[i];
-            uint64_t c = 0;
-            bool ok = true;
-            for (int k = 0; k < 2 * N + 1; ++k) {
-                const uint64_t v = col[k] + c;
-                const uint32_t limb = (uint32_t)(v & RR::MASK);
-                c = v >> RR::W;
-                const uint32_t want = k < N ? 0u : (k < 2 * N ? w28.l[k - N] : 0u);
-                ok = ok && limb == want;
-            }
-            if (!ok || c) { if (fails++ < 5) printf("%s fixed quotient identity broken (it %d)\n", name, it); }
-        }
-        // multiplicand r + k p, tight limbs with the excess on top, then carries pushed back DOWN at random (limbs < 1.5 * 2^30)
-        F28<RR> r;
-        if (it % 7 == 0) { for (int i = 0; i < N; ++i) r.l[i] = 0; }
-        else if (it % 7 == 1) { for (int i = 0; i < N; ++i) r.l[i] = RR::MOD[i]; r.l[0] -= 1; }
-        else {
-            for (int i = 0; i < N; ++i) r.l[i] = (uint32_t)next_u64() & RR::MASK;
-            r.l[N - 1] %= RR::MOD[N - 1];
-        }
-        const unsigned k = (unsigned)(next_u64() % 40);
-        F28<RR> y;
-        uint64_t c = 0;
-        for (int i = 0; i < N; ++i) {
-            const uint64_t t = (uint64_t)r.l[i] + (uint64_t)k * RR::MOD[i] + c;
-            y.l[i] = i + 1 < N ? (uint32_t)(t & RR::MASK) : (uint32_t)t;
-            c = t >> RR::W;
-        }
-        for (int i = N - 2; i >= 0; --i)
-            if (y.l[i + 1] > 0 && (next_u64() & 1)) { y.l[i + 1] -= 1; y.l[i] += 1u << RR::W; }
-        Fp<P> r_dense;
-        f28_pack_canonical<RR>(r, r_dense.l);
-        const Fp<P> want = mul<P>(r_dense, Wm);                                                     // r w mod p, plain
-        const F28<RR> t = f28_mul_fixed<RR>(y, w28, wq);
-        bool tight = true;
-        for (int i = 0; i < N; ++i) tight = tight && t.l[i] <= RR::MASK;
-        Fp<P> got;
-        f28_pack_canonical<RR>(f28_canonical_lazy<RR, 1>(t), got.l);                                // t < 3p
-        if (!tight || !got.eq(want)) { if (fails++ < 5) printf("%s fixed-multiplier product mismatch (it %d, k %u)\n", name, it, k); }
-    }
-    printf("%s f28_mul_fixed vs dense: %d failures of %d\n", name, fails, iters);
-    return fails;
-}
-
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 2000;
     int f = run<BlsCurve>("bls12_381", iters) + run<BnCurve>("bn254", iters);
@@ -270,6 +200,5 @@ int main(int argc, char **argv) {
     f += canonical_check<BlsFrRR29, 5>("BlsFr29", 200 * iters) + canonical_check<BlsFrRR29, 4>("BlsFr29", 200 * iters) +
          canonical_check<BnFrRR29, 5>("BnFr29", 200 * iters) + canonical_check<BnFrRR29, 4>("BnFr29", 200 * iters);
     printf("canonical_quot: %s\n", f ? "FAILURES" : "ok");
-    f += fixed_mul_check<BlsFrP, BlsFrRR29>("BlsFr29", 100 * iters) + fixed_mul_check<BnFrP, BnFrRR29>("BnFr29", 100 * iters);
     return f ? 1 : 0;
 }
