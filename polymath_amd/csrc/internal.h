@@ -333,7 +333,19 @@ int msm_resident_end(pm_ctx *ctx, uint64_t *out_xy, int *out_inf);
 // msm_reduce.hip: the bucket reduction of the table-mode MSM (one set of NB >= 4096 buckets whose task partials sit in ctx->msm),
 // three launches on ctx->stream; *out = the sum sum_b (b + 1) B_b, internal form, inside the workspace.
 template <class C>
-int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets = 1);
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets = 1, size_t bucket0 = 0);   // bucket0: first bucket of the first set
+
+// Wide mode: buckets of the set of a window that is one bit narrower than the plan's widest (c bits; the 256 % nwin wider windows
+// come first): half of 2^(c-1) where that is still whole 2^15-bucket sort regions.  Planner (setup.hip: wide_plan), driver and
+// kernels (msm.hip: win_base) agree through this.
+inline size_t wide_narrow_buckets(unsigned nwin, unsigned c) {
+    const size_t nb1 = (size_t)1 << (c - 1);
+    return (256 % nwin != 0 && (nb1 >> 1) >= ((size_t)1 << 15)) ? nb1 >> 1 : nb1;
+}
+inline size_t wide_total_buckets(unsigned nwin, unsigned c) {
+    const size_t nb1 = (size_t)1 << (c - 1), nbn = wide_narrow_buckets(nwin, c);
+    return nbn == nb1 ? nb1 * nwin : nb1 * (256 % nwin) + nbn * (nwin - 256 % nwin);
+}
 
 // One bucket pipeline covers at most this many pairs (sorted-entry positions are u32: windows x pairs < 2^32); longer
 // MSMs run in pieces summed on the host.  2^27 in production; PM_OPT_MSM_MAX_PIECE_LOG (developer / test knob) lowers it

@@ -540,6 +540,13 @@ __device__ __forceinline__ Fp<P> canon_scalar(const Fp<P> *scalars, const unsign
 // with a run-time layout the compiler parks the scalar in LDS and fetches offsets with vector loads.
 __host__ __device__ constexpr unsigned win_width(unsigned nwin, unsigned w) { return 256 / nwin + (w < 256 % nwin ? 1u : 0u); }
 __host__ __device__ constexpr unsigned win_off(unsigned nwin, unsigned w) { return w * (256 / nwin) + (w < 256 % nwin ? w : 256 % nwin); }
+// Wide mode (every window has its own bucket set): first bucket of window w's set.  The 256 % nwin windows that are one bit wider come
+// first (win_width) and own `wide_b` buckets each, the others `narrow_b` (round 6: half as many, where that is still whole sort
+// regions; until then every set had wide_b buckets: 12 windows of 22 / 21 bits held 12 x 2^21 = 25.2 M buckets instead of 16.8 M).
+// Table mode passes 0 for both: one shared set.
+__host__ __device__ constexpr uint32_t win_base(unsigned nwin, unsigned w, uint32_t wide_b, uint32_t narrow_b) {
+    return w <= 256 % nwin ? w * wide_b : (256 % nwin) * wide_b + (w - 256 % nwin) * narrow_b;
+}
 
 template <class P>
 __device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned lo, unsigned c, uint32_t &carry, uint32_t &bucket, uint32_t &neg) {
@@ -568,7 +575,7 @@ __device__ __forceinline__ bool digit_at(const Fp<P> &k, unsigned lo, unsigned c
 // regions hammering 64 addresses serialised in L2 and cost more than the rest of the kernel.
 template <class P, unsigned NWIN>
 __global__ __launch_bounds__(1024) void k_tbl_count(const Fp<P> *scalars, const unsigned char *inf, size_t len, unsigned regions,
-                                                   uint32_t *block_cnt, uint32_t win_buckets) {
+                                                   uint32_t *block_cnt, uint32_t win_buckets, uint32_t narrow_buckets) {
     __shared__ uint32_t cnt[1024];
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) cnt[r] = 0;
     __syncthreads();
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(1024) void k_tbl_count(const Fp<P> *scalars, const 
         uint32_t carry = 0, b, neg;
 #pragma unroll
         for (unsigned w = 0; w < NWIN; ++w)
-            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) atomicAdd(&cnt[(b + w * win_buckets) >> LO_BITS], 1u);
+            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) atomicAdd(&cnt[(b + win_base(NWIN, w, win_buckets, narrow_buckets)) >> LO_BITS], 1u);
     }
     __syncthreads();
     for (unsigned r = threadIdx.x; r < regions; r += blockDim.x) block_cnt[(size_t)blockIdx.x * regions + r] = cnt[r];
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(1024) void k_region_offsets(const uint32_t *region_
 template <class P, unsigned NWIN>
 __global__ __launch_bounds__(1024) void k_tbl_partition(const Fp<P> *scalars, const unsigned char *inf, size_t len,
                                                        unsigned regions, const uint32_t *region_off, const uint32_t *block_off, size_t tbl_stride, size_t base_index, uint16_t *keys,
-                                                       uint32_t *vals, uint32_t win_buckets) {
+                                                       uint32_t *vals, uint32_t win_buckets, uint32_t narrow_buckets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t *cnt = (uint32_t *)smem_raw, *delta = cnt + 1024;
     uint32_t *st_val = delta + 1024, *st_key = st_val + (size_t)blockDim.x * NWIN;
@@ -705,7 +712,7 @@ __global__ __launch_bounds__(1024) void k_tbl_partition(const Fp<P> *scalars, co
         uint32_t carry = 0, b, neg;
 #pragma unroll
         for (unsigned w = 0; w < NWIN; ++w)
-            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) rank[w] = atomicAdd(&cnt[(b + w * win_buckets) >> LO_BITS], 1u);
+            if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) rank[w] = atomicAdd(&cnt[(b + win_base(NWIN, w, win_buckets, narrow_buckets)) >> LO_BITS], 1u);
     }
     __syncthreads();
     {   // exclusive scan over the regions: lane t owns regions [t rpl, (t + 1) rpl), rpl = 1 or 2 (regions <= 2 blockDim, checked by
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(1024) void k_tbl_partition(const Fp<P> *scalars, co
 #pragma unroll
         for (unsigned w = 0; w < NWIN; ++w)
             if (digit_at<P>(k, win_off(NWIN, w), win_width(NWIN, w), carry, b, neg)) {
-                b += w * win_buckets;
+                b += win_base(NWIN, w, win_buckets, narrow_buckets);
                 const uint32_t rg = b >> LO_BITS, slot = cnt[rg] + rank[w];
                 st_key[slot] = (rg << 16) | (b & ((1u << LO_BITS) - 1));
                 st_val[slot] = (uint32_t)(((size_t)w * tbl_stride + base_index + i) << 1) | neg;
@@ -1179,8 +1186,12 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
     const bool wide = tb.wide;
     if ((wide && !plain) || (wide && async_res)) return PM_ERR_INVALID_ARG;
     const size_t NB1 = (size_t)1 << (c - 1);               // buckets of one window
-    const size_t NB = wide ? NB1 * nwin : NB1;             // buckets of the pipeline: one shared set, or one set per window
-    const uint32_t win_buckets = wide ? (uint32_t)NB1 : 0u;
+    // buckets of the pipeline: one shared set, or one set per window -- 2^(c-1) for the 256 % nwin windows of c bits, half of that for
+    // the narrower ones (round 6; wide_narrow_buckets)
+    const size_t NBn = wide ? wide_narrow_buckets(nwin, c) : 0;
+    const unsigned n_wide_sets = !wide ? 1u : (NBn == NB1 ? nwin : 256 % nwin), n_narrow_sets = wide ? nwin - n_wide_sets : 0u;
+    const size_t NB = (size_t)n_wide_sets * NB1 + (size_t)n_narrow_sets * NBn;
+    const uint32_t win_buckets = wide ? (uint32_t)NB1 : 0u, narrow_buckets = (uint32_t)NBn;
     const unsigned lo_buckets = (unsigned)(NB < ((size_t)1 << LO_BITS) ? NB : ((size_t)1 << LO_BITS));
     const unsigned regions = (unsigned)(NB / lo_buckets);
     if (regions > 1024 || (size_t)regions * lo_buckets != NB) return PM_ERR_INVALID_ARG;   // whole regions only (wide mode: nwin 2^(c-1) buckets)
@@ -1223,7 +1234,10 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
 #endif
     // scalars per partition workgroup.  More than 512 regions (the 768 of a 12-window wide plan): 1024, so that a workgroup's run
     // inside a region is 16 entries (64 B of values), not 8 -- same-box A/B at 2^24 gates in profiles/r06_wide_12_windows_ab.txt
-    const unsigned pbd = regions > 512 ? PM_PARTITION_WIDE_LANES : nwin <= 16 ? PM_PARTITION_LANES : 256;
+#ifndef PM_PARTITION_WIDE_FROM
+#define PM_PARTITION_WIDE_FROM 512
+#endif
+    const unsigned pbd = regions >= PM_PARTITION_WIDE_FROM ? PM_PARTITION_WIDE_LANES : nwin <= 16 ? PM_PARTITION_LANES : 256;
     if (regions > 2 * pbd) return PM_ERR_INVALID_ARG;                  // at most two regions per scan lane (k_tbl_partition)
     const size_t plds = 2 * 1024 * 4 + (size_t)pbd * nwin * 8;
     {
@@ -1256,7 +1270,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
 #define PM_TBL_CASE(NW)                                                                                                     \
         case NW:                                                                                                                \
             hipLaunchKernelGGL((k_tbl_count<FrP, NW>), dim3(pblocks), dim3(pbd), 0, st, sc, inf, cnt, regions,                  \
-                               block_cnt, win_buckets);                                                                         \
+                               block_cnt, win_buckets, narrow_buckets);                                                         \
             hipLaunchKernelGGL(k_block_sums, dim3(bsh.G), dim3(1024), 0, st, block_cnt, pblocks, regions, bsh, block_partial);  \
             hipLaunchKernelGGL(k_block_offsets, dim3(bsh.G), dim3(1024), 0, st, block_cnt, pblocks, regions, bsh, block_partial, \
                                region_count);                                                                                  \
@@ -1266,7 +1280,7 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
                                     (int)plds) != hipSuccess) break;                                                            \
             hipLaunchKernelGGL((k_tbl_partition<FrP, NW>), dim3(pblocks), dim3(pbd), plds, st, sc, inf, cnt,                    \
                                regions, region_off, block_cnt, wide ? (size_t)0 : tb.stride, tb.base_index + lo, keys, vals,    \
-                               win_buckets);                                                                                    \
+                               win_buckets, narrow_buckets);                                                                    \
             launched = 1;                                                                                                       \
             break;
         switch (nwin) {
@@ -1356,8 +1370,12 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
             StageTimer t(ctx, T_MSM_REDUCE);
             PM_TRY(fold_hot_buckets<C>(ctx, S, NB, max_tasks));
             XYZZ<C> *dres = nullptr;
-            PM_TRY(reduce_two_level<C>(ctx, NB1, &dres, nwin));
-            PM_HIP(ctx, hipMemcpyAsync(hS.data(), dres, nwin * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
+            PM_TRY(reduce_two_level<C>(ctx, NB1, &dres, n_wide_sets));                       // the sets of the c-bit windows ...
+            PM_HIP(ctx, hipMemcpyAsync(hS.data(), dres, n_wide_sets * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
+            if (n_narrow_sets) {                                                             // ... then those of the (c - 1)-bit ones (stream order:
+                PM_TRY(reduce_two_level<C>(ctx, NBn, &dres, n_narrow_sets, (size_t)n_wide_sets * NB1));   // the workspace is free again)
+                PM_HIP(ctx, hipMemcpyAsync(hS.data() + n_wide_sets, dres, n_narrow_sets * sizeof(XYZZ<C>), hipMemcpyDeviceToHost, ctx->stream));
+            }
         }
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         XYZZ<C> acc = XYZZ<C>::identity();

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // ctx->msm: three launches on ctx->stream, the nsets results (internal form) at (*out)[0 .. nsets) in the workspace.  nsets = 1:
 // the shared bucket set of the window-table MSM; nsets = windows: the wide-window MSM without tables.
 template <class C>
-int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets) {
+int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets, size_t bucket0) {
     MsmWorkspace &ws = ctx->msm;
     const MsmSet *S = &ws.set;
     if (nsets == 0 || (NB & (NB - 1)) != 0) return PM_ERR_INVALID_ARG;
@@ -249,7 +249,7 @@ int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets) {
     PM_HIP(ctx, ws.wsum.reserve((2 * lanes0 + (blocks0 > blocks1 ? blocks0 : blocks1) + 4 + nsets) * sizeof(XYZZ<C>)));
     XYZZ<C> *A = ws.wsum.as<XYZZ<C>>(), *Acc = A + lanes0, *parts = Acc + lanes0, *dres = parts + (blocks0 > blocks1 ? blocks0 : blocks1);
     hipLaunchKernelGGL(k_reduce_level0<C>, dim3((unsigned)blocks0), dim3(256), 256 * sizeof(XYZZ28<C>), ctx->stream,
-                       S->partials.as<XYZZ<C>>(), S->task_off.as<uint32_t>(), S->task_cnt.as<uint32_t>(), total, lanes0, K0, A, Acc);
+                       S->partials.as<XYZZ<C>>(), S->task_off.as<uint32_t>() + bucket0, S->task_cnt.as<uint32_t>() + bucket0, total, lanes0, K0, A, Acc);
     PM_HIP(ctx, hipGetLastError());
     const unsigned per_set = (unsigned)(blocks1 / nsets);     // level-1 workgroups (= partials) per set; exact when nsets > 1
     hipLaunchKernelGGL((k_reduce_level1_coop<C, 4>), dim3((unsigned)blocks1), dim3(256), 64 * sizeof(XYZZ28<C>), ctx->stream, A, Acc,
@@ -261,7 +261,7 @@ int reduce_two_level(pm_ctx *ctx, size_t NB, XYZZ<C> **out, unsigned nsets) {
     return PM_OK;
 }
 
-template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **, unsigned);
-template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **, unsigned);
+template int reduce_two_level<BlsCurve>(pm_ctx *, size_t, XYZZ<BlsCurve> **, unsigned, size_t);
+template int reduce_two_level<BnCurve>(pm_ctx *, size_t, XYZZ<BnCurve> **, unsigned, size_t);
 
 }  // namespace pm

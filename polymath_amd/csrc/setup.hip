@@ -336,13 +336,14 @@ MsmTables tables_plan(size_t total_pairs, unsigned n_msm, size_t resident_points
     return best_t;
 }
 
-// Plan of the WIDE mode (no tables: MsmTables::wide): every window has its own 2^(c-1) buckets.  piece = the pairs one bucket
-// pipeline covers (<= msm_max_piece()).  Cost in the units of tables_plan: nwin (piece + reduction of one bucket set), with the
-// sort front end's limit of 1024 regions of 2^15 buckets (k_tbl_partition: up to two regions per scan lane of its 512-lane
-// workgroups; until round 5 one region per lane = 512, which shut out 12 windows x 2^21 buckets = 768 regions) and >= 4096
-// buckets per window (the two-level reduction).  Long MSMs land on 12 windows of 22 / 21 bits: 12 additions per pair where the
-// LDS-histogram pipeline of the one-shot MSM stops at c = 16 (16 additions).  force_c (PM_OPT_TABLE_WINDOW_BITS, tuning / tests):
-// the widest window, whatever the cost model says.
+// Plan of the WIDE mode (no tables: MsmTables::wide): every window has its own bucket set -- 2^(c-1) buckets for the 256 % nwin
+// windows of c bits, half as many for the others (round 6: internal.h: wide_narrow_buckets; until then 2^(c-1) for all: 12 windows
+// of 22 / 21 bits reduced 25.2 M buckets instead of 16.8 M and sorted into 768 regions instead of 512).  piece = the pairs one
+// bucket pipeline covers (<= msm_max_piece()).  Cost in the units of tables_plan: accumulation of nwin x piece entries + the
+// reduction of all sets, within the sort front end's limit of 1024 regions of 2^15 buckets (k_tbl_partition: up to two regions
+// per scan lane) and >= 4096 buckets per window (the two-level reduction).  Long MSMs land on 12 windows of 22 / 21 bits: 12
+// additions per pair where the LDS-histogram pipeline of the one-shot MSM stops at c = 16 (16 additions).  force_c
+// (PM_OPT_TABLE_WINDOW_BITS, tuning / tests): the widest window, whatever the cost model says.
 MsmTables wide_plan(size_t piece, unsigned force_c) {
     MsmTables best_t;
     double best = 1e300;
@@ -350,18 +351,18 @@ MsmTables wide_plan(size_t piece, unsigned force_c) {
         MsmTables t;
         tables_layout(t, nwin);
         if (t.c < 16 || t.c > 23) continue;                                   // whole 2^15-bucket regions per window (the sort's first level)
-        const double NB = (double)((size_t)1 << (t.c - 1));
 #ifndef PM_WIDE_MAX_REGIONS
 #define PM_WIDE_MAX_REGIONS 1024          // same-box A/B against round 5's front end: PM_BUILD_FLAGS=-DPM_WIDE_MAX_REGIONS=512
 #endif
-        if ((double)nwin * NB / 32768.0 > (double)PM_WIDE_MAX_REGIONS) continue;
+        const double NBT = (double)wide_total_buckets(nwin, t.c);              // all sets: the narrower windows own half as many (round 6)
+        if (NBT / 32768.0 > (double)PM_WIDE_MAX_REGIONS) continue;
         if ((double)nwin * (double)piece >= 4294967296.0) continue;          // u32 positions of the sorted entries
         if (force_c >= 16 && force_c <= 23) {
             if (t.c == force_c) { best_t = t; break; }
             continue;
         }
         const double E = (double)nwin * (double)piece;
-        const double cost = std::max(E, E / (NB * nwin) * 135e3) + 3.3e6 + 3.3 * NB * nwin;   // ONE batched reduction over all sets
+        const double cost = std::max(E, E / NBT * 135e3) + 3.3e6 + 3.3 * NBT;   // the sets are reduced in one or two batched launches
         if (cost < best) { best = cost; best_t = t; }
     }
     best_t.wide = best_t.c != 0;

@@ -51,8 +51,9 @@ def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, lo
     import os
     wide22 = tables == "wide22"
     if wide22:
-        # the plan a 2^24-gate key's [c]_1 / [d]_1 get on one GPU (round 6): 12 windows of 22 / 21 bits = 768 regions of 2^15 buckets,
-        # two regions per scan lane in k_tbl_partition -- forced here at a size the CPU restatement can check bit for bit
+        # the plan a 2^24-gate key's [c]_1 / [d]_1 get on one GPU (round 6): 12 windows of 22 / 21 bits, four bucket sets of 2^21 and
+        # eight of 2^20 (512 regions of 2^15 buckets, two batched reductions) -- forced here at a size the CPU restatement can check
+        # bit for bit
         tables = "wide"
         gpu_ctx.set_option("table_window_bits", 22)
     gpu_ctx.set_option("tables", TABLES_OPT[tables])        # read by pm_pk_generate below; restored by conftest
@@ -150,8 +151,8 @@ def test_config_2p22_one_gpu():
 def test_config_2p24_one_gpu_piece_split():
     """BASELINE configs[3] circuit (2^24-100 gates, n = 2^25, 470 M MSM pairs) on ONE GPU: nine-stage NTT passes, and the
     335 M-pair quotient MSM runs in > 2^27-pair pieces (msm.hip: msm_run).  Its window tables would take 515 GB, so the key runs
-    it (and the 100 M-pair [c]_1) in the WIDE mode: 12 windows of 22 / 21 bits on the plain base array (768 regions of 2^15
-    buckets in the sort's first level: two per scan lane, round 6), 12 additions per pair instead of the per-window
+    it (and the 100 M-pair [c]_1) in the WIDE mode: 12 windows of 22 / 21 bits on the plain base array (16.8 M buckets in sets of
+    2^21 / 2^20 = 512 regions of the sort's first level, round 6), 12 additions per pair instead of the per-window
     pipeline's 16 (pm_pk_msm_plan shows the plan)."""
     plans = _full_size_config("bls12_381", 24, 0x2424)
     assert plans[2][0] == 10 * (1 << 25) + 22 and plans[2][0] > (1 << 27)
