@@ -38,6 +38,9 @@ _ORACLE_AT_SIZE = {}       # (curve, log_nr) -> the oracle's proof, transcript t
 
 # grouped by (curve, size): the CPU restatement's proof is computed for the first of a group and reused by the others
 _AT_SIZE_CASES = [(cv, lg, tb) for cv in CURVE_LIST for lg, modes in ((16, ("1", "0", "wide", "wide22")), (18, ("1", "0", "wide"))) for tb in modes]
+# the other window counts whose sets differ in size in the wide mode (13 x 20 / 19 bits, 14 x 19 / 18, 15 x 18 / 17): one curve each
+_AT_SIZE_CASES += [("bls12_381", 16, "wide20"), ("bn254", 16, "wide19"), ("bls12_381", 16, "wide18")]
+_AT_SIZE_CASES.sort(key=lambda t: (CURVE_LIST.index(t[0]), t[1]))      # keep the (curve, size) groups together: the oracle's proof is shared
 
 
 @pytest.mark.parametrize("curve,log_nr,tables", _AT_SIZE_CASES, ids=["%d-%s-%s" % (lg, tb, cv) for cv, lg, tb in _AT_SIZE_CASES])
@@ -49,13 +52,13 @@ def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, lo
     The CPU restatement's key is seeded with the GPU's exported bases (their parity is tested at mid size: the CPU
     setup would take minutes here); proof, challenges and all 8 intermediate vectors must be identical."""
     import os
-    wide22 = tables == "wide22"
-    if wide22:
-        # the plan a 2^24-gate key's [c]_1 / [d]_1 get on one GPU (round 6): 12 windows of 22 / 21 bits, four bucket sets of 2^21 and
-        # eight of 2^20 (512 regions of 2^15 buckets, two batched reductions) -- forced here at a size the CPU restatement can check
-        # bit for bit
+    wide_c = int(tables[4:]) if tables.startswith("wide") and len(tables) > 4 else 0
+    if wide_c:
+        # wide22: the plan a 2^24-gate key's [c]_1 / [d]_1 get on one GPU (round 6): 12 windows of 22 / 21 bits, four bucket sets of
+        # 2^21 and eight of 2^20 (512 regions of 2^15 buckets, two batched reductions) -- forced here at a size the CPU restatement
+        # can check bit for bit; wide20 / 19 / 18: 13 / 14 / 15 windows, 9 / 4 / 1 of them one bit wider than the rest
         tables = "wide"
-        gpu_ctx.set_option("table_window_bits", 22)
+        gpu_ctx.set_option("table_window_bits", wide_c)
     gpu_ctx.set_option("tables", TABLES_OPT[tables])        # read by pm_pk_generate below; restored by conftest
     from polymath_amd import circuits as PC
     from polymath_amd.polymath import Polymath
@@ -71,8 +74,9 @@ def test_whole_proof_bit_exact_vs_oracle_at_size(gpu_ctx, oracle, api, curve, lo
     assert gpk.msm_plan(2)[3] == (tables == "1")
     if tables == "wide":
         assert all(12 <= gpk.msm_plan(k)[1] <= 16 and gpk.msm_plan(k)[2] >= 16 for k in range(3))     # wide_plan: big windows, no tables
-    if wide22:
-        assert all(gpk.msm_plan(k)[1:] == (12, 22, False) for k in range(3)), [gpk.msm_plan(k) for k in range(3)]
+    if wide_c:
+        nwin = {22: 12, 20: 13, 19: 14, 18: 15}[wide_c]
+        assert all(gpk.msm_plan(k)[1:] == (nwin, wide_c, False) for k in range(3)), [gpk.msm_plan(k) for k in range(3)]
     threads = os.cpu_count() or 8
     TR = T.make_transcripts(c)
     cap = 10 * gpk.n + 64
