@@ -1232,8 +1232,10 @@ static int msm_piece_tables(pm_ctx *ctx, const MsmTables &tb, const Fp<typename 
 #ifndef PM_PARTITION_WIDE_LANES
 #define PM_PARTITION_WIDE_LANES 1024
 #endif
-    // scalars per partition workgroup.  More than 512 regions (the 768 of a 12-window wide plan): 1024, so that a workgroup's run
-    // inside a region is 16 entries (64 B of values), not 8 -- same-box A/B at 2^24 gates in profiles/r06_wide_12_windows_ab.txt
+    // scalars per partition workgroup.  From 512 regions up (the 12-window wide plan of a 2^24-gate key: 4 x 2^21 + 8 x 2^20 buckets):
+    // 1024, so that a workgroup's run inside a region is 24 entries (96 B of values), not 12 -- what the first level pays for is
+    // the length of that run, not the number of regions: same-box A/B at 2^24 gates in profiles/r06_wide_ragged_sets_ab.txt (512
+    // regions on 512 lanes: sort + 5 ... 8 ms against 768 regions on 1024) and r06_wide_12_windows_ab.txt
 #ifndef PM_PARTITION_WIDE_FROM
 #define PM_PARTITION_WIDE_FROM 512
 #endif
