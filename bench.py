@@ -370,8 +370,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-micro", default="20,22,24,26", help="log2 lengths of the standalone resident MSM legs ('' = none)")
     ap.add_argument("--ntt-micro", default="21,22,24", help="log2 sizes of the standalone resident NTT legs ('' = none)")
-    ap.add_argument("--other-configs", default="bn254:20,bls12_381:22",
-                    help="curve:log2(constraints) legs run after the headline on the same GPU (BASELINE.json configs[4], configs[2] on one GPU; '' = none)")
+    ap.add_argument("--other-configs", default="bn254:20,bls12_381:22,bls12_381:24",
+                    help="curve:log2(constraints) legs run after the headline on the same GPU (BASELINE.json configs[4], configs[2], configs[3] on one GPU; '' = none)")
     ap.add_argument("--inflight", type=int, default=2, help="proofs in flight of the serving-throughput leg beside `value` (0 = skip; single GPU only)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure `roofline.traffic`")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",

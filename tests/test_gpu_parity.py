@@ -529,7 +529,7 @@ def test_bench_two_ranks_one_gpu_same_proof():
     proof bytes as the single-rank run."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "1", "--warmup", "0", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
+    common = ["--steps", "1", "--warmup", "0", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic", "--other-configs", ""]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0")
@@ -558,7 +558,7 @@ def test_bench_gpus_2_starts_its_own_ranks():
      and the HBM-resident variant is reported beside it."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "2", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
+    common = ["--steps", "2", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic", "--other-configs", ""]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0")
@@ -584,7 +584,7 @@ def test_bench_fallback_chain_when_rccl_cannot_serve_the_job():
     fabric that will not come up, seen end to end: one JSON line, from a later attempt, with the single-GPU proof."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "2", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
+    common = ["--steps", "2", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic", "--other-configs", ""]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     env = dict(os.environ, BENCH_FORCE_DEVICE="0", BENCH_ATTEMPT_DEADLINE_S="300")
@@ -617,7 +617,7 @@ def test_bench_dead_rank_ends_the_job_non_zero():
     are covered by tests/test_sharded_vector.py.)"""
     import os, subprocess, sys, time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "100000", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
+    common = ["--steps", "100000", "--warmup", "1", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic", "--other-configs", ""]
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_FORCE_DEVICE="0", BENCH_TEST_DIE="1,3.0", BENCH_COMM_TIMEOUT_S="20")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)

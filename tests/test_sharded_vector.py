@@ -750,7 +750,7 @@ def test_bench_multi_gpu_launch_path_with_a_world_of_one():
     Same proof bytes as the plain single-GPU run, and the JSON line says the native communicator was used."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--steps", "1", "--warmup", "0", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic"]
+    common = ["--steps", "1", "--warmup", "0", "--log-constraints", "12", "--no-cpu-baseline", "--msm-micro", "", "--no-live-traffic", "--other-configs", ""]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-3000:]
     env = dict(os.environ, BENCH_FORCE_VECTOR="1")
